@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (it imports /root/reference, which does not
+exist on the GPU box).  Only tensors leave this script: inputs and the
+reference's outputs, as .npz.  No reference source text is stored.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Weights come from spatialalignmentnetwork_amd.synth.fill_params (keyed by
+state_dict name), inputs from synth.phantom_pair / Philox streams, so tests can
+regenerate identical inputs and only need the reference OUTPUTS from here.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("SAN_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+from spatialalignmentnetwork_amd import synth  # noqa: E402
+
+# ---- the reference (imported, never copied) --------------------------------
+import signal_utils as R_sig  # noqa: E402
+import varnet as R_varnet  # noqa: E402
+import cross as R_cross  # noqa: E402
+import ssimloss as R_ssim  # noqa: E402
+import lnccloss as R_lncc  # noqa: E402
+import masks as R_masks  # noqa: E402
+
+
+def _import_reference_model():
+    # model.py imports skimage (absent in this image) through metrics.py; only
+    # PSNR/SSIM reporting needs it, so satisfy the import with an empty stub.
+    import types
+    sk = types.ModuleType("skimage")
+    skm = types.ModuleType("skimage.metrics")
+    skm.structural_similarity = skm.peak_signal_noise_ratio = None
+    sk.metrics = skm
+    sys.modules.setdefault("skimage", sk)
+    sys.modules.setdefault("skimage.metrics", skm)
+    import model as R_model
+    return R_model
+
+
+R_model = _import_reference_model()
+R_gradient_loss = R_model.gradient_loss          # model.py:21-28
+
+
+def philox(name, shape, seed=0, lo=-1.0, hi=1.0):
+    g = synth._rng(name, seed)
+    return torch.from_numpy(g.uniform(lo, hi, shape)).float()
+
+
+def cplx(name, shape, seed=0):
+    return torch.complex(philox(name + ".re", shape, seed), philox(name + ".im", shape, seed))
+
+
+def npy(t):
+    t = t.detach()
+    if torch.is_complex(t):
+        return torch.view_as_real(t).numpy()
+    return t.numpy()
+
+
+def load_into(module, seed):
+    sd = module.state_dict()
+    vals = synth.fill_params([(k, tuple(v.shape)) for k, v in sd.items()], seed=seed)
+    module.load_state_dict(vals)
+    return vals
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrs)} arrays")
+
+
+# ---------------------------------------------------------------------------
+def make_ops():
+    out = {}
+    # fft2 / ifft2 / rss at three sizes (radix 2, 3, 5, 23 all occur)
+    for tag, shp in (("32", (2, 2, 32, 32)), ("48x80", (1, 3, 48, 80)), ("46x368", (1, 1, 46, 368))):
+        x = cplx("fft." + tag, shp)
+        out[f"fft2_{tag}"] = npy(R_sig.fft2(x))
+        out[f"ifft2_{tag}"] = npy(R_sig.ifft2(x))
+        out[f"rss_c_{tag}"] = npy(R_sig.rss(x))
+        out[f"rss_r_{tag}"] = npy(R_sig.rss(x.real.contiguous()))
+    # sens_reduce / sens_expand / one soft-DC combine
+    blk = R_varnet.VarNetBlock(torch.nn.Identity())
+    k = cplx("blk.k", (2, 3, 32, 48))
+    s = cplx("blk.s", (2, 3, 32, 48))
+    img = cplx("blk.img", (2, 1, 32, 48))
+    out["sens_reduce"] = npy(blk.sens_reduce(k, s))
+    out["sens_expand"] = npy(blk.sens_expand(img, s))
+    # NormUnet.norm / unnorm
+    nu = R_varnet.NormUnet(4, 2)
+    x2 = philox("nu.x", (3, 2, 32, 48)) * 3 + 0.7
+    xn, mean, std = nu.norm(x2)
+    out["norm_x"], out["norm_mean"], out["norm_std"] = npy(xn), npy(mean), npy(std)
+    out["unnorm"] = npy(nu.unnorm(xn, mean, std))
+    # ConvBlock / TransposeConvBlock
+    cb = R_varnet.ConvBlock(3, 6)
+    pv = load_into(cb, 11)
+    xin = philox("cb.x", (2, 3, 24, 40))
+    out["convblock"] = npy(cb(xin))
+    tb = R_varnet.TransposeConvBlock(6, 4)
+    load_into(tb, 12)
+    # NB: key lacks 'up_transpose_conv' so fan_in follows the conv rule; the test
+    # regenerates with the same names so this is consistent.
+    xin2 = philox("tb.x", (2, 6, 12, 20))
+    out["tconvblock"] = npy(tb(xin2))
+    # identity grid + warp with offsets up to a few pixels, some out of bounds
+    st = R_cross.SpatialTransformer(1)
+    imgw = philox("warp.img", (2, 2, 24, 40), lo=0.0, hi=1.0)
+    theta = torch.tensor([[[1.0, 0, 0], [0, 1, 0]]])
+    ident = torch.nn.functional.affine_grid(theta, (1, 2, 24, 40), align_corners=False)
+    off = philox("warp.off", (2, 24, 40, 2)) * 0.3
+    off[0, :2] += 1.5      # force rows fully outside
+    out["identity_grid"] = npy(ident)
+    out["warp"] = npy(st.warp(imgw, ident + off))
+    # losses
+    a = philox("loss.a", (2, 1, 40, 56), lo=0.0, hi=1.0)
+    b = (a + 0.1 * philox("loss.b", (2, 1, 40, 56))).clamp(0, 1)
+    out["ssimloss"] = npy(R_ssim.ssimloss(a, b))
+    out["lncc"] = npy(R_lncc.lncc_loss(a, b))
+    out["ms_lncc"] = npy(R_lncc.ms_lncc_loss(a, b))
+    out["gradient_loss"] = npy(R_gradient_loss(off))
+    # ACS window (varnet.py:395-397) for the three benchmark settings
+    for w, nlf in ((320, 25), (320, 12), (368, 14), (32, 2), (80, 6)):
+        m = torch.ones(w)
+        m[nlf:] = 0
+        m = torch.roll(m, -nlf // 2)
+        out[f"acs_{w}_{nlf}"] = npy(m)
+    # masks: Equispaced is random in its start; record start-0 equivalents by
+    # seeding python's random until start == 0 is drawn is fragile -> instead
+    # record (seed -> pruned) pairs and the test checks our generator can
+    # reproduce each of them for SOME legal start.
+    import random
+    for w, sp in ((320, 0.25), (320, 0.125), (368, 0.125)):
+        random.seed(w + int(sp * 1000))
+        m = R_masks.EquispacedMask(sp, w)
+        out[f"equispaced_{w}_{int(1 / sp)}"] = m.pruned.numpy()
+        lp = R_masks.LowpassMask(sp, w)
+        out[f"lowpass_{w}_{int(1 / sp)}"] = lp.pruned.numpy()
+    save("ops_small.npz", **out)
+
+
+# ---------------------------------------------------------------------------
+def run_pair(n, c, h, w, sparsity, num_cascades, chans, sens_chans, pools, seed, training):
+    """set_input + forwardT + forwardR exactly as model.py:89-169 composes them,
+    using the reference's modules."""
+    img_full, img_aux = synth.phantom_pair(n, c, h, w, seed=seed)
+    pruned = synth.equispaced_pruned(w, sparsity, start=0)
+    net_T = R_cross.SpatialTransformer(channels=c)
+    net_R = R_varnet.VarNet(num_cascades=num_cascades, sens_chans=sens_chans, sens_pools=pools,
+                            chans=chans, pools=pools, use_ref=True)
+    load_into(net_T, seed + 1)
+    load_into(net_R, seed + 2)
+    net_T.train(training)
+    net_R.train(training)
+    k_full = R_sig.fft2(img_full)
+    k_samp = k_full * (1 - pruned.float())
+    samp = R_sig.ifft2(k_samp)
+    offset, grid = net_T(moving=img_aux.abs(), fixed=samp.abs())
+    warped = net_T.warp(img_aux.abs(), grid)
+    loss_smooth = R_gradient_loss(offset)
+    nlf = int(w * sparsity * 0.32)
+    rec = net_R(masked_kspace=k_samp, mask=torch.logical_not(pruned), ref=warped, num_low_frequencies=nlf)
+    full_rss = R_sig.rss(img_full)
+    loss_sim = R_ssim.ssimloss(full_rss, rec)
+    res = dict(img_k_sampled=k_samp, img_sampled=samp, img_offset=offset, img_grid=grid,
+               img_warped=warped, img_rec=rec, img_full_rss=full_rss,
+               loss_smooth=loss_smooth, loss_sim=loss_sim)
+    return net_T, net_R, img_full, img_aux, pruned, res
+
+
+def make_e2e_small():
+    for tag, (n, c, h, w) in (("32", (2, 1, 32, 32)), ("48x80c3", (2, 3, 48, 80))):
+        sparsity = 0.25
+        out = {}
+        # eval-mode forward (BN running stats)
+        _, _, _, _, pruned, res = run_pair(n, c, h, w, sparsity, 2, 4, 2, 2, seed=40, training=False)
+        out["pruned"] = pruned.numpy()
+        for k_, v in res.items():
+            out["eval." + k_] = npy(v)
+        # train-mode forward + backward of the 'Rec' objective (model.py:206-216)
+        net_T, net_R, _, _, _, res = run_pair(n, c, h, w, sparsity, 2, 4, 2, 2, seed=40, training=True)
+        loss = res["loss_smooth"] * 1000.0 + res["loss_sim"] * 1.0
+        loss.backward()
+        for k_, v in res.items():
+            out["train." + k_] = npy(v)
+        out["train.loss_all"] = npy(loss)
+        for nm, prm in net_T.named_parameters():
+            out["grad.T." + nm] = prm.grad.numpy()
+        for nm, prm in net_R.named_parameters():
+            out["grad.R." + nm] = prm.grad.numpy()
+        for nm, buf in net_T.named_buffers():
+            if nm.endswith(("running_mean", "running_var")):
+                out["bn_after.T." + nm] = buf.numpy()
+        save(f"e2e_small_{tag}.npz", **out)
+
+
+def make_e2e_full():
+    """Config-2 shape (320x320, 12 cascades, chans 18, sens_chans 8), N=1, eval."""
+    n, c, h, w = 1, 1, 320, 320
+    net_T, net_R, img_full, img_aux, pruned, res = run_pair(
+        n, c, h, w, 0.25, 12, 18, 8, 4, seed=1234, training=False)
+    out = {"pruned": pruned.numpy(), "img_full_re": img_full.real.numpy(), "img_aux_re": img_aux.real.numpy()}
+    for k_ in ("img_offset", "img_warped", "img_rec", "loss_smooth", "loss_sim"):
+        out[k_] = npy(res[k_])
+    # per-cascade k-space checksums via forward hooks on the reference's cascades
+    sums = []
+    hooks = [cas.register_forward_hook(lambda m, i, o: sums.append(
+        [o.real.double().sum().item(), o.imag.double().sum().item(), o.abs().double().pow(2).sum().sqrt().item()]))
+        for cas in net_R.cascades]
+    with torch.no_grad():
+        net_R(masked_kspace=res["img_k_sampled"], mask=torch.logical_not(pruned), ref=res["img_warped"],
+              num_low_frequencies=int(w * 0.25 * 0.32))
+    for hk in hooks:
+        hk.remove()
+    out["cascade_checksums"] = np.asarray(sums)
+    # fp64 arbiter of the same network
+    net_T64, net_R64 = net_T.double(), net_R.double()
+    with torch.no_grad():
+        f64, a64 = img_full.to(torch.complex128), img_aux.to(torch.complex128)
+        k_samp = R_sig.fft2(f64) * (1 - pruned.double())
+        samp = R_sig.ifft2(k_samp)
+        off64, grid64 = net_T64(moving=a64.abs(), fixed=samp.abs())
+        # SpatialTransformer.warp force-casts to fp32 (cross.py:33-34); bypass for the arbiter
+        warped64 = torch.nn.functional.grid_sample(a64.abs(), grid64, align_corners=False)
+        rec64 = net_R64(masked_kspace=k_samp, mask=torch.logical_not(pruned), ref=warped64,
+                        num_low_frequencies=int(w * 0.25 * 0.32))
+    out["img_rec_f64"] = rec64.numpy()
+    out["img_warped_f64"] = warped64.numpy()
+    r32, r64 = res["img_rec"].detach().double(), rec64
+    print("reference fp32 vs fp64 rel-L2 (rec):", ((r32 - r64).norm() / r64.norm()).item())
+    save("e2e_full_320.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ops", "small", "full"]
+    with torch.no_grad():
+        if "ops" in which:
+            make_ops()
+    if "small" in which:
+        make_e2e_small()
+    if "full" in which:
+        make_e2e_full()
