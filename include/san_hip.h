@@ -1,0 +1,219 @@
+/*
+ * san_hip.h -- C ABI of libsan_hip.so: the MI355X (gfx950) kernels behind the
+ * reconstruction + alignment hot path of woxuankai/SpatialAlignmentNetwork.
+ *
+ * The reference has NO native/FFI layer (it is pure Python on PyTorch ATen), so
+ * there is no existing binding to inherit; each entry point below names the
+ * reference call site (file:line in the reference repo) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes stub a reference maintainer would
+ * add at each of those call sites.
+ *
+ * Conventions
+ *  - Plain C types only.  Every pointer is a DEVICE pointer unless it says "host".
+ *  - Ownership: the caller owns every buffer, including outputs and workspaces.
+ *    The library allocates device memory only for immutable twiddle tables
+ *    (once per FFT length per device; call san_fft_prepare() before hipGraph
+ *    capture).  It keeps no caller pointer after a call returns.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*); no
+ *    hidden synchronisation, nothing on the default stream.
+ *  - Real tensors are fp32 NCHW contiguous.  A "channel view" (ptr, ctot, coff)
+ *    addresses channels [coff, coff+C) of a tensor that has `ctot` channels, so
+ *    producers can write straight into a concatenation buffer.
+ *  - Complex tensors are interleaved (re, im) fp32 pairs = torch.view_as_real,
+ *    shape [N, C, H, W]; "planar" complex is a real [N, 2, H, W] (re plane,
+ *    im plane) = the reference's complex_to_chan_dim layout (varnet.py:246-248).
+ *  - Lazy normalisation: activations are stored RAW (conv output) next to a
+ *    per-(sample, channel) affine (scale, shift) and a LeakyReLU slope; every
+ *    consumer applies  lrelu(scale*x + shift, slope)  while loading.  A NULL
+ *    scale/shift pair means identity.
+ *  - Return value: 0 = success; negative = SAN_E_* argument error; positive =
+ *    a raw hipError_t from the launch.  Nothing throws across this boundary.
+ */
+#ifndef SAN_HIP_H
+#define SAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAN_OK 0
+#define SAN_E_ARG (-1)         /* bad pointer / dimension                       */
+#define SAN_E_UNSUPPORTED (-2) /* shape outside what the kernels are built for  */
+#define SAN_E_WORKSPACE (-3)   /* workspace too small                           */
+
+/* norm finalisation modes (san_norm_finalize) */
+#define SAN_NORM_INSTANCE 0 /* InstanceNorm2d: biased var, eps inside sqrt (varnet.py:141) */
+#define SAN_NORM_GROUP 1    /* NormUnet.norm: unbiased std, eps added to std (varnet.py:257-268) */
+#define SAN_NORM_BATCH 2    /* BatchNorm2d training: batch stats over N,H,W (unet.py:125)        */
+
+const char* san_last_error_string(void);
+int san_version(void);
+
+/* ---------------------------------------------------------------- FFT + DC */
+
+/* Build (and cache) the twiddle tables for lengths h and w on the current
+ * device.  Optional; required before capturing FFT calls into a hipGraph. */
+int san_fft_prepare(int h, int w);
+
+/* Bytes of workspace the FFT-based entry points need for [planes, h, w]. */
+size_t san_fft_workspace_bytes(int planes, int h, int w);
+
+/* out = (i)fft2(in * colmask_in[w]) * colmask_out[w], ortho norm, no shift.
+ * in/out: interleaved complex [planes, h, w]; masks: fp32 [w] or NULL.
+ * planar_ctot == 0: interleaved output.  planar_ctot >= 2: write PLANAR into a
+ * real tensor [planes, planar_ctot, h, w] (re -> channel 0, im -> channel 1).
+ * Replaces signal_utils.py:4-12 (fft2/ifft2), model.py:110-114 (set_input),
+ * varnet.py:395-402 (ACS window + ifft2). */
+int san_fft2(const float* in, float* out, int planes, int h, int w, int inverse,
+             const float* colmask_in, const float* colmask_out, int planar_ctot,
+             void* ws, size_t ws_bytes, void* stream);
+
+/* m[n] = sum_c ifft2(k[n,c]) * conj(sens[n,c]); out is PLANAR: channels 0 (re)
+ * and 1 (im) of a real tensor [n, out_ctot, h, w] (out_ctot = 3 when the
+ * reference image rides along as channel 2: varnet.py:319).
+ * Replaces VarNetBlock.sens_reduce (varnet.py:511-512) + complex_to_chan_dim. */
+int san_sens_reduce(const float* k, const float* sens, float* out_planar, int out_ctot, int n, int c, int h, int w,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* k_out = k - dc_w * mask[w] * (k - k0) - fft2(r * sens)   with r PLANAR [n,2,h,w].
+ * mask: fp32 [w] (1 = sampled column); dc_w: device pointer to one fp32.
+ * Replaces chan_dim_to_complex + sens_expand + soft DC + combine
+ * (varnet.py:250-255, :508-509, :527-530). k_out may alias k. */
+int san_sens_expand_dc(const float* r_planar, const float* sens, const float* k, const float* k0,
+                       const float* mask, const float* dc_w, float* k_out, int n, int c, int h, int w,
+                       void* ws, size_t ws_bytes, void* stream);
+
+/* out[n,0] = sqrt(sum_c |ifft2(k[n,c])|^2)   (real [n,1,h,w]).
+ * Replaces rss(ifft2(kspace_pred)) (varnet.py:486). */
+int san_ifft2_rss(const float* k, float* out, int n, int c, int h, int w,
+                  void* ws, size_t ws_bytes, void* stream);
+
+/* sens[n,c] = est[n,c] / (rss_c(est[n]) + 1e-6), est PLANAR [n*c, 2, h, w] ->
+ * sens interleaved [n, c, h, w].  Replaces varnet.py:418-419. */
+int san_sens_normalize(const float* est_planar, float* sens, int n, int c, int h, int w, void* stream);
+
+/* out[n,0] = sqrt(sum_c x^2) for real x, or sqrt(sum_c re^2+im^2) for complex
+ * interleaved x.  Replaces signal_utils.rss (signal_utils.py:24-26). */
+int san_rss(const float* x, float* out, int n, int c, int hw, int is_complex, void* stream);
+
+/* ------------------------------------------------------- conv / norm stack */
+
+/* Repack conv weights for the scalar-operand direct convolution:
+ * w [cout, cin, ks, ks] -> packed [groups][cin][ks*ks][co_t], zero padded.
+ * transposed != 0 reads a ConvTranspose2d weight [cin, cout, ks, ks].
+ * san_conv_packed_floats gives the element count of `packed`. */
+size_t san_conv_packed_floats(int cout, int cin, int ks);
+int san_conv_pack_weights(const float* w, float* packed, int cout, int cin, int ks, int transposed,
+                          void* stream);
+
+/* y[n, y_coff+co] = bias[co] + sum_{ci,ky,kx} Wp[co,ci,ky,kx] * T(x)[n, x_coff+ci, .+ky-p, .+kx-p]
+ * with T = lazy normalisation (in_scale/in_shift, in_slope),
+ * zero padding applied AFTER T.  ks in {1, 3}.  Optional output affine
+ * y = y*out_scale[n,co] + out_shift[n,co] (used for NormUnet.unnorm).
+ * in_scale/in_shift are laid out like x's channel axis: fp32 [n, x_ctot],
+ * read at [n, x_coff + ci].
+ * If part_stats != NULL the kernel also writes per-tile (count, mean, M2) of the
+ * raw output for every (n, co): fp32 [n, cout, tiles, 3], tiles from
+ * san_conv_stat_tiles(h, w, cin, cout, ks); feed them to san_norm_finalize.
+ * Replaces F.conv2d at varnet.py:78,140,143 and unet.py:119-140,185-186. */
+int san_conv_stat_tiles(int h, int w, int cin, int cout, int ks);
+int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin,
+                   const float* in_scale, const float* in_shift, float in_slope,
+                   const float* w_packed, const float* bias,
+                   float* y, int y_ctot, int y_coff, int cout,
+                   const float* out_scale, const float* out_shift,
+                   float* part_stats,
+                   int n, int h, int w, int ks, void* stream);
+
+/* ConvTranspose2d 2x2 stride 2, no bias: y [n, cout, 2h, 2w].
+ * w_packed from san_conv_pack_weights(..., ks=2, transposed=1).
+ * part_stats: fp32 [n, cout, san_tconv_stat_tiles(h, w, cout), 3].
+ * Replaces nn.ConvTranspose2d at varnet.py:177-179. */
+int san_tconv_stat_tiles(int h, int w, int cout);
+int san_tconv2x2_fwd(const float* x, int x_ctot, int x_coff, int cin,
+                     const float* in_scale, const float* in_shift, float in_slope,
+                     const float* w_packed,
+                     float* y, int y_ctot, int y_coff, int cout,
+                     float* part_stats,
+                     int n, int h, int w, void* stream);
+
+/* Merge per-tile partials into the lazy-normalisation affine of the tensor:
+ *   INSTANCE: scale = rsqrt(var_b + eps),        shift = -mean*scale   per (n,c)
+ *   GROUP   : scale = 1/(std_unbiased + eps),    shift = -mean*scale   per (n,c);
+ *             also aux_a[n,c] = std, aux_b[n,c] = mean (for unnorm)
+ *   BATCH   : stats over all n; scale = gamma*rsqrt(var_b+eps), shift = beta-mean*scale,
+ *             broadcast to every n; aux_a[c] = batch mean, aux_b[c] = unbiased
+ *             batch var (for the running-stat update).
+ * part: fp32 [n, c, tiles, 3]; scale/shift: fp32 views [n, sc_ctot] at channel
+ * offset sc_coff.  Replaces the statistics half of InstanceNorm2d / x.std() /
+ * BatchNorm2d (varnet.py:141,235,257-268; unet.py:125). */
+int san_norm_finalize(const float* part, int n, int c, int tiles, int mode, float eps,
+                      const float* gamma, const float* beta,
+                      float* scale, float* shift, int sc_ctot, int sc_coff,
+                      float* aux_a, float* aux_b, void* stream);
+
+/* Per-plane (count, mean, M2) partials of an existing tensor view, one tile per
+ * plane: part [n, c, 1, 3].  Used for tensors no conv produced (ref image,
+ * sens_reduce output). */
+int san_plane_stats(const float* x, int x_ctot, int x_coff, int c, int n, int hw,
+                    float* part, void* stream);
+
+/* Eval-mode BatchNorm as a lazy affine: scale = gamma*rsqrt(rvar+eps),
+ * shift = beta - rmean*scale, broadcast over n.  (unet.py:125 in eval()). */
+int san_bn_eval_affine(const float* gamma, const float* beta, const float* rmean, const float* rvar,
+                       float eps, float* scale, float* shift, int sc_ctot, int sc_coff,
+                       int n, int c, void* stream);
+
+/* Element-wise materialisers, all of the form  y = op(T(x)):
+ *   avgpool2 : y [n,c,h/2,w/2] = mean of 2x2 block       (varnet.py:98, unet.py:137)
+ *   upsample2: y [n,c,2h,2w]   = nearest                 (unet.py:130)
+ *   add      : y = T_a(a) + T_b(b)                       (unet.py:24 ResSequential)
+ *   apply    : y = T(x)                                   (plain materialise)
+ */
+int san_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
+                     float* y, int y_ctot, int y_coff, int n, int c, int h, int w, void* stream);
+int san_upsample2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
+                      float* y, int y_ctot, int y_coff, int n, int c, int h, int w, void* stream);
+int san_add_fwd(const float* a, int a_ctot, int a_coff, const float* a_sc, const float* a_sh, float a_slope,
+                const float* b, int b_ctot, int b_coff, const float* b_sc, const float* b_sh, float b_slope,
+                float* y, int y_ctot, int y_coff, int n, int c, int hw, void* stream);
+int san_apply_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
+                  float* y, int y_ctot, int y_coff, int n, int c, int hw, void* stream);
+
+/* -------------------------------------------------------- warp and losses */
+
+/* out[n,c,i,j] = bilinear sample of img[n,c] at identity_grid(i,j) + offset[n,:,i,j]
+ * (zeros padding, align_corners=False).  offset is NCHW [n, 2, h, w] (channel 0
+ * = x, 1 = y, normalised units) = the alignment head's raw output, i.e. the
+ * reference's NHWC `offset` before its permute; grid_out (optional, NHWC
+ * [n,h,w,2]) receives identity + offset.  padding: 0 zeros, 1 reflection.
+ * Replaces affine_grid + add + F.grid_sample (cross.py:24-34; augment.py:60). */
+int san_warp_fwd(const float* img, const float* offset, float* out, float* grid_out,
+                 int n, int c, int h, int w, int padding, void* stream);
+
+/* Generic sampler: explicit NHWC grid [n, ho, wo, 2]. */
+int san_grid_sample_fwd(const float* img, const float* grid, float* out,
+                        int n, int c, int h, int w, int ho, int wo, int padding, void* stream);
+
+/* loss[0] = 1 - mean SSIM(x, y), 7x7 uniform valid window (ssimloss.py:11-40).
+ * ws: fp32 [san_loss_workspace_floats(n, h, w)]. */
+size_t san_loss_workspace_floats(int n, int h, int w);
+int san_ssim_loss_fwd(const float* x, const float* y, float* loss, int n, int h, int w,
+                      float* ws, void* stream);
+
+/* loss[0] = -mean(cross^2/(Ivar*Jvar+1e-5)), win x win zero padded box sums
+ * (lnccloss.py:7-56). */
+int san_lncc_loss_fwd(const float* i, const float* j, float* loss, int n, int h, int w, int win,
+                      float* ws, void* stream);
+
+/* loss[0] = (mean(dW^2) + mean(dH^2))/2 of an offset field given as NCHW
+ * [n, 2, h, w] (model.py:21-28 on the permuted view). */
+int san_gradient_loss_fwd(const float* offset, float* loss, int n, int h, int w, float* ws, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAN_HIP_H */

@@ -1,0 +1,90 @@
+"""ctypes binding of libsan_hip.so (the C ABI declared in include/san_hip.h).
+
+The prototypes are parsed from the header itself, so the binding cannot drift
+from the ABI and a test can check that every declared symbol is exported.
+There is NO fallback: if the shared object is missing or a symbol is absent the
+import raises, and every product entry point goes through this module.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libsan_hip.so links against)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), "include", "san_hip.h")
+LIB_PATH = os.path.join(HERE, "libsan_hip.so")
+
+_CT = {
+    "int": ctypes.c_int,
+    "float": ctypes.c_float,
+    "double": ctypes.c_double,
+    "size_t": ctypes.c_size_t,
+}
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[object, List[object]]]:
+    """{function name: (restype, [argtypes])} for every prototype in the header."""
+    text = open(path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int|size_t)\s+(san_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = ctypes.c_char_p if "char" in ret else _CT[ret]
+        argtypes = []
+        args = args.strip()
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                else:
+                    argtypes.append(_CT[a.split()[0] if a.split()[0] != "const" else a.split()[1]])
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+class SanLibrary:
+    def __init__(self, path: str = LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -m spatialalignmentnetwork_amd.build` "
+                "(there is no CPU or PyTorch fallback for the hot path)")
+        self._dll = ctypes.CDLL(path)
+        self.protos = parse_header()
+        for name, (restype, argtypes) in self.protos.items():
+            try:
+                fn = getattr(self._dll, name)
+            except AttributeError as e:  # pragma: no cover
+                raise RuntimeError(f"libsan_hip.so does not export {name}") from e
+            fn.restype = restype
+            fn.argtypes = argtypes
+            setattr(self, "_" + name, fn)
+
+    def last_error(self) -> str:
+        return self._san_last_error_string().decode()
+
+    def call(self, name: str, *args):
+        """Call an int-returning entry point; raise RuntimeError on failure."""
+        rc = getattr(self, "_" + name)(*args)
+        if rc != 0:
+            kind = "argument error" if rc < 0 else "hipError_t"
+            raise RuntimeError(f"{name} failed ({kind} {rc}): {self.last_error()}")
+
+    def query(self, name: str, *args):
+        """Call a size/count query (returns its value)."""
+        return getattr(self, "_" + name)(*args)
+
+
+_LIB = None
+
+
+def lib() -> SanLibrary:
+    global _LIB
+    if _LIB is None:
+        _LIB = SanLibrary()
+    return _LIB

@@ -1,0 +1,49 @@
+"""Host-side mirror of the reference's cross.py (SpatialTransformer) on the HIP
+kernels.  Reference: cross.py:9-38."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import Act, GLOBAL_ARENA as ARENA
+from .unet import UNet
+
+
+class SpatialTransformer(torch.nn.Module):
+    """Alignment network: UNet(2C -> 32) -> LeakyReLU -> conv3x3(32 -> 2) predicts a
+    displacement field in normalised coordinates (x, y); ``warp`` resamples with it."""
+
+    def __init__(self, channels=1):
+        super().__init__()
+        self.channels = channels
+        self.net = torch.nn.Sequential(
+            UNet(2 * channels, 32, (32, 64, 64, 64, 64)),
+            torch.nn.LeakyReLU(inplace=True),
+            torch.nn.Conv2d(32, 2, kernel_size=3, padding=1))
+        # the reference zero-initialises the head so training starts from the identity warp (cross.py:20-21)
+        torch.nn.init.zeros_(self.net[-1].weight)
+        torch.nn.init.zeros_(self.net[-1].bias)
+
+    def forward(self, moving, fixed, features=None):
+        """Returns (offset [N,H,W,2], grid [N,H,W,2]) like cross.py:23-30.  The
+        offset is a permuted view of the head's NCHW output, as in the reference."""
+        n, c, h, w = moving.shape
+        dev = moving.device
+        xin = Act(ARENA.get("align.in", (n, 2 * c, h, w), dev), 0, 2 * c)
+        ops.apply(ops.full(moving.contiguous()), xin.view(0, c))      # torch.cat([moving, fixed], 1)
+        ops.apply(ops.full(fixed.contiguous()), xin.view(c, c))
+        feat = Act(ARENA.get("align.feat", (n, 32, h, w), dev), 0, 32, None, None, 0.01)   # LeakyReLU read lazily
+        self.net[0].run(xin, feat)
+        head = self.net[2]
+        offset_nchw = torch.empty((n, 2, h, w), device=dev)
+        ops.conv2d(feat, head.weight, head.bias, ops.full(offset_nchw))
+        grid = torch.empty((n, h, w, 2), device=dev)
+        # grid = affine_grid(identity) + offset (cross.py:24-29): c == 0 asks the warp kernel for the grid only
+        ops.lib().call("san_warp_fwd", ops._p(None), ops._p(offset_nchw), ops._p(None), ops._p(grid), n, 0, h, w, 0,
+                       ops._stream())
+        self._last_offset_nchw = offset_nchw
+        return offset_nchw.permute(0, 2, 3, 1), grid
+
+    def warp(self, img, grid, interp=False):
+        """Bilinear, zeros padding, align_corners=False; inputs forced to fp32 (cross.py:32-38)."""
+        return ops.grid_sample(img.float().contiguous(), grid.float().contiguous())

@@ -1,0 +1,714 @@
+// 2-D complex FFT with fused k-space prologues/epilogues for gfx950.
+//
+// A 2-D transform of an H x W plane is two batched 1-D passes.  One plane
+// (320 x 320 x 8 B = 800 KiB) does not fit a CU's 160 KiB LDS, so each pass
+// stages a batch of B lines in LDS, runs a mixed-radix Stockham autosort FFT on
+// them (twiddles staged in LDS, ping-pong buffers), and touches global memory
+// exactly once on the way in and once on the way out.  Everything the reference
+// does around its torch.fft calls (sensitivity multiply, coil sum, soft data
+// consistency, root-sum-of-squares, column masks, planar<->complex) is folded
+// into those two touches, so the only extra HBM traffic is the inter-pass
+// intermediate, which is L2/MALL sized (N*C*H*W*8 B).
+//
+//   row pass   : B full rows per workgroup, contiguous 8-byte-per-lane accesses
+//   column pass: a tile of B adjacent columns x H rows per workgroup; B*8-byte
+//                contiguous segments per row (64 or 128 B), LDS pitch H+1 to
+//                keep the transposing stores conflict-free.
+#include "san_common.h"
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxRad = 12;
+
+enum RowPro { RP_NONE = 0, RP_PLANAR_MUL_SENS = 1 };
+enum RowEpi { RE_STORE = 0, RE_STORE_PLANAR = 1, RE_CONJ_SENS_SUM_PLANAR = 2, RE_RSS = 3 };
+enum ColEpi { CE_STORE = 0, CE_DC = 1 };
+
+struct FftArgs {
+    const float2* in;
+    float2* out;
+    const float* in_planar;  // RP_PLANAR_MUL_SENS: [n, 2, H, W]
+    const float2* sens;      // [n, C, H, W]
+    const float2* k;         // CE_DC
+    const float2* k0;        // CE_DC
+    const float* mask;       // CE_DC: [W]
+    const float* dcw;        // CE_DC: 1 float
+    float* out_real;         // planar / rss output
+    const float* cm_in;      // optional column mask on load  [W]
+    const float* cm_out;     // optional column mask on store [W]
+    const float2* tw;        // W_len^k, k in [0, len)
+    int C, H, W;
+    int len;                 // transform length of this pass
+    int B;                   // lines per workgroup (power of two, <= 256)
+    int logB;
+    int pitch;               // LDS pitch in float2
+    int inner;               // coil-loop count (reduce epilogues) else 1
+    int out_ctot;            // planar outputs: channels per sample in the destination (>= 2)
+    int nrad;
+    int rad[kMaxRad];
+    int ns_shift[kMaxRad];   // log2(Ns) if Ns is a power of two else -1
+    float scale;
+    float sgn;               // +1 forward, -1 inverse
+    int pro, epi;
+};
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// One Stockham pass of radix R over `nseq` sequences (one per thread group of
+// `tps` threads).  src/dst are the sequence bases of THIS thread's sequence.
+template <int R>
+__device__ __forceinline__ void stockham_pass_reg(const float2* __restrict__ src, float2* __restrict__ dst,
+                                                  const float2* __restrict__ tw, int n, int Ns, int ns_shift,
+                                                  int lane, int tps, float sgn) {
+    const int m = n / R;           // butterflies per sequence
+    const int ts = n / (Ns * R);   // twiddle stride
+    const int wr = n / R;          // W_R^1 = tw[n/R]
+    for (int j = lane; j < m; j += tps) {
+        int kk, jq;
+        if (ns_shift >= 0) {
+            kk = j & (Ns - 1);
+            jq = j >> ns_shift;
+        } else {
+            jq = j / Ns;
+            kk = j - jq * Ns;
+        }
+        float2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = src[j + r * m];
+#pragma unroll
+        for (int r = 1; r < R; ++r) v[r] = cmul(v[r], tw[r * kk * ts]);
+        const int j0 = jq * Ns * R + kk;
+        if (R == 2) {
+            dst[j0] = cadd(v[0], v[1]);
+            dst[j0 + Ns] = csub(v[0], v[1]);
+        } else if (R == 4) {
+            float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
+            float2 c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+            float2 dr = make_float2(sgn * d.y, -sgn * d.x);   // d * (-i) forward, d * (+i) inverse
+            dst[j0] = cadd(a, c);
+            dst[j0 + Ns] = cadd(b, dr);
+            dst[j0 + 2 * Ns] = csub(a, c);
+            dst[j0 + 3 * Ns] = csub(b, dr);
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                float2 acc = v[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) acc = cadd(acc, cmul(v[r], tw[((q * r) % R) * wr]));
+                dst[j0 + q * Ns] = acc;
+            }
+        }
+    }
+}
+
+// Any other (prime) radix: twiddle the R inputs in place (each butterfly owns
+// its inputs), then a direct DFT reading them back from LDS.
+__device__ __forceinline__ void stockham_pass_any(float2* __restrict__ src, float2* __restrict__ dst,
+                                                  const float2* __restrict__ tw, int n, int R, int Ns,
+                                                  int ns_shift, int lane, int tps) {
+    const int m = n / R;
+    const int ts = n / (Ns * R);
+    const int wr = n / R;
+    for (int j = lane; j < m; j += tps) {
+        int kk, jq;
+        if (ns_shift >= 0) {
+            kk = j & (Ns - 1);
+            jq = j >> ns_shift;
+        } else {
+            jq = j / Ns;
+            kk = j - jq * Ns;
+        }
+        for (int r = 1; r < R; ++r) src[j + r * m] = cmul(src[j + r * m], tw[r * kk * ts]);
+        const int j0 = jq * Ns * R + kk;
+        for (int q = 0; q < R; ++q) {
+            float2 acc = src[j];
+            int qr = 0;
+            for (int r = 1; r < R; ++r) {
+                qr += q;
+                if (qr >= R) qr -= R;
+                acc = cadd(acc, cmul(src[j + r * m], tw[qr * wr]));
+            }
+            dst[j0 + q * Ns] = acc;
+        }
+    }
+}
+
+// Runs all passes; returns the buffer that holds the result.
+__device__ __forceinline__ float2* run_fft(const FftArgs& a, float2* bufA, float2* bufB, const float2* tw,
+                                           int seq, int lane, int tps, bool active) {
+    float2* src = bufA;
+    float2* dst = bufB;
+    int Ns = 1;
+    for (int p = 0; p < a.nrad; ++p) {
+        const int R = a.rad[p];
+        if (active) {
+            float2* s = src + seq * a.pitch;
+            float2* d = dst + seq * a.pitch;
+            switch (R) {
+                case 2: stockham_pass_reg<2>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, a.sgn); break;
+                case 3: stockham_pass_reg<3>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, a.sgn); break;
+                case 4: stockham_pass_reg<4>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, a.sgn); break;
+                case 5: stockham_pass_reg<5>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, a.sgn); break;
+                default: stockham_pass_any(s, d, tw, a.len, R, Ns, a.ns_shift[p], lane, tps); break;
+            }
+        }
+        __syncthreads();
+        Ns *= R;
+        float2* t = src;
+        src = dst;
+        dst = t;
+    }
+    return src;
+}
+
+extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+// ------------------------------------------------------------------ row pass
+// grid: (ceil(H/B), outer); plane = outer*inner + l for l in [0, inner)
+__global__ void __launch_bounds__(kThreads) fft_rows_kernel(const FftArgs a) {
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* bufA = tw + a.len;
+    float2* bufB = bufA + a.B * a.pitch;
+    const int tid = threadIdx.x;
+    const int W = a.W, H = a.H;
+    const int h0 = blockIdx.x * a.B;
+    const int rows = min(a.B, H - h0);
+    const int cnt = rows * W;                 // contiguous floats2 in global for this row group
+    const int tps = kThreads >> a.logB;
+    const int seq = tid / tps;
+    const int lane = tid - seq * tps;
+
+    for (int i = tid; i < a.len; i += kThreads) {
+        float2 t = a.tw[i];
+        t.y *= a.sgn;
+        tw[i] = t;
+    }
+
+    const int outer = blockIdx.y;
+    // per-thread accumulators for the coil-reducing epilogues: element e = tid + it*kThreads
+    // (B*W/256 <= 8*640/256 = 20 per thread at the largest supported row)
+    constexpr int kMaxAcc = 24;
+    float2 acc[kMaxAcc];
+#pragma unroll
+    for (int i = 0; i < kMaxAcc; ++i) acc[i] = make_float2(0.f, 0.f);
+
+    for (int l = 0; l < a.inner; ++l) {
+        const int plane = outer * a.inner + l;
+        const size_t base = ((size_t)plane * H + h0) * W;
+        __syncthreads();   // bufA free (previous iteration's epilogue done), tw visible
+        // ---- load (pitch == W for the row pass, so LDS index == e)
+        if (a.pro == RP_NONE) {
+            int wi = tid % W;
+            for (int e = tid; e < a.B * W; e += kThreads) {
+                float2 v = make_float2(0.f, 0.f);
+                if (e < cnt) {
+                    v = a.in[base + e];
+                    if (a.cm_in) {
+                        float m = a.cm_in[wi];
+                        v.x *= m;
+                        v.y *= m;
+                    }
+                }
+                bufA[e] = v;
+                wi += kThreads % W;
+                if (wi >= W) wi -= W;
+            }
+        } else {  // RP_PLANAR_MUL_SENS: plane = n*C + c ; r planar [n,2,H,W]
+            const int n = plane / a.C;
+            const size_t rbase = ((size_t)n * 2 * H + h0) * W;
+            const size_t ibase = rbase + (size_t)H * W;
+            for (int e = tid; e < a.B * W; e += kThreads) {
+                float2 v = make_float2(0.f, 0.f);
+                if (e < cnt) {
+                    float2 r = make_float2(a.in_planar[rbase + e], a.in_planar[ibase + e]);
+                    v = cmul(r, a.sens[base + e]);
+                }
+                bufA[e] = v;
+            }
+        }
+        __syncthreads();
+        float2* res = run_fft(a, bufA, bufB, tw, seq, lane, tps, seq < rows);
+        // ---- epilogue
+        if (a.epi == RE_STORE) {
+            int wi = tid % W;
+            for (int e = tid; e < cnt; e += kThreads) {
+                float2 v = res[e];
+                float s = a.scale;
+                if (a.cm_out) s *= a.cm_out[wi];
+                a.out[base + e] = make_float2(v.x * s, v.y * s);
+                wi += kThreads % W;
+                if (wi >= W) wi -= W;
+            }
+        } else if (a.epi == RE_STORE_PLANAR) {
+            const size_t rbase = ((size_t)plane * a.out_ctot * H + h0) * W;
+            const size_t ibase = rbase + (size_t)H * W;
+            for (int e = tid; e < cnt; e += kThreads) {
+                float2 v = res[e];
+                a.out_real[rbase + e] = v.x * a.scale;
+                a.out_real[ibase + e] = v.y * a.scale;
+            }
+        } else if (a.epi == RE_CONJ_SENS_SUM_PLANAR) {
+#pragma unroll
+            for (int it = 0; it < kMaxAcc; ++it) {
+                const int e = tid + it * kThreads;
+                if (e < cnt) {
+                    float2 s = a.sens[base + e];
+                    float2 v = res[e];
+                    // v * conj(s)
+                    acc[it].x += v.x * s.x + v.y * s.y;
+                    acc[it].y += v.y * s.x - v.x * s.y;
+                }
+            }
+        } else {  // RE_RSS
+#pragma unroll
+            for (int it = 0; it < kMaxAcc; ++it) {
+                const int e = tid + it * kThreads;
+                if (e < cnt) {
+                    float2 v = res[e];
+                    acc[it].x += v.x * v.x + v.y * v.y;
+                }
+            }
+        }
+    }
+    if (a.epi == RE_CONJ_SENS_SUM_PLANAR) {
+        const size_t rbase = ((size_t)outer * a.out_ctot * H + h0) * W;
+        const size_t ibase = rbase + (size_t)H * W;
+#pragma unroll
+        for (int it = 0; it < kMaxAcc; ++it) {
+            const int e = tid + it * kThreads;
+            if (e < cnt) {
+                a.out_real[rbase + e] = acc[it].x * a.scale;
+                a.out_real[ibase + e] = acc[it].y * a.scale;
+            }
+        }
+    } else if (a.epi == RE_RSS) {
+        const size_t obase = ((size_t)outer * H + h0) * W;
+#pragma unroll
+        for (int it = 0; it < kMaxAcc; ++it) {
+            const int e = tid + it * kThreads;
+            if (e < cnt) a.out_real[obase + e] = sqrtf(acc[it].x) * a.scale;
+        }
+    }
+}
+
+// --------------------------------------------------------------- column pass
+// grid: (ceil(W/B), planes).  Transform length = H.
+__global__ void __launch_bounds__(kThreads) fft_cols_kernel(const FftArgs a) {
+    float2* tw = reinterpret_cast<float2*>(smem_raw);
+    float2* bufA = tw + a.len;
+    float2* bufB = bufA + a.B * a.pitch;
+    const int tid = threadIdx.x;
+    const int W = a.W, H = a.H, B = a.B;
+    const int w0 = blockIdx.x * B;
+    const int cols = min(B, W - w0);
+    const int plane = blockIdx.y;
+    const size_t base = (size_t)plane * H * W + w0;
+    const int tps = kThreads >> a.logB;
+    const int seq = tid / tps;
+    const int lane = tid - seq * tps;
+
+    for (int i = tid; i < a.len; i += kThreads) {
+        float2 t = a.tw[i];
+        t.y *= a.sgn;
+        tw[i] = t;
+    }
+    for (int e = tid; e < H * B; e += kThreads) {
+        const int h = e >> a.logB;
+        const int j = e & (B - 1);
+        float2 v = make_float2(0.f, 0.f);
+        if (j < cols) {
+            v = a.in[base + (size_t)h * W + j];
+            if (a.cm_in) {
+                float m = a.cm_in[w0 + j];
+                v.x *= m;
+                v.y *= m;
+            }
+        }
+        bufA[j * a.pitch + h] = v;
+    }
+    __syncthreads();
+    float2* res = run_fft(a, bufA, bufB, tw, seq, lane, tps, seq < cols);
+    if (a.epi == CE_STORE) {
+        for (int e = tid; e < H * B; e += kThreads) {
+            const int h = e >> a.logB;
+            const int j = e & (B - 1);
+            if (j < cols) {
+                float2 v = res[j * a.pitch + h];
+                a.out[base + (size_t)h * W + j] = make_float2(v.x * a.scale, v.y * a.scale);
+            }
+        }
+    } else {  // CE_DC: k_out = (k - dcw*mask*(k-k0)) - R
+        const float dcw = a.dcw[0];
+        for (int e = tid; e < H * B; e += kThreads) {
+            const int h = e >> a.logB;
+            const int j = e & (B - 1);
+            if (j < cols) {
+                const size_t idx = base + (size_t)h * W + j;
+                float2 R = res[j * a.pitch + h];
+                R.x *= a.scale;
+                R.y *= a.scale;
+                const float2 kk = a.k[idx];
+                const float2 k0 = a.k0[idx];
+                const float m = a.mask[w0 + j];
+                float2 dc = make_float2((kk.x - k0.x) * m * dcw, (kk.y - k0.y) * m * dcw);
+                a.out[idx] = make_float2((kk.x - dc.x) - R.x, (kk.y - dc.y) - R.y);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------- host side
+struct Plan {
+    int n = 0;
+    int nrad = 0;
+    int rad[kMaxRad];
+    int ns_shift[kMaxRad];
+    float2* tw = nullptr;
+};
+
+std::mutex g_mu;
+std::map<std::pair<int, int>, Plan> g_plans;  // (device, n)
+
+bool factorize(int n, Plan& p) {
+    p.n = n;
+    p.nrad = 0;
+    int m = n;
+    auto push = [&](int r) {
+        if (p.nrad >= kMaxRad) return false;
+        p.rad[p.nrad++] = r;
+        return true;
+    };
+    while (m % 4 == 0) {
+        if (!push(4)) return false;
+        m /= 4;
+    }
+    while (m % 2 == 0) {
+        if (!push(2)) return false;
+        m /= 2;
+    }
+    for (int f = 3; f <= 61 && m > 1; f += 2) {
+        while (m % f == 0) {
+            if (!push(f)) return false;
+            m /= f;
+        }
+    }
+    if (m != 1) return false;   // prime factor > 61: unsupported
+    int Ns = 1;
+    for (int i = 0; i < p.nrad; ++i) {
+        int s = -1;
+        if ((Ns & (Ns - 1)) == 0) {
+            s = 0;
+            while ((1 << s) < Ns) ++s;
+        }
+        p.ns_shift[i] = s;
+        Ns *= p.rad[i];
+    }
+    return true;
+}
+
+int get_plan(int n, Plan* out) {
+    if (n < 1 || n > 4096) {
+        san_set_error("fft length %d outside [1, 4096]", n);
+        return SAN_E_UNSUPPORTED;
+    }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_pair(dev, n);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) {
+        *out = it->second;
+        return SAN_OK;
+    }
+    Plan p;
+    if (!factorize(n, p)) {
+        san_set_error("fft length %d has a prime factor > 61", n);
+        return SAN_E_UNSUPPORTED;
+    }
+    std::vector<float2> h(n);
+    for (int k = 0; k < n; ++k) {
+        // exact-ish angles: reduce k/n to an octant in integer arithmetic first
+        long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+        h[k] = make_float2((float)cosl(ang), (float)sinl(ang));
+    }
+    e = hipMalloc(&p.tw, sizeof(float2) * n);
+    if (e != hipSuccess) {
+        san_set_error("hipMalloc twiddles: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    e = hipMemcpy(p.tw, h.data(), sizeof(float2) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        san_set_error("hipMemcpy twiddles: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    g_plans[key] = p;
+    *out = p;
+    return SAN_OK;
+}
+
+void fill_pass(FftArgs& a, const Plan& p) {
+    a.len = p.n;
+    a.nrad = p.nrad;
+    for (int i = 0; i < p.nrad; ++i) {
+        a.rad[i] = p.rad[i];
+        a.ns_shift[i] = p.ns_shift[i];
+    }
+    a.tw = p.tw;
+}
+
+int ilog2(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+// lines per workgroup: as many as keep LDS <= ~64 KiB and give every sequence >= 8 threads
+int pick_batch(int len, int lines, int max_b) {
+    int b = max_b;
+    while (b > 1 && (size_t)b * (len + 1) * sizeof(float2) * 2 > 60 * 1024) b >>= 1;
+    (void)lines;
+    return b;
+}
+
+size_t lds_bytes(const FftArgs& a) { return sizeof(float2) * ((size_t)a.len + 2 * (size_t)a.B * a.pitch); }
+
+int launch_rows(FftArgs& a, int outer, hipStream_t s) {
+    a.B = pick_batch(a.len, a.H, 8);
+    // the coil-reducing epilogues keep B*W/256 accumulators per thread (<= 24)
+    while (a.B > 1 && a.B * a.W > 24 * kThreads) a.B >>= 1;
+    if (a.B * a.W > 24 * kThreads && (a.epi == RE_CONJ_SENS_SUM_PLANAR || a.epi == RE_RSS)) {
+        san_set_error("row length %d too long for the reducing epilogue", a.W);
+        return SAN_E_UNSUPPORTED;
+    }
+    a.logB = ilog2(a.B);
+    a.pitch = a.len;
+    dim3 grid(san_cdiv(a.H, a.B), outer);
+    size_t lds = lds_bytes(a);
+    if (lds > 160 * 1024) {
+        san_set_error("fft row of %d does not fit LDS", a.len);
+        return SAN_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(fft_rows_kernel, grid, dim3(kThreads), lds, s, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int launch_cols(FftArgs& a, int planes, hipStream_t s) {
+    int maxb = 16;
+    if ((long)san_cdiv(a.W, 16) * planes < 512) maxb = 8;
+    a.B = pick_batch(a.len, a.W, maxb);
+    a.logB = ilog2(a.B);
+    a.pitch = a.len + 1;
+    dim3 grid(san_cdiv(a.W, a.B), planes);
+    size_t lds = lds_bytes(a);
+    if (lds > 160 * 1024) {
+        san_set_error("fft column of %d does not fit LDS", a.len);
+        return SAN_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(fft_cols_kernel, grid, dim3(kThreads), lds, s, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int ensure_big_lds() {
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_rows_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_cols_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    return (int)err;
+}
+
+FftArgs base_args(int c, int h, int w) {
+    FftArgs a{};
+    a.C = c;
+    a.H = h;
+    a.W = w;
+    a.inner = 1;
+    a.scale = 1.f;
+    a.sgn = 1.f;
+    a.out_ctot = 2;
+    return a;
+}
+
+int common_checks(const void* p0, const void* p1, int planes, int h, int w, void* ws, size_t ws_bytes) {
+    if (!p0 || !p1) {
+        san_set_error("null tensor pointer");
+        return SAN_E_ARG;
+    }
+    if (planes < 1 || h < 1 || w < 1) {
+        san_set_error("bad dims planes=%d h=%d w=%d", planes, h, w);
+        return SAN_E_ARG;
+    }
+    if (!ws || ws_bytes < san_fft_workspace_bytes(planes, h, w)) {
+        san_set_error("workspace too small: need %zu bytes", san_fft_workspace_bytes(planes, h, w));
+        return SAN_E_WORKSPACE;
+    }
+    return ensure_big_lds();
+}
+
+}  // namespace
+
+extern "C" {
+
+int san_fft_prepare(int h, int w) {
+    Plan p;
+    int r = get_plan(h, &p);
+    if (r) return r;
+    r = get_plan(w, &p);
+    if (r) return r;
+    return ensure_big_lds();
+}
+
+size_t san_fft_workspace_bytes(int planes, int h, int w) {
+    return (size_t)planes * (size_t)h * (size_t)w * sizeof(float2);
+}
+
+int san_fft2(const float* in, float* out, int planes, int h, int w, int inverse, const float* colmask_in,
+             const float* colmask_out, int planar_ctot, void* ws, size_t ws_bytes, void* stream) {
+    int r = common_checks(in, out, planes, h, w, ws, ws_bytes);
+    const int planar_out = planar_ctot != 0;
+    if (planar_out && planar_ctot < 2) {
+        san_set_error("planar_ctot must be 0 (interleaved) or >= 2");
+        return SAN_E_ARG;
+    }
+    if (r) return r;
+    Plan ph, pw;
+    if ((r = get_plan(h, &ph))) return r;
+    if ((r = get_plan(w, &pw))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    const float sgn = inverse ? -1.f : 1.f;
+    FftArgs c = base_args(1, h, w);
+    fill_pass(c, ph);
+    c.in = (const float2*)in;
+    c.out = (float2*)ws;
+    c.cm_in = colmask_in;
+    c.sgn = sgn;
+    c.epi = CE_STORE;
+    if ((r = launch_cols(c, planes, s))) return r;
+    FftArgs a = base_args(1, h, w);
+    fill_pass(a, pw);
+    a.in = (const float2*)ws;
+    a.out = (float2*)out;
+    a.out_real = out;
+    a.cm_out = planar_out ? nullptr : colmask_out;
+    a.sgn = sgn;
+    a.scale = (float)(1.0 / std::sqrt((double)h * (double)w));
+    a.pro = RP_NONE;
+    a.epi = planar_out ? RE_STORE_PLANAR : RE_STORE;
+    if (planar_out) a.out_ctot = planar_ctot;
+    if (planar_out && colmask_out) {
+        san_set_error("planar_out with colmask_out is not supported");
+        return SAN_E_UNSUPPORTED;
+    }
+    return launch_rows(a, planes, s);
+}
+
+int san_sens_reduce(const float* k, const float* sens, float* out_planar, int out_ctot, int n, int c, int h, int w,
+                    void* ws, size_t ws_bytes, void* stream) {
+    int r = common_checks(k, out_planar, n * c, h, w, ws, ws_bytes);
+    if (r) return r;
+    SAN_CHECK_ARG(sens != nullptr, "sens is null");
+    SAN_CHECK_ARG(out_ctot >= 2, "out_ctot must be >= 2");
+    Plan ph, pw;
+    if ((r = get_plan(h, &ph))) return r;
+    if ((r = get_plan(w, &pw))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    FftArgs cargs = base_args(c, h, w);
+    fill_pass(cargs, ph);
+    cargs.in = (const float2*)k;
+    cargs.out = (float2*)ws;
+    cargs.sgn = -1.f;
+    cargs.epi = CE_STORE;
+    if ((r = launch_cols(cargs, n * c, s))) return r;
+    FftArgs a = base_args(c, h, w);
+    fill_pass(a, pw);
+    a.in = (const float2*)ws;
+    a.sens = (const float2*)sens;
+    a.out_real = out_planar;
+    a.out_ctot = out_ctot;
+    a.sgn = -1.f;
+    a.scale = (float)(1.0 / std::sqrt((double)h * (double)w));
+    a.inner = c;
+    a.pro = RP_NONE;
+    a.epi = RE_CONJ_SENS_SUM_PLANAR;
+    return launch_rows(a, n, s);
+}
+
+int san_sens_expand_dc(const float* r_planar, const float* sens, const float* k, const float* k0,
+                       const float* mask, const float* dc_w, float* k_out, int n, int c, int h, int w, void* ws,
+                       size_t ws_bytes, void* stream) {
+    int r = common_checks(r_planar, k_out, n * c, h, w, ws, ws_bytes);
+    if (r) return r;
+    SAN_CHECK_ARG(sens && k && k0 && mask && dc_w, "null input");
+    Plan ph, pw;
+    if ((r = get_plan(h, &ph))) return r;
+    if ((r = get_plan(w, &pw))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    FftArgs a = base_args(c, h, w);
+    fill_pass(a, pw);
+    a.in_planar = r_planar;
+    a.sens = (const float2*)sens;
+    a.out = (float2*)ws;
+    a.sgn = 1.f;
+    a.pro = RP_PLANAR_MUL_SENS;
+    a.epi = RE_STORE;
+    if ((r = launch_rows(a, n * c, s))) return r;
+    FftArgs cargs = base_args(c, h, w);
+    fill_pass(cargs, ph);
+    cargs.in = (const float2*)ws;
+    cargs.out = (float2*)k_out;
+    cargs.k = (const float2*)k;
+    cargs.k0 = (const float2*)k0;
+    cargs.mask = mask;
+    cargs.dcw = dc_w;
+    cargs.sgn = 1.f;
+    cargs.scale = (float)(1.0 / std::sqrt((double)h * (double)w));
+    cargs.epi = CE_DC;
+    return launch_cols(cargs, n * c, s);
+}
+
+int san_ifft2_rss(const float* k, float* out, int n, int c, int h, int w, void* ws, size_t ws_bytes,
+                  void* stream) {
+    int r = common_checks(k, out, n * c, h, w, ws, ws_bytes);
+    if (r) return r;
+    Plan ph, pw;
+    if ((r = get_plan(h, &ph))) return r;
+    if ((r = get_plan(w, &pw))) return r;
+    hipStream_t s = (hipStream_t)stream;
+    FftArgs cargs = base_args(c, h, w);
+    fill_pass(cargs, ph);
+    cargs.in = (const float2*)k;
+    cargs.out = (float2*)ws;
+    cargs.sgn = -1.f;
+    cargs.epi = CE_STORE;
+    if ((r = launch_cols(cargs, n * c, s))) return r;
+    FftArgs a = base_args(c, h, w);
+    fill_pass(a, pw);
+    a.in = (const float2*)ws;
+    a.out_real = out;
+    a.sgn = -1.f;
+    a.scale = (float)(1.0 / std::sqrt((double)h * (double)w));
+    a.inner = c;
+    a.pro = RP_NONE;
+    a.epi = RE_RSS;
+    return launch_rows(a, n, s);
+}
+
+}  // extern "C"

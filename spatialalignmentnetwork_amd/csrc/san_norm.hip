@@ -1,0 +1,332 @@
+// Normalisation statistics (merge of per-tile Welford partials) and the
+// element-wise materialisers of the lazy-normalisation scheme.  All of these are
+// HBM-bound streaming kernels: 16-byte accesses where the layout allows,
+// grid-stride loops capped at 2048 workgroups.
+#include "san_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// -------------------------------------------------------------------------
+// one wave per output statistic; partials merged in double, fixed order
+// grid: (c, n_groups) ; n_groups = n (instance/group) or 1 (batch)
+__global__ void __launch_bounds__(64)
+norm_finalize_kernel(const float* __restrict__ part, int n, int c, int tiles, int mode, float eps,
+                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
+                     float* __restrict__ shift, int sc_ctot, int sc_coff, float* __restrict__ aux_a,
+                     float* __restrict__ aux_b) {
+    const int ch = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int n_lo = (mode == SAN_NORM_BATCH) ? 0 : blockIdx.y;
+    const int n_hi = (mode == SAN_NORM_BATCH) ? n : blockIdx.y + 1;
+    double cnt = 0.0, s = 0.0;
+    for (int b = n_lo; b < n_hi; ++b) {
+        const float* p = part + ((size_t)(b * c + ch) * tiles) * 3;
+        for (int t = lane; t < tiles; t += 64) {
+            const double k = p[t * 3 + 0];
+            cnt += k;
+            s += k * (double)p[t * 3 + 1];
+        }
+    }
+    cnt = san_wave_sum_d(cnt);
+    s = san_wave_sum_d(s);
+    const double mean = cnt > 0.0 ? s / cnt : 0.0;
+    double m2 = 0.0;
+    for (int b = n_lo; b < n_hi; ++b) {
+        const float* p = part + ((size_t)(b * c + ch) * tiles) * 3;
+        for (int t = lane; t < tiles; t += 64) {
+            const double k = p[t * 3 + 0];
+            const double d = (double)p[t * 3 + 1] - mean;
+            m2 += (double)p[t * 3 + 2] + k * d * d;
+        }
+    }
+    m2 = san_wave_sum_d(m2);
+    if (lane != 0) return;
+    const double var_b = cnt > 0.0 ? m2 / cnt : 0.0;
+    const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : 0.0;
+    if (mode == SAN_NORM_INSTANCE) {
+        const float sc = (float)(1.0 / sqrt(var_b + (double)eps));
+        scale[blockIdx.y * sc_ctot + sc_coff + ch] = sc;
+        shift[blockIdx.y * sc_ctot + sc_coff + ch] = (float)(-mean) * sc;
+    } else if (mode == SAN_NORM_GROUP) {
+        const float sd = (float)sqrt(var_u);
+        const float sc = 1.f / (sd + eps);
+        scale[blockIdx.y * sc_ctot + sc_coff + ch] = sc;
+        shift[blockIdx.y * sc_ctot + sc_coff + ch] = (float)(-mean) * sc;
+        if (aux_a) aux_a[blockIdx.y * c + ch] = sd;
+        if (aux_b) aux_b[blockIdx.y * c + ch] = (float)mean;
+    } else {
+        const float g = gamma ? gamma[ch] : 1.f;
+        const float bt = beta ? beta[ch] : 0.f;
+        const float sc = g * (float)(1.0 / sqrt(var_b + (double)eps));
+        const float sh = bt - (float)mean * sc;
+        for (int b = 0; b < n; ++b) {
+            scale[b * sc_ctot + sc_coff + ch] = sc;
+            shift[b * sc_ctot + sc_coff + ch] = sh;
+        }
+        if (aux_a) aux_a[ch] = (float)mean;
+        if (aux_b) aux_b[ch] = (float)var_u;
+    }
+}
+
+// one workgroup per (c, n) plane: exact two-pass (mean, then centred M2)
+__global__ void __launch_bounds__(kThreads)
+plane_stats_kernel(const float* __restrict__ x, int x_ctot, int x_coff, int c, int hw, float* __restrict__ part) {
+    __shared__ float red[8];
+    const int ch = blockIdx.x, n = blockIdx.y;
+    const float* p = x + ((size_t)(n * x_ctot + x_coff + ch)) * hw;
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int i = tid; i < hw; i += kThreads) s += p[i];
+    s = san_wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)hw;
+    float d = 0.f;
+    for (int i = tid; i < hw; i += kThreads) {
+        const float e = p[i] - mean;
+        d = fmaf(e, e, d);
+    }
+    d = san_wave_sum(d);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = d;
+    __syncthreads();
+    if (tid == 0) {
+        float* o = part + ((size_t)(n * c + ch)) * 3;
+        o[0] = (float)hw;
+        o[1] = mean;
+        o[2] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, int sc_ctot, int sc_coff,
+                                      int n, int c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const int b = i / c, ch = i - b * c;
+    const float sc = gamma[ch] / sqrtf(rvar[ch] + eps);
+    scale[b * sc_ctot + sc_coff + ch] = sc;
+    shift[b * sc_ctot + sc_coff + ch] = beta[ch] - rmean[ch] * sc;
+}
+
+// ------------------------------------------------------------ materialisers
+struct EwArgs {
+    const float* x;
+    const float* sc;
+    const float* sh;
+    float slope;
+    int x_ctot, x_coff;
+    const float* b;
+    const float* b_sc;
+    const float* b_sh;
+    float b_slope;
+    int b_ctot, b_coff;
+    float* y;
+    int y_ctot, y_coff;
+    int n, c, h, w;
+};
+
+__device__ __forceinline__ void load_affine(const float* sc, const float* sh, int idx, float& s, float& t) {
+    s = 1.f;
+    t = 0.f;
+    if (sc) {
+        s = sc[idx];
+        t = sh[idx];
+    }
+}
+
+// grid: (blocks over the plane, c, n)
+__global__ void __launch_bounds__(kThreads) avgpool2_kernel(const EwArgs a) {
+    const int ch = blockIdx.y, n = blockIdx.z;
+    const int oh = a.h >> 1, ow = a.w >> 1;
+    float s, t;
+    load_affine(a.sc, a.sh, n * a.x_ctot + a.x_coff + ch, s, t);
+    const float* xp = a.x + ((size_t)(n * a.x_ctot + a.x_coff + ch)) * a.h * a.w;
+    float* yp = a.y + ((size_t)(n * a.y_ctot + a.y_coff + ch)) * oh * ow;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < oh * ow; i += gridDim.x * kThreads) {
+        const int oy = i / ow, ox = i - oy * ow;
+        const float2 r0 = *reinterpret_cast<const float2*>(xp + (size_t)(2 * oy) * a.w + 2 * ox);
+        const float2 r1 = *reinterpret_cast<const float2*>(xp + (size_t)(2 * oy + 1) * a.w + 2 * ox);
+        const float v = (san_act(r0.x, s, t, a.slope) + san_act(r0.y, s, t, a.slope)) +
+                        (san_act(r1.x, s, t, a.slope) + san_act(r1.y, s, t, a.slope));
+        yp[i] = v * 0.25f;
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) upsample2_kernel(const EwArgs a) {
+    const int ch = blockIdx.y, n = blockIdx.z;
+    const int ow = a.w * 2;
+    float s, t;
+    load_affine(a.sc, a.sh, n * a.x_ctot + a.x_coff + ch, s, t);
+    const float* xp = a.x + ((size_t)(n * a.x_ctot + a.x_coff + ch)) * a.h * a.w;
+    float* yp = a.y + ((size_t)(n * a.y_ctot + a.y_coff + ch)) * (size_t)(4 * a.h * a.w);
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < a.h * a.w; i += gridDim.x * kThreads) {
+        const int iy = i / a.w, ix = i - iy * a.w;
+        const float v = san_act(xp[i], s, t, a.slope);
+        const float2 vv = make_float2(v, v);
+        *reinterpret_cast<float2*>(yp + (size_t)(2 * iy) * ow + 2 * ix) = vv;
+        *reinterpret_cast<float2*>(yp + (size_t)(2 * iy + 1) * ow + 2 * ix) = vv;
+    }
+}
+
+// h*w passed as a.h (a.w == 1)
+__global__ void __launch_bounds__(kThreads) add_kernel(const EwArgs a) {
+    const int ch = blockIdx.y, n = blockIdx.z;
+    const int hw = a.h;
+    float s0, t0, s1, t1;
+    load_affine(a.sc, a.sh, n * a.x_ctot + a.x_coff + ch, s0, t0);
+    load_affine(a.b_sc, a.b_sh, n * a.b_ctot + a.b_coff + ch, s1, t1);
+    const float* xp = a.x + ((size_t)(n * a.x_ctot + a.x_coff + ch)) * hw;
+    const float* bp = a.b + ((size_t)(n * a.b_ctot + a.b_coff + ch)) * hw;
+    float* yp = a.y + ((size_t)(n * a.y_ctot + a.y_coff + ch)) * hw;
+    if ((hw & 3) == 0) {
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw / 4; i += gridDim.x * kThreads) {
+            const float4 u = reinterpret_cast<const float4*>(xp)[i];
+            const float4 v = reinterpret_cast<const float4*>(bp)[i];
+            float4 o;
+            o.x = san_act(u.x, s0, t0, a.slope) + san_act(v.x, s1, t1, a.b_slope);
+            o.y = san_act(u.y, s0, t0, a.slope) + san_act(v.y, s1, t1, a.b_slope);
+            o.z = san_act(u.z, s0, t0, a.slope) + san_act(v.z, s1, t1, a.b_slope);
+            o.w = san_act(u.w, s0, t0, a.slope) + san_act(v.w, s1, t1, a.b_slope);
+            reinterpret_cast<float4*>(yp)[i] = o;
+        }
+    } else {
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads)
+            yp[i] = san_act(xp[i], s0, t0, a.slope) + san_act(bp[i], s1, t1, a.b_slope);
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) apply_kernel(const EwArgs a) {
+    const int ch = blockIdx.y, n = blockIdx.z;
+    const int hw = a.h;
+    float s0, t0;
+    load_affine(a.sc, a.sh, n * a.x_ctot + a.x_coff + ch, s0, t0);
+    const float* xp = a.x + ((size_t)(n * a.x_ctot + a.x_coff + ch)) * hw;
+    float* yp = a.y + ((size_t)(n * a.y_ctot + a.y_coff + ch)) * hw;
+    if ((hw & 3) == 0) {
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw / 4; i += gridDim.x * kThreads) {
+            const float4 u = reinterpret_cast<const float4*>(xp)[i];
+            float4 o;
+            o.x = san_act(u.x, s0, t0, a.slope);
+            o.y = san_act(u.y, s0, t0, a.slope);
+            o.z = san_act(u.z, s0, t0, a.slope);
+            o.w = san_act(u.w, s0, t0, a.slope);
+            reinterpret_cast<float4*>(yp)[i] = o;
+        }
+    } else {
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads)
+            yp[i] = san_act(xp[i], s0, t0, a.slope);
+    }
+}
+
+dim3 ew_grid(int elems_per_plane, int c, int n) {
+    int bx = san_cdiv(elems_per_plane, kThreads * 4);
+    if (bx < 1) bx = 1;
+    long cap = 4096 / ((long)c * n > 0 ? (long)c * n : 1);
+    if (cap < 1) cap = 1;
+    if (bx > cap) bx = (int)cap;
+    return dim3(bx, c, n);
+}
+
+int check_view(int ctot, int coff, int c) { return coff >= 0 && c > 0 && coff + c <= ctot; }
+
+}  // namespace
+
+extern "C" {
+
+int san_norm_finalize(const float* part, int n, int c, int tiles, int mode, float eps, const float* gamma,
+                      const float* beta, float* scale, float* shift, int sc_ctot, int sc_coff, float* aux_a,
+                      float* aux_b, void* stream) {
+    SAN_CHECK_ARG(part && scale && shift, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && tiles > 0, "bad dims");
+    SAN_CHECK_ARG(mode >= 0 && mode <= 2, "bad mode");
+    SAN_CHECK_ARG(check_view(sc_ctot, sc_coff, c), "bad scale/shift view");
+    dim3 grid(c, mode == SAN_NORM_BATCH ? 1 : n);
+    hipLaunchKernelGGL(norm_finalize_kernel, grid, dim3(64), 0, (hipStream_t)stream, part, n, c, tiles, mode, eps,
+                       gamma, beta, scale, shift, sc_ctot, sc_coff, aux_a, aux_b);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_plane_stats(const float* x, int x_ctot, int x_coff, int c, int n, int hw, float* part, void* stream) {
+    SAN_CHECK_ARG(x && part, "null pointer");
+    SAN_CHECK_ARG(n > 0 && hw > 0 && check_view(x_ctot, x_coff, c), "bad dims");
+    hipLaunchKernelGGL(plane_stats_kernel, dim3(c, n), dim3(kThreads), 0, (hipStream_t)stream, x, x_ctot, x_coff, c,
+                       hw, part);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_bn_eval_affine(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                       float* scale, float* shift, int sc_ctot, int sc_coff, int n, int c, void* stream) {
+    SAN_CHECK_ARG(gamma && beta && rmean && rvar && scale && shift, "null pointer");
+    SAN_CHECK_ARG(n > 0 && check_view(sc_ctot, sc_coff, c), "bad dims");
+    hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(san_cdiv(n * c, 256)), dim3(256), 0, (hipStream_t)stream, gamma,
+                       beta, rmean, rvar, eps, scale, shift, sc_ctot, sc_coff, n, c);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope, float* y,
+                     int y_ctot, int y_coff, int n, int c, int h, int w, void* stream) {
+    SAN_CHECK_ARG(x && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h >= 2 && w >= 2 && (h % 2 == 0) && (w % 2 == 0), "h, w must be even");
+    SAN_CHECK_ARG(check_view(x_ctot, x_coff, c) && check_view(y_ctot, y_coff, c), "bad channel view");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    EwArgs a{};
+    a.x = x; a.sc = sc; a.sh = sh; a.slope = slope; a.x_ctot = x_ctot; a.x_coff = x_coff;
+    a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff; a.n = n; a.c = c; a.h = h; a.w = w;
+    hipLaunchKernelGGL(avgpool2_kernel, ew_grid((h / 2) * (w / 2) * 4, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_upsample2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope, float* y,
+                      int y_ctot, int y_coff, int n, int c, int h, int w, void* stream) {
+    SAN_CHECK_ARG(x && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0, "bad dims");
+    SAN_CHECK_ARG(check_view(x_ctot, x_coff, c) && check_view(y_ctot, y_coff, c), "bad channel view");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    EwArgs a{};
+    a.x = x; a.sc = sc; a.sh = sh; a.slope = slope; a.x_ctot = x_ctot; a.x_coff = x_coff;
+    a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff; a.n = n; a.c = c; a.h = h; a.w = w;
+    hipLaunchKernelGGL(upsample2_kernel, ew_grid(h * w * 4, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_add_fwd(const float* a_, int a_ctot, int a_coff, const float* a_sc, const float* a_sh, float a_slope,
+                const float* b, int b_ctot, int b_coff, const float* b_sc, const float* b_sh, float b_slope, float* y,
+                int y_ctot, int y_coff, int n, int c, int hw, void* stream) {
+    SAN_CHECK_ARG(a_ && b && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && hw > 0, "bad dims");
+    SAN_CHECK_ARG(check_view(a_ctot, a_coff, c) && check_view(b_ctot, b_coff, c) && check_view(y_ctot, y_coff, c),
+                  "bad channel view");
+    SAN_CHECK_ARG(((a_sc == nullptr) == (a_sh == nullptr)) && ((b_sc == nullptr) == (b_sh == nullptr)),
+                  "scale/shift must come together");
+    EwArgs a{};
+    a.x = a_; a.sc = a_sc; a.sh = a_sh; a.slope = a_slope; a.x_ctot = a_ctot; a.x_coff = a_coff;
+    a.b = b; a.b_sc = b_sc; a.b_sh = b_sh; a.b_slope = b_slope; a.b_ctot = b_ctot; a.b_coff = b_coff;
+    a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff; a.n = n; a.c = c; a.h = hw; a.w = 1;
+    hipLaunchKernelGGL(add_kernel, ew_grid(hw, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_apply_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope, float* y,
+                  int y_ctot, int y_coff, int n, int c, int hw, void* stream) {
+    SAN_CHECK_ARG(x && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && hw > 0, "bad dims");
+    SAN_CHECK_ARG(check_view(x_ctot, x_coff, c) && check_view(y_ctot, y_coff, c), "bad channel view");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    EwArgs a{};
+    a.x = x; a.sc = sc; a.sh = sh; a.slope = slope; a.x_ctot = x_ctot; a.x_coff = x_coff;
+    a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff; a.n = n; a.c = c; a.h = hw; a.w = 1;
+    hipLaunchKernelGGL(apply_kernel, ew_grid(hw, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+}  // extern "C"

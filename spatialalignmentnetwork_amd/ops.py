@@ -1,0 +1,367 @@
+"""Tensor-level wrappers over the C ABI (include/san_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream.  Every function
+below hands raw device pointers + the current HIP stream to libsan_hip.so; no
+ATen compute kernel is launched on the hot path.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from ._lib import lib
+
+NORM_INSTANCE, NORM_GROUP, NORM_BATCH = 0, 1, 2
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32, name: str = "tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    return t
+
+
+def _creal(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    """complex64 [..] -> float32 [.., 2] view (no copy)."""
+    if t.dtype != torch.complex64:
+        raise RuntimeError(f"{name} must be complex64, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (the HIP path has no CPU fallback)")
+    return torch.view_as_real(t)
+
+
+# ---------------------------------------------------------------------------
+# scratch arena: named, shape-keyed device buffers reused across calls (the
+# library never allocates activations; the caching allocator does, once)
+# ---------------------------------------------------------------------------
+class Arena:
+    def __init__(self):
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
+
+    def get(self, name: str, shape, device, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
+        key = (name, tuple(int(s) for s in shape), str(device), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
+            self._bufs[key] = t
+        return t
+
+    def bytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+
+    def clear(self):
+        self._bufs.clear()
+
+
+GLOBAL_ARENA = Arena()
+
+
+@dataclass
+class Act:
+    """A lazily normalised activation: channels [coff, coff+c) of ``buf``
+    ([N, ctot, H, W] raw values) to be read as lrelu(scale*x + shift, slope).
+    ``scale``/``shift`` are [N, ctot] (same channel layout as ``buf``) or None."""
+    buf: torch.Tensor
+    coff: int
+    c: int
+    scale: Optional[torch.Tensor] = None
+    shift: Optional[torch.Tensor] = None
+    slope: float = 1.0
+
+    @property
+    def n(self):
+        return self.buf.shape[0]
+
+    @property
+    def ctot(self):
+        return self.buf.shape[1]
+
+    @property
+    def h(self):
+        return self.buf.shape[2]
+
+    @property
+    def w(self):
+        return self.buf.shape[3]
+
+    def view(self, coff: int, c: int) -> "Act":
+        return Act(self.buf, self.coff + coff, c, self.scale, self.shift, self.slope)
+
+
+def full(buf: torch.Tensor, scale=None, shift=None, slope: float = 1.0) -> Act:
+    return Act(buf, 0, buf.shape[1], scale, shift, slope)
+
+
+# ---------------------------------------------------------------------------
+# FFT family
+# ---------------------------------------------------------------------------
+def fft_workspace(planes: int, h: int, w: int, device) -> torch.Tensor:
+    nbytes = lib().query("san_fft_workspace_bytes", planes, h, w)
+    return GLOBAL_ARENA.get("fft_ws", (nbytes // 4,), device)
+
+
+def fft2c(x: torch.Tensor, inverse: bool = False, colmask_in: Optional[torch.Tensor] = None,
+          colmask_out: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Ortho (i)fft2 of a complex64 [N, C, H, W] tensor, optional [W] column masks."""
+    xr = _creal(x, "x")
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    ws = fft_workspace(n * c, h, w, x.device)
+    lib().call("san_fft2", _p(xr), _p(_creal(out, "out")), n * c, h, w, int(inverse), _p(colmask_in), _p(colmask_out), 0,
+               _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+def ifft2c_planar(x: torch.Tensor, colmask_in: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
+    """ifft2(x * colmask) written planar into real ``out`` [N*C, ctot>=2, H, W]."""
+    xr = _creal(x, "x")
+    n, c, h, w = x.shape
+    _chk(out, name="out")
+    assert out.shape[0] == n * c and out.shape[2:] == (h, w)
+    ws = fft_workspace(n * c, h, w, x.device)
+    lib().call("san_fft2", _p(xr), _p(out), n * c, h, w, 1, _p(colmask_in), _p(None), int(out.shape[1]),
+               _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+def sens_reduce(k: torch.Tensor, sens: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """sum_c ifft2(k)*conj(sens) -> channels 0,1 of real ``out`` [N, ctot, H, W]."""
+    n, c, h, w = k.shape
+    _chk(out, name="out")
+    ws = fft_workspace(n * c, h, w, k.device)
+    lib().call("san_sens_reduce", _p(_creal(k, "k")), _p(_creal(sens, "sens")), _p(out), int(out.shape[1]), n, c, h, w,
+               _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+def sens_expand_dc(r_planar: torch.Tensor, sens: torch.Tensor, k: torch.Tensor, k0: torch.Tensor,
+                   mask: torch.Tensor, dc_w: torch.Tensor, k_out: torch.Tensor) -> torch.Tensor:
+    n, c, h, w = k.shape
+    _chk(r_planar, name="r_planar")
+    assert r_planar.shape == (n, 2, h, w)
+    ws = fft_workspace(n * c, h, w, k.device)
+    lib().call("san_sens_expand_dc", _p(r_planar), _p(_creal(sens, "sens")), _p(_creal(k, "k")), _p(_creal(k0, "k0")),
+               _p(_chk(mask, name="mask")), _p(_chk(dc_w, name="dc_w")), _p(_creal(k_out, "k_out")), n, c, h, w,
+               _p(ws), ws.numel() * 4, _stream())
+    return k_out
+
+
+def ifft2_rss(k: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, c, h, w = k.shape
+    if out is None:
+        out = torch.empty((n, 1, h, w), device=k.device, dtype=torch.float32)
+    ws = fft_workspace(n * c, h, w, k.device)
+    lib().call("san_ifft2_rss", _p(_creal(k, "k")), _p(_chk(out, name="out")), n, c, h, w, _p(ws), ws.numel() * 4, _stream())
+    return out
+
+
+def sens_normalize(est_planar: torch.Tensor, n: int, c: int) -> torch.Tensor:
+    _chk(est_planar, name="est_planar")
+    h, w = est_planar.shape[2:]
+    sens = torch.empty((n, c, h, w), device=est_planar.device, dtype=torch.complex64)
+    lib().call("san_sens_normalize", _p(est_planar), _p(torch.view_as_real(sens)), n, c, h, w, _stream())
+    return sens
+
+
+def rss(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    n, c = x.shape[:2]
+    hw = x.shape[2] * x.shape[3]
+    if out is None:
+        out = torch.empty((n, 1) + tuple(x.shape[2:]), device=x.device, dtype=torch.float32)
+    if torch.is_complex(x):
+        lib().call("san_rss", _p(_creal(x, "x")), _p(out), n, c, hw, 1, _stream())
+    else:
+        lib().call("san_rss", _p(_chk(x, name="x")), _p(out), n, c, hw, 0, _stream())
+    return out
+
+
+def cabs(x: torch.Tensor) -> torch.Tensor:
+    """|x| per element of a complex [N,C,H,W] tensor (rss over a single channel)."""
+    n, c, h, w = x.shape
+    return rss(x.contiguous().reshape(n * c, 1, h, w)).reshape(n, c, h, w)
+
+
+# ---------------------------------------------------------------------------
+# conv / norm stack
+# ---------------------------------------------------------------------------
+_PACK_CACHE: Dict[Tuple, Tuple[int, torch.Tensor]] = {}
+
+
+def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """Repacked copy of a conv weight for the scalar-operand kernels, cached on
+    (storage, version) so an optimizer step invalidates it."""
+    key = (w.data_ptr(), tuple(w.shape), transposed)
+    ver = w._version
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    _chk(w, name="weight")
+    if transposed:
+        cin, cout, ks = w.shape[0], w.shape[1], w.shape[2]
+    else:
+        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+    nfl = lib().query("san_conv_packed_floats", cout, cin, ks)
+    packed = torch.empty(nfl, device=w.device, dtype=torch.float32)
+    lib().call("san_conv_pack_weights", _p(w.detach()), _p(packed), cout, cin, ks, int(transposed), _stream())
+    _PACK_CACHE[key] = (ver, packed)
+    return packed
+
+
+def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: bool = False,
+           out_scale: Optional[torch.Tensor] = None, out_shift: Optional[torch.Tensor] = None,
+           arena: Arena = GLOBAL_ARENA, tag: str = "") -> Optional[torch.Tensor]:
+    """y.buf[:, y.coff:y.coff+cout] = conv(T(x)) (+bias).  Returns the per-tile
+    statistics partials [N, cout, tiles, 3] when ``stats``."""
+    cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+    assert cin == x.c and cout == y.c, (cin, x.c, cout, y.c)
+    assert x.buf.shape[2:] == y.buf.shape[2:]
+    wp = packed_weight(weight)
+    n, h, w = x.n, x.h, x.w
+    part = None
+    if stats:
+        tiles = lib().query("san_conv_stat_tiles", h, w, cin, cout, ks)
+        part = arena.get("part" + tag, (n, cout, tiles, 3), x.buf.device)
+    lib().call("san_conv2d_fwd", _p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope),
+               _p(wp), _p(bias), _p(y.buf), y.ctot, y.coff, cout, _p(out_scale), _p(out_shift), _p(part),
+               n, h, w, ks, _stream())
+    return part
+
+
+def tconv2x2(x: Act, weight: torch.Tensor, y: Act, stats: bool = False, arena: Arena = GLOBAL_ARENA,
+             tag: str = "") -> Optional[torch.Tensor]:
+    cin, cout = weight.shape[0], weight.shape[1]
+    assert cin == x.c and cout == y.c
+    assert y.h == 2 * x.h and y.w == 2 * x.w
+    wp = packed_weight(weight, transposed=True)
+    part = None
+    if stats:
+        tiles = lib().query("san_tconv_stat_tiles", x.h, x.w, cout)
+        part = arena.get("tpart" + tag, (x.n, cout, tiles, 3), x.buf.device)
+    lib().call("san_tconv2x2_fwd", _p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope),
+               _p(wp), _p(y.buf), y.ctot, y.coff, cout, _p(part), x.n, x.h, x.w, _stream())
+    return part
+
+
+def norm_finalize(part: torch.Tensor, mode: int, eps: float, scale: torch.Tensor, shift: torch.Tensor, coff: int,
+                  gamma: Optional[torch.Tensor] = None, beta: Optional[torch.Tensor] = None,
+                  aux_a: Optional[torch.Tensor] = None, aux_b: Optional[torch.Tensor] = None) -> None:
+    n, c, tiles, _ = part.shape
+    lib().call("san_norm_finalize", _p(part), n, c, tiles, mode, float(eps), _p(gamma), _p(beta), _p(scale), _p(shift),
+               int(scale.shape[1]), coff, _p(aux_a), _p(aux_b), _stream())
+
+
+def plane_stats(x: Act, arena: Arena = GLOBAL_ARENA, tag: str = "") -> torch.Tensor:
+    part = arena.get("pstat" + tag, (x.n, x.c, 1, 3), x.buf.device)
+    lib().call("san_plane_stats", _p(x.buf), x.ctot, x.coff, x.c, x.n, x.h * x.w, _p(part), _stream())
+    return part
+
+
+def bn_eval_affine(gamma, beta, rmean, rvar, eps: float, scale: torch.Tensor, shift: torch.Tensor, coff: int) -> None:
+    n, c = scale.shape[0], gamma.shape[0]
+    lib().call("san_bn_eval_affine", _p(gamma), _p(beta), _p(rmean), _p(rvar), float(eps), _p(scale), _p(shift),
+               int(scale.shape[1]), coff, n, c, _stream())
+
+
+def avgpool2(x: Act, y: Act) -> None:
+    assert x.c == y.c
+    lib().call("san_avgpool2_fwd", _p(x.buf), x.ctot, x.coff, _p(x.scale), _p(x.shift), float(x.slope),
+               _p(y.buf), y.ctot, y.coff, x.n, x.c, x.h, x.w, _stream())
+
+
+def upsample2(x: Act, y: Act) -> None:
+    assert x.c == y.c
+    lib().call("san_upsample2_fwd", _p(x.buf), x.ctot, x.coff, _p(x.scale), _p(x.shift), float(x.slope),
+               _p(y.buf), y.ctot, y.coff, x.n, x.c, x.h, x.w, _stream())
+
+
+def add(a: Act, b: Act, y: Act) -> None:
+    assert a.c == b.c == y.c
+    lib().call("san_add_fwd", _p(a.buf), a.ctot, a.coff, _p(a.scale), _p(a.shift), float(a.slope),
+               _p(b.buf), b.ctot, b.coff, _p(b.scale), _p(b.shift), float(b.slope),
+               _p(y.buf), y.ctot, y.coff, a.n, a.c, a.h * a.w, _stream())
+
+
+def apply(x: Act, y: Act) -> None:
+    assert x.c == y.c
+    lib().call("san_apply_fwd", _p(x.buf), x.ctot, x.coff, _p(x.scale), _p(x.shift), float(x.slope),
+               _p(y.buf), y.ctot, y.coff, x.n, x.c, x.h * x.w, _stream())
+
+
+# ---------------------------------------------------------------------------
+# warp and losses
+# ---------------------------------------------------------------------------
+def warp(img: torch.Tensor, offset_nchw: torch.Tensor, padding: str = "zeros",
+         want_grid: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Bilinear sample of img [N,C,H,W] at identity + offset (offset NCHW [N,2,H,W])."""
+    _chk(img, name="img")
+    _chk(offset_nchw, name="offset")
+    n, c, h, w = img.shape
+    out = torch.empty_like(img)
+    grid = torch.empty((n, h, w, 2), device=img.device, dtype=torch.float32) if want_grid else None
+    lib().call("san_warp_fwd", _p(img), _p(offset_nchw), _p(out), _p(grid), n, c, h, w,
+               0 if padding == "zeros" else 1, _stream())
+    return out, grid
+
+
+def grid_sample(img: torch.Tensor, grid: torch.Tensor, padding: str = "zeros") -> torch.Tensor:
+    _chk(img, name="img")
+    _chk(grid, name="grid")
+    n, c, h, w = img.shape
+    ho, wo = grid.shape[1:3]
+    out = torch.empty((n, c, ho, wo), device=img.device, dtype=torch.float32)
+    lib().call("san_grid_sample_fwd", _p(img), _p(grid), _p(out), n, c, h, w, ho, wo,
+               0 if padding == "zeros" else 1, _stream())
+    return out
+
+
+def _loss_ws(n, h, w, device):
+    return GLOBAL_ARENA.get("loss_ws", (lib().query("san_loss_workspace_floats", n, h, w),), device)
+
+
+def ssim_loss(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    _chk(x, name="x")
+    _chk(y, name="y")
+    n, c, h, w = x.shape
+    assert c == 1 and y.shape == x.shape
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    lib().call("san_ssim_loss_fwd", _p(x), _p(y), _p(loss), n, h, w, _p(_loss_ws(n, h, w, x.device)), _stream())
+    return loss
+
+
+def lncc_loss(i: torch.Tensor, j: torch.Tensor, win: int = 9) -> torch.Tensor:
+    _chk(i, name="i")
+    _chk(j, name="j")
+    n, c, h, w = i.shape
+    assert c == 1 and j.shape == i.shape
+    loss = torch.empty((), device=i.device, dtype=torch.float32)
+    lib().call("san_lncc_loss_fwd", _p(i), _p(j), _p(loss), n, h, w, win, _p(_loss_ws(n, h, w, i.device)), _stream())
+    return loss
+
+
+def gradient_loss_nchw(offset_nchw: torch.Tensor) -> torch.Tensor:
+    _chk(offset_nchw, name="offset")
+    n, two, h, w = offset_nchw.shape
+    assert two == 2
+    loss = torch.empty((), device=offset_nchw.device, dtype=torch.float32)
+    lib().call("san_gradient_loss_fwd", _p(offset_nchw), _p(loss), n, h, w, _p(_loss_ws(n, h, w, offset_nchw.device)),
+               _stream())
+    return loss

@@ -1,0 +1,301 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and
+the committed golden fixtures.  Floating-point tolerances are written next to
+each assertion; north_star's end-to-end bar is 1e-4 relative (fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import as_t, cplx, philox, rel_err, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def S():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import spatialalignmentnetwork_amd as pkg  # noqa: F401
+    from spatialalignmentnetwork_amd import ops, synth, varnet, cross, signal_utils, ssimloss, lnccloss
+    from oracle import cpu_ref as O
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.ops, ns.synth, ns.varnet, ns.cross, ns.sig = ops, synth, varnet, cross, signal_utils
+    ns.ssim, ns.lncc, ns.O = ssimloss, lnccloss, O
+    return ns
+
+
+def g(t):
+    return t.to(DEV).contiguous()
+
+
+# ---------------------------------------------------------------- FFT family
+@pytest.mark.parametrize("shape", [(2, 2, 32, 32), (1, 3, 48, 80), (1, 1, 46, 368), (2, 1, 320, 320), (1, 2, 640, 368),
+                                   (1, 1, 30, 45), (1, 1, 7, 11)])
+def test_fft2_ifft2(S, shape):
+    x = cplx("hipfft" + str(shape), shape)
+    for inv, ref in ((False, S.O.fft2(x)), (True, S.O.ifft2(x))):
+        got = S.ops.fft2c(g(x), inverse=inv).cpu()
+        assert rel_err(got, ref) < 2e-6, (shape, inv)
+    # round trip at full size: ifft2(fft2(x)) == x
+    back = S.ops.fft2c(S.ops.fft2c(g(x)), inverse=True).cpu()
+    assert rel_err(back, x) < 2e-6
+
+
+def test_fft_golden(S, ops_golden):
+    for tag, shp in (("32", (2, 2, 32, 32)), ("48x80", (1, 3, 48, 80)), ("46x368", (1, 1, 46, 368))):
+        x = cplx("fft." + tag, shp)
+        assert rel_err(S.sig.fft2(g(x)).cpu(), as_t(ops_golden[f"fft2_{tag}"], True)) < 2e-6
+        assert rel_err(S.sig.ifft2(g(x)).cpu(), as_t(ops_golden[f"ifft2_{tag}"], True)) < 2e-6
+        assert rel_err(S.sig.rss(g(x)).cpu(), as_t(ops_golden[f"rss_c_{tag}"])) < 1e-6
+        assert rel_err(S.sig.rss(g(x.real.contiguous())).cpu(), as_t(ops_golden[f"rss_r_{tag}"])) < 1e-6
+
+
+def test_fft_linearity_and_parseval_full_size(S):
+    """Size-independent properties at BASELINE's full size (N=8, 320x320)."""
+    a, b = cplx("lin.a", (8, 1, 320, 320)), cplx("lin.b", (8, 1, 320, 320))
+    fa, fb = S.ops.fft2c(g(a)), S.ops.fft2c(g(b))
+    fab = S.ops.fft2c(g(a * 2.0 - b * 0.5))
+    assert rel_err((fa * 2.0 - fb * 0.5).cpu(), fab.cpu()) < 2e-6
+    e_x = (a.abs().double() ** 2).sum().item()
+    e_k = (fa.cpu().abs().double() ** 2).sum().item()
+    assert abs(e_x - e_k) / e_x < 1e-6      # ortho transform preserves energy
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 32, 48), (2, 1, 320, 320), (1, 15, 64, 368)])
+def test_sens_reduce_expand_dc_rss(S, shape):
+    n, c, h, w = shape
+    k, k0, s = cplx("sr.k", shape), cplx("sr.k0", shape), cplx("sr.s", shape)
+    r = cplx("sr.r", (n, 1, h, w))
+    mask = (philox("sr.m", (w,)) > 0.3)
+    dcw = torch.tensor([0.73])
+    # sens_reduce -> planar (written into a 3-channel buffer like the cascades do)
+    out = torch.zeros((n, 3, h, w), device=DEV)
+    S.ops.sens_reduce(g(k), g(s), out)
+    want = S.O.sens_reduce(k, s)
+    got = torch.complex(out[:, 0:1], out[:, 1:2]).cpu()
+    assert rel_err(got, want) < 3e-6
+    assert out[:, 2].abs().max().item() == 0.0
+    # sens_expand + soft DC + combine
+    rp = torch.cat([r.real, r.imag], 1)
+    kout = torch.empty_like(g(k))
+    S.ops.sens_expand_dc(g(rp), g(s), g(k), g(k0), g(mask.float()), g(dcw), kout)
+    zero = torch.zeros(1, 1, 1, 1, dtype=k.dtype)
+    want = k - torch.where(mask, k - k0, zero) * dcw - S.O.sens_expand(r, s)
+    assert rel_err(kout.cpu(), want) < 3e-6
+    # in-place variant (k_out aliases k) gives the same answer
+    kk = g(k).clone()
+    S.ops.sens_expand_dc(g(rp), g(s), kk, g(k0), g(mask.float()), g(dcw), kk)
+    assert torch.equal(kk, kout)
+    # rss(ifft2(k))
+    assert rel_err(S.ops.ifft2_rss(g(k)).cpu(), S.O.rss(S.O.ifft2(k))) < 3e-6
+
+
+def test_sens_golden(S, ops_golden):
+    k, s, img = cplx("blk.k", (2, 3, 32, 48)), cplx("blk.s", (2, 3, 32, 48)), cplx("blk.img", (2, 1, 32, 48))
+    out = torch.empty((2, 2, 32, 48), device=DEV)
+    S.ops.sens_reduce(g(k), g(s), out)
+    assert rel_err(torch.complex(out[:, 0:1], out[:, 1:2]).cpu(), as_t(ops_golden["sens_reduce"], True)) < 3e-6
+    rp = torch.cat([img.real, img.imag], 1)
+    z = torch.zeros_like(g(k))
+    kout = torch.empty_like(z)
+    S.ops.sens_expand_dc(g(rp), g(s), z, z, g(torch.zeros(48)), g(torch.zeros(1)), kout)
+    assert rel_err((-kout).cpu(), as_t(ops_golden["sens_expand"], True)) < 3e-6
+
+
+# ------------------------------------------------------------ conv/norm stack
+@pytest.mark.parametrize("cin,cout,h,w,ks", [(3, 18, 32, 32, 3), (18, 18, 64, 64, 3), (36, 18, 40, 40, 3),
+                                              (72, 144, 20, 20, 3), (5, 7, 24, 40, 3), (18, 2, 32, 32, 1),
+                                              (64, 64, 40, 40, 1), (96, 32, 64, 32, 3), (2, 32, 320, 320, 3)])
+def test_conv2d_vs_torch(S, cin, cout, h, w, ks):
+    n = 2
+    x = philox("cv.x", (n, cin, h, w))
+    wt = philox("cv.w", (cout, cin, ks, ks)) * (1.0 / (cin * ks * ks) ** 0.5)
+    b = philox("cv.b", (cout,))
+    sc, sh = philox("cv.sc", (n, cin), lo=0.5, hi=1.5), philox("cv.sh", (n, cin))
+    xin = S.ops.Act(g(x), 0, cin, g(sc), g(sh), 0.2)
+    y = torch.empty((n, cout, h, w), device=DEV)
+    part = S.ops.conv2d(xin, g(wt), g(b), S.ops.full(y), stats=True)
+    xa = torch.nn.functional.leaky_relu(x * sc[:, :, None, None] + sh[:, :, None, None], 0.2)
+    want = torch.nn.functional.conv2d(xa.double(), wt.double(), b.double(), padding=ks // 2).float()
+    assert rel_err(y.cpu(), want) < 2e-6
+    # fused statistics: merged partials == mean / biased variance of the output
+    scale = torch.empty((n, cout), device=DEV)
+    shift = torch.empty((n, cout), device=DEV)
+    S.ops.norm_finalize(part, S.ops.NORM_INSTANCE, 1e-5, scale, shift, 0)
+    mean = want.double().mean(dim=(2, 3))
+    var = want.double().var(dim=(2, 3), unbiased=False)
+    wsc = 1.0 / torch.sqrt(var + 1e-5)
+    assert torch.allclose(scale.cpu().double(), wsc, rtol=2e-5)
+    assert torch.allclose(shift.cpu().double(), -mean * wsc, rtol=2e-4, atol=2e-5)
+
+
+def test_conv_blocks_golden(S, ops_golden):
+    p = S.synth.fill_params([("layers.0.weight", (6, 3, 3, 3)), ("layers.3.weight", (6, 6, 3, 3))], seed=11)
+    cb = S.varnet.ConvBlock(3, 6)
+    cb.load_state_dict(p)
+    cb.to(DEV)
+    y = cb(g(philox("cb.x", (2, 3, 24, 40))))
+    assert rel_err(y.cpu(), as_t(ops_golden["convblock"])) < 1e-5
+    p = S.synth.fill_params([("layers.0.weight", (6, 4, 2, 2))], seed=12)
+    tb = S.varnet.TransposeConvBlock(6, 4)
+    tb.load_state_dict(p)
+    tb.to(DEV)
+    y = tb(g(philox("tb.x", (2, 6, 12, 20))))
+    assert rel_err(y.cpu(), as_t(ops_golden["tconvblock"])) < 1e-5
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(36, 18, 20, 20), (288, 144, 20, 20), (8, 4, 16, 24), (5, 3, 7, 9)])
+def test_tconv_vs_torch(S, cin, cout, h, w):
+    n = 2
+    x = philox("tc.x", (n, cin, h, w))
+    wt = philox("tc.w", (cin, cout, 2, 2)) * (1.0 / cin ** 0.5)
+    y = torch.empty((n, cout, 2 * h, 2 * w), device=DEV)
+    part = S.ops.tconv2x2(S.ops.full(g(x)), g(wt), S.ops.full(y), stats=True)
+    want = torch.nn.functional.conv_transpose2d(x.double(), wt.double(), stride=2).float()
+    assert rel_err(y.cpu(), want) < 2e-6
+    scale = torch.empty((n, cout), device=DEV)
+    shift = torch.empty((n, cout), device=DEV)
+    S.ops.norm_finalize(part, S.ops.NORM_INSTANCE, 1e-5, scale, shift, 0)
+    var = want.double().var(dim=(2, 3), unbiased=False)
+    assert torch.allclose(scale.cpu().double(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-5)
+
+
+def test_group_norm_and_elementwise(S, ops_golden):
+    x2 = philox("nu.x", (3, 2, 32, 48)) * 3 + 0.7
+    xa = S.ops.Act(g(x2), 0, 2, torch.empty((3, 2), device=DEV), torch.empty((3, 2), device=DEV), 1.0)
+    std = torch.empty((3, 2), device=DEV)
+    mean = torch.empty((3, 2), device=DEV)
+    S.ops.norm_finalize(S.ops.plane_stats(xa), S.ops.NORM_GROUP, 1e-6, xa.scale, xa.shift, 0, aux_a=std, aux_b=mean)
+    assert rel_err(mean.cpu().view(3, 2, 1, 1), as_t(ops_golden["norm_mean"])) < 2e-6
+    assert rel_err(std.cpu().view(3, 2, 1, 1), as_t(ops_golden["norm_std"])) < 2e-6
+    y = torch.empty_like(xa.buf)
+    S.ops.apply(xa, S.ops.full(y))
+    assert rel_err(y.cpu(), as_t(ops_golden["norm_x"])) < 5e-6
+    # avgpool / upsample / add with lazy affines
+    a = philox("ew.a", (2, 5, 16, 24))
+    sc, sh = philox("ew.sc", (2, 5), lo=0.5, hi=1.5), philox("ew.sh", (2, 5))
+    act = lambda t: torch.nn.functional.leaky_relu(t * sc[:, :, None, None] + sh[:, :, None, None], 0.01)
+    A = S.ops.Act(g(a), 0, 5, g(sc), g(sh), 0.01)
+    y = torch.empty((2, 5, 8, 12), device=DEV)
+    S.ops.avgpool2(A, S.ops.full(y))
+    assert rel_err(y.cpu(), torch.nn.functional.avg_pool2d(act(a), 2)) < 1e-6
+    y = torch.empty((2, 7, 32, 48), device=DEV)
+    S.ops.upsample2(A, S.ops.Act(y, 2, 5))
+    assert torch.equal(y[:, 2:7].cpu(), torch.nn.functional.interpolate(act(a), scale_factor=2, mode="nearest"))
+    y = torch.empty((2, 5, 16, 24), device=DEV)
+    S.ops.add(A, S.ops.full(g(a)), S.ops.full(y))
+    assert rel_err(y.cpu(), act(a) + a) < 1e-6
+
+
+# ----------------------------------------------------------- warp and losses
+def test_warp_and_losses_golden(S, ops_golden):
+    img = philox("warp.img", (2, 2, 24, 40), lo=0.0, hi=1.0)
+    off = philox("warp.off", (2, 24, 40, 2)) * 0.3
+    off[0, :2] += 1.5
+    off_nchw = off.permute(0, 3, 1, 2).contiguous()
+    out, grid = S.ops.warp(g(img), g(off_nchw))
+    assert rel_err(out.cpu(), as_t(ops_golden["warp"])) < 1e-5
+    assert torch.allclose(grid.cpu(), as_t(ops_golden["identity_grid"]) + off, atol=3e-7)
+    out2 = S.ops.grid_sample(g(img), grid)
+    assert torch.equal(out2, out)
+    # reflection padding (augmentation path) against ATen
+    want = torch.nn.functional.grid_sample(img, grid.cpu(), padding_mode="reflection", align_corners=False)
+    assert rel_err(S.ops.grid_sample(g(img), grid, padding="reflection").cpu(), want) < 1e-5
+    a = philox("loss.a", (2, 1, 40, 56), lo=0.0, hi=1.0)
+    b = (a + 0.1 * philox("loss.b", (2, 1, 40, 56))).clamp(0, 1)
+    assert abs(S.ssim.ssimloss(g(a), g(b)).item() - float(ops_golden["ssimloss"])) < 2e-6
+    assert abs(S.lncc.lncc_loss(g(a), g(b)).item() - float(ops_golden["lncc"])) < 2e-6
+    gl = S.ops.gradient_loss_nchw(g(off_nchw)).item()
+    assert abs(gl - float(ops_golden["gradient_loss"])) < 1e-6 * max(1.0, float(ops_golden["gradient_loss"]))
+
+
+def test_losses_full_size_properties(S):
+    """SSIM(x, x) == 1 -> loss 0; LNCC is symmetric; at N=8, 320x320."""
+    x = philox("fs.x", (8, 1, 320, 320), lo=0.0, hi=1.0)
+    y = philox("fs.y", (8, 1, 320, 320), lo=0.0, hi=1.0)
+    assert abs(S.ssim.ssimloss(g(x), g(x)).item()) < 1e-6
+    assert abs(S.ssim.ssimloss(g(x), g(y)).item() - S.O.ssimloss(x, y).item()) < 2e-6
+    l1, l2 = S.lncc.lncc_loss(g(x), g(y)).item(), S.lncc.lncc_loss(g(y), g(x)).item()
+    assert abs(l1 - l2) < 1e-7
+    assert abs(l1 - S.O.lncc_loss(x, y).item()) < 2e-6
+
+
+# --------------------------------------------------------------- end to end
+def _build_nets(S, g_npz, c, num_cascades, chans, sens_chans, pools):
+    net_T = S.cross.SpatialTransformer(c)
+    net_R = S.varnet.VarNet(num_cascades=num_cascades, sens_chans=sens_chans, sens_pools=pools, chans=chans,
+                            pools=pools, use_ref=True)
+    return net_T, net_R
+
+
+def _run_pipeline(S, net_T, net_R, img_full, img_aux, pruned, w, sparsity):
+    with torch.no_grad():
+        keep = (~pruned).float().to(DEV)
+        k_samp = S.ops.fft2c(g(img_full), colmask_out=keep)
+        samp = S.sig.ifft2(k_samp)
+        aux_abs = S.ops.cabs(g(img_aux))
+        samp_abs = S.ops.cabs(samp)
+        offset, grid = net_T(aux_abs, samp_abs)
+        warped = net_T.warp(aux_abs, grid)
+        rec = net_R(k_samp, (~pruned).to(DEV), warped, int(w * sparsity * 0.32))
+        loss_sim = S.ssim.ssimloss(S.sig.rss(g(img_full)), rec)
+        loss_smooth = S.ops.gradient_loss_nchw(net_T._last_offset_nchw)
+    return dict(img_k_sampled=k_samp, img_sampled=samp, img_offset=offset, img_grid=grid, img_warped=warped,
+                img_rec=rec, loss_sim=loss_sim, loss_smooth=loss_smooth)
+
+
+@pytest.mark.parametrize("tag,shape", [("32", (2, 1, 32, 32)), ("48x80c3", (2, 3, 48, 80))])
+def test_e2e_small_golden(S, tag, shape):
+    gold = load_golden(f"e2e_small_{tag}.npz")
+    n, c, h, w = shape
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+    net_T, net_R = _build_nets(S, gold, c, 2, 4, 2, 2)
+    net_T.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net_T.state_dict().items()], seed=41))
+    net_R.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net_R.state_dict().items()], seed=42))
+    net_T.to(DEV).eval()
+    net_R.to(DEV).eval()
+    o = _run_pipeline(S, net_T, net_R, img_full, img_aux, pruned, w, 0.25)
+    assert rel_err(o["img_k_sampled"].cpu(), as_t(gold["eval.img_k_sampled"], True)) < 3e-6
+    assert rel_err(o["img_sampled"].cpu(), as_t(gold["eval.img_sampled"], True)) < 3e-6
+    assert rel_err(o["img_offset"].cpu(), as_t(gold["eval.img_offset"])) < 3e-5
+    assert rel_err(o["img_warped"].cpu(), as_t(gold["eval.img_warped"])) < 3e-5
+    assert rel_err(o["img_rec"].cpu(), as_t(gold["eval.img_rec"])) < 1e-4          # north_star bar
+    assert abs(o["loss_sim"].item() - float(gold["eval.loss_sim"])) < 2e-5
+    ls = float(gold["eval.loss_smooth"])
+    assert abs(o["loss_smooth"].item() - ls) < 1e-4 * max(abs(ls), 1e-6)
+
+
+def test_e2e_full_320_golden(S):
+    """Config-2 network (12 cascades, chans 18, sens_chans 8) at 320x320, N=1,
+    against the reference's own fp32 output, with its fp64 run as arbiter."""
+    gold = load_golden("e2e_full_320.npz")
+    n, c, h, w = 1, 1, 320, 320
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=1234)
+    assert torch.equal(img_full.real, as_t(gold["img_full_re"]))
+    pruned = as_t(gold["pruned"])
+    net_T = S.cross.SpatialTransformer(1)
+    net_R = S.varnet.VarNet(num_cascades=12, sens_chans=8, sens_pools=4, chans=18, pools=4, use_ref=True)
+    net_T.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net_T.state_dict().items()], seed=1235))
+    net_R.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net_R.state_dict().items()], seed=1236))
+    net_T.to(DEV).eval()
+    net_R.to(DEV).eval()
+    o = _run_pipeline(S, net_T, net_R, img_full, img_aux, pruned, w, 0.25)
+    ref32, ref64 = as_t(gold["img_rec"]), as_t(gold["img_rec_f64"])
+    e_ref = rel_err(ref32, ref64)                      # the reference's own fp32 noise (about 4.5e-5)
+    e32 = rel_err(o["img_rec"].cpu(), ref32)
+    e64 = rel_err(o["img_rec"].cpu(), ref64)
+    print(f"rec rel-L2: hip-vs-ref32 {e32:.2e}, hip-vs-ref64 {e64:.2e}, ref32-vs-ref64 {e_ref:.2e}")
+    assert rel_err(o["img_offset"].cpu(), as_t(gold["img_offset"])) < 3e-5
+    assert rel_err(o["img_warped"].cpu(), as_t(gold["img_warped"])) < 3e-5
+    assert e32 < 1e-4                                   # north_star: within 1e-4 of the CPU reference
+    assert e64 < max(1e-4, 2 * e_ref)                   # and no further from the truth than the reference is
+    assert abs(o["loss_sim"].item() - float(gold["loss_sim"])) < 2e-5
+    psnr = S.O.psnr(ref32, o["img_rec"].cpu())
+    print(f"PSNR(hip, ref32) = {psnr:.1f} dB")
+    assert psnr > 80.0
