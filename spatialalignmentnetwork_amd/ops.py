@@ -203,16 +203,14 @@ def cabs(x: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 # conv / norm stack
 # ---------------------------------------------------------------------------
-_PACK_CACHE: Dict[Tuple, Tuple[int, torch.Tensor]] = {}
-
-
 def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     """Repacked copy of a conv weight for the scalar-operand kernels, cached on
     (storage, version) so an optimizer step invalidates it."""
-    key = (w.data_ptr(), tuple(w.shape), transposed)
-    ver = w._version
-    hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == ver:
+    # the cache lives ON the tensor object (so it dies with it: a data_ptr-keyed table would
+    # hand a freed layer's packing to whichever new weight the allocator puts at that address)
+    tagv = (w._version, w.data_ptr(), transposed)
+    hit = getattr(w, "_san_packed", None)
+    if hit is not None and hit[0] == tagv:
         return hit[1]
     _chk(w, name="weight")
     if transposed:
@@ -222,7 +220,7 @@ def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     nfl = lib().query("san_conv_packed_floats", cout, cin, ks)
     packed = torch.empty(nfl, device=w.device, dtype=torch.float32)
     lib().call("san_conv_pack_weights", _p(w.detach()), _p(packed), cout, cin, ks, int(transposed), _stream())
-    _PACK_CACHE[key] = (ver, packed)
+    w._san_packed = (tagv, packed)
     return packed
 
 
