@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the reconstruction + alignment hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic input already
+resident in HBM: CSModel.set_input (fft2 -> column mask -> ifft2 -> rss),
+forwardT (alignment U-Net + bilinear warp + smoothness loss) and forwardR
+(VarNet: sensitivity net + 12 cascades of [ifft2.conj(S).sum -> NormUnet -> fft2
++ soft DC] + rss, then the SSIM loss), BASELINE.json configs[1]: batch 8 of
+320x320 single-coil slices per GPU, 12 cascades, chans 18, sens_chans 8.
+Slices are independent, so N GPUs run N shards with no data-path collective
+(weak scaling); only the timing is reduced across ranks.
+
+Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max
+rank time) that also carries
+  roofline      : the dominant kernel (by GPU time inside the timed region),
+                  algorithmic work / HIP-event time of its launches;
+  roofline_fft_dc: the fused FFT + data-consistency kernels against HBM;
+  cpu_baseline  : the CPU oracle (PyTorch CPU restatement of the reference) timed
+                  on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
+
+
+def build_model(n_per_gpu, h, w, num_cascades, dev, seed=0):
+    from spatialalignmentnetwork_amd import synth
+    from spatialalignmentnetwork_amd.basemodel import Config
+    from spatialalignmentnetwork_amd.model import CSModel
+    cfg = Config(sparsity=0.25, lr=1e-4, shape=w, coils=1, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                 weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=num_cascades)
+    net = CSModel(cfg)
+    net.net_mask.pruned = synth.equispaced_pruned(w, 0.25, 0)
+    # random-init weights of the reference's architecture (no checkpoints offline), deterministic per name
+    for sub, sd in (("net_T", 1), ("net_R", 2)):
+        m = getattr(net, sub)
+        m.load_state_dict(synth.fill_params([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=seed + sd))
+    net.to(dev).eval()
+    return net
+
+
+def one_step(net, img_full, img_aux):
+    with torch.no_grad():
+        net.set_input(img_full, img_aux)
+        net.loss_all = 0
+        net.forwardT()
+        net.forwardR()
+    return net.img_rec
+
+
+def usable_cores(cap=32):
+    """Host threads the baseline may really use: the affinity mask and the cgroup CPU quota,
+    not os.cpu_count() (a 256-thread oneDNN team on a quota-limited box crawls), capped."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(num_cascades, h, w, budget_s=20.0):
+    """The oracle on host cores: same arithmetic as the reference's CPU path
+    (same ATen kernels), N=1 slices one at a time until ~budget_s is spent."""
+    from oracle import cpu_ref as O
+    from spatialalignmentnetwork_amd import synth
+    from spatialalignmentnetwork_amd.cross import SpatialTransformer
+    from spatialalignmentnetwork_amd.varnet import VarNet
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    t_shapes = [(k, tuple(v.shape)) for k, v in SpatialTransformer(1).state_dict().items()]
+    r_shapes = [(k, tuple(v.shape)) for k, v in VarNet(num_cascades=num_cascades, use_ref=True).state_dict().items()]
+    pT, pR = synth.fill_params(t_shapes, seed=1), synth.fill_params(r_shapes, seed=2)
+    img_full, img_aux = synth.phantom_pair(1, 1, h, w, seed=1234)
+    pruned = synth.equispaced_pruned(w, 0.25, 0)
+    run = lambda: O.recon_align_forward(pT, pR, img_full, img_aux, pruned, shape=w, sparsity=0.25,
+                                        num_cascades=num_cascades)
+    warm = lambda: O.recon_align_forward(pT, pR, img_full, img_aux, pruned, shape=w, sparsity=0.25, num_cascades=1)
+    with torch.no_grad():
+        warm()                      # warm-up on a 1-cascade pass (thread pools, oneDNN primitives)
+        t0 = time.perf_counter()
+        done = 0
+        while True:
+            run()
+            done += 1
+            if time.perf_counter() - t0 > budget_s or done >= 16:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"{done} slice(s) of the same workload, one at a time (N=1), 1 warm-up, {dt:.1f} s of CPU work"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="slices per GPU")
+    ap.add_argument("--size", type=int, default=320)
+    ap.add_argument("--cascades", type=int, default=12)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from spatialalignmentnetwork_amd import ops, synth
+    n, h, w = args.batch, args.size, args.size
+    net = build_model(n, h, w, args.cascades, dev)
+    img_full, img_aux = synth.phantom_pair(n, 1, h, w, seed=1234 + rank)
+    img_full, img_aux = img_full.to(dev), img_aux.to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        one_step(net, img_full, img_aux)
+    torch.cuda.synchronize()
+    barrier()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step(net, img_full, img_aux)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    if rank == 0:
+        total_slices = n * world * args.steps
+        out = {
+            "metric": "slices/sec (320x320, 12-cascade VarNet+align)", "value": total_slices / dt, "unit": "slices/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"inference pass set_input+align+warp+VarNet{args.cascades}+SSIM, "
+                                   f"{n} slices/GPU of {h}x{w} single-coil, 4x equispaced mask, random-init weights",
+                       "slices_per_gpu": n, "global_batch": n * world, "cascades": args.cascades,
+                       "parallelism": f"dp{world} (independent slice shards, no data-path collective)"},
+        }
+        if timer is not None:
+            tot = timer.totals()
+            dom = max(tot, key=lambda k: tot[k]["ms"])
+            for key, field in ((dom, "roofline"), ("fft_dc", "roofline_fft_dc")):
+                if key not in tot:
+                    continue
+                d = tot[key]
+                sec = d["ms"] * 1e-3
+                if d["unit"] == "FLOP":
+                    ach, peak, unit, bound = d["work"] / sec / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s", "mfma"
+                else:
+                    ach, peak, unit, bound = d["work"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+                out[field] = {"kernel": key, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                              "frac": ach / peak, "traffic": None, "launches": d["launches"],
+                              "avg_launch_us": 1e3 * d["ms"] / d["launches"],
+                              "share_of_step": d["ms"] / (1e3 * dt)}
+            out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cascades, h, w)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference's CSModel (model.py:39-321) for the
+reconstruction + alignment path: same constructor, ``set_input`` / ``forwardT`` /
+``forwardR`` / ``test`` / ``get_vis`` / ``save`` / ``load`` protocol and the same
+``img_*`` / ``loss_*`` / ``metric_*`` attribute discovery, driving the HIP kernels.
+
+Scope notes: the GAN branch (``net_G`` / ``net_D``, regimes
+'Mixed' and 'GAN-Only') is out of scope for this path, so ``test()`` does not run
+``forwardG`` and reports no ``loss_gan_sim``; ``num_cascades`` etc. are
+constructor-visible through cfg (defaults = the reference's hard-coded values,
+model.py:64-71) instead of being hard-coded.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+from .basemodel import BaseModel, Config  # noqa: F401
+from .cross import SpatialTransformer
+from .masks import masks
+from .signal_utils import rss
+from .ssimloss import ssimloss
+from .varnet import VarNet
+
+
+def gradient_loss(s: torch.Tensor) -> torch.Tensor:
+    """Smoothness of an NHWC offset field (model.py:21-28).  ``s`` must be the
+    permuted view SpatialTransformer.forward returns (NCHW storage)."""
+    assert s.shape[-1] == 2, "not 2D grid?"
+    nchw = s.permute(0, 3, 1, 2)
+    if not nchw.is_contiguous():
+        nchw = nchw.contiguous()
+    return ops.gradient_loss_nchw(nchw)
+
+
+class CSModel(BaseModel):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init"}
+
+    def build(self, cfg):
+        super().build(cfg)
+        assert cfg.lr == 1e-4          # model.py:52
+        shape, sparsity, coils = cfg.shape, cfg.sparsity, cfg.coils
+        get = lambda k, d: cfg[k] if k in cfg else d
+        mask = cfg.mask
+        self.net_mask = masks[mask](shape) if mask == "mask" else masks[mask](sparsity, shape)
+        self.net_T = SpatialTransformer(channels=coils)
+        self.net_R = VarNet(num_cascades=get("num_cascades", 8), sens_chans=get("sens_chans", 8),
+                            sens_pools=get("sens_pools", 4), chans=get("chans", 18), pools=get("pools", 4),
+                            use_ref=True)
+        self.optim_T = torch.optim.AdamW(self.net_T.parameters(), lr=cfg.lr, weight_decay=0)
+        self.optim_R = torch.optim.AdamW(self.net_R.parameters(), lr=cfg.lr, weight_decay=0)
+        self.use_amp = bool(get("use_amp", False))
+        self.device = torch.device("cpu")
+
+    # ------------------------------------------------------------------ inputs
+    def set_input(self, img_full, img_aux=None):
+        """fft2 -> drop pruned columns -> ifft2 -> rss x3.  model.py:89-121."""
+        for name in [k for k in self.__dict__ if k.startswith(("loss_", "img_", "metric_"))]:
+            delattr(self, name)
+        extra = set(self.__dict__.keys()) - self.memo_init
+        assert len(extra) == 0, extra
+        self.img_full = img_full.contiguous()
+        self.img_aux = torch.zeros_like(img_full) if img_aux is None else img_aux.contiguous()
+        pruned = self.net_mask.pruned
+        keep = _keep_mask(pruned)
+        self.img_k_full = ops.fft2c(self.img_full)
+        self.img_k_sampled = ops.fft2c(self.img_full, colmask_out=keep)      # k_full * (1 - pruned)
+        self.img_sampled = ops.fft2c(self.img_k_sampled, inverse=True)
+        self.img_full_rss = rss(self.img_full)
+        self.img_sampled_rss = rss(self.img_sampled)
+        self.img_aux_rss = rss(self.img_aux)
+        n, _, h, w = self.img_full.shape
+        vis = (1.0 - pruned.float()).roll(w // 2).view(1, 1, 1, w).expand(n, 1, h, w)   # fftshift2 of a column mask
+        self.img_mask = vis
+
+    # ---------------------------------------------------------------- forwards
+    def forwardT(self):
+        """model.py:142-155."""
+        aux_abs = ops.cabs(self.img_aux)
+        self.img_offset, self.img_grid = self.net_T(moving=aux_abs, fixed=ops.cabs(self.img_sampled))
+        self.img_warped = self.net_T.warp(aux_abs, self.img_grid)
+        self.img_warped_rss = rss(self.img_warped)
+        self.loss_smooth = gradient_loss(self.img_offset)
+        self.loss_all = self.loss_all + self.loss_smooth * self.cfg.weight_smooth
+
+    def forwardR(self):
+        """model.py:157-169."""
+        self.img_rec = self.net_R(
+            masked_kspace=self.img_k_sampled,
+            mask=torch.logical_not(self.net_mask.pruned),
+            ref=self.img_warped,
+            num_low_frequencies=int(self.cfg.shape * self.cfg.sparsity * 0.32))
+        self.loss_sim = ssimloss(self.img_full_rss, self.img_rec)
+        self.loss_all = self.loss_all + self.loss_sim * self.cfg.weight_sim
+
+    def update(self):
+        raise NotImplementedError(
+            "training step (hand-written backward kernels + AdamW) is not built yet; "
+            "the HIP path currently covers set_input / forwardT / forwardR / test")
+
+    def test(self):
+        """model.py:265-286 without the GAN branch; returns -PSNR."""
+        assert self.training is False
+        with torch.no_grad():
+            self.loss_all = 0
+            self.forwardT()
+            self.loss_all = 0
+            self.forwardR()
+            gt, pred = self.img_full_rss.double(), self.img_rec.double()
+            mse = ((gt - pred) ** 2).mean().item()
+            self.metric_MSE = mse
+            self.metric_MAE = (gt - pred).abs().mean().item()
+            self.metric_PSNR = 10.0 * math.log10(1.0 / mse) if mse > 0 else float("inf")   # data_range 1, whole batch
+        return -self.metric_PSNR
+
+    def get_vis(self, content=None):
+        """model.py:292-321."""
+        assert content in [None, "scalars", "histograms", "images"]
+        vis = {}
+        if content in (None, "scalars"):
+            vis["scalars"] = {}
+            for k, v in self.__dict__.items():
+                if k.startswith("loss_") and v is not None and k != "loss_all":
+                    vis["scalars"][k] = v.detach().item()
+                elif k.startswith("metric_") and v is not None:
+                    vis["scalars"][k] = v
+        if content in (None, "images"):
+            vis["images"] = {k: v.detach() for k, v in self.__dict__.items()
+                             if k.startswith("img_") and v is not None and not torch.is_complex(v)
+                             and v.shape[1] in (1, 3)}
+        if content in (None, "histograms"):
+            vis["histograms"] = {"weights": {"values": self.net_mask.weight.detach()}}
+        return vis
+
+
+_KEEP_CACHE = {}
+
+
+def _keep_mask(pruned: torch.Tensor) -> torch.Tensor:
+    """float [W] 1 = sampled; cached per buffer (the mask is fixed for a model's lifetime)."""
+    key = (pruned.data_ptr(), pruned._version, str(pruned.device))
+    hit = _KEEP_CACHE.get(key)
+    if hit is None or hit[0] is not pruned:
+        hit = (pruned, (~pruned).to(torch.float32).contiguous())
+        _KEEP_CACHE[key] = hit
+    return hit[1]

@@ -17,6 +17,42 @@ from ._lib import lib
 NORM_INSTANCE, NORM_GROUP, NORM_BATCH = 0, 1, 2
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (bench.py
+    uses it for the roofline figures).  bracket(name, work, unit, fn) times one
+    C-ABI call; totals() needs a prior device synchronisation."""
+
+    def __init__(self):
+        self.recs = []
+
+    def bracket(self, name, work, unit, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.recs.append((name, work, unit, e0, e1))
+
+    def totals(self):
+        out = {}
+        for name, work, unit, e0, e1 in self.recs:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
+
+
+TIMER: Optional[KernelTimer] = None
+
+
+def _timed(name, work, unit, fn):
+    if TIMER is None:
+        fn()
+    else:
+        TIMER.bracket(name, work, unit, fn)
+
+
 def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -148,8 +184,10 @@ def sens_reduce(k: torch.Tensor, sens: torch.Tensor, out: torch.Tensor) -> torch
     n, c, h, w = k.shape
     _chk(out, name="out")
     ws = fft_workspace(n * c, h, w, k.device)
-    lib().call("san_sens_reduce", _p(_creal(k, "k")), _p(_creal(sens, "sens")), _p(out), int(out.shape[1]), n, c, h, w,
-               _p(ws), ws.numel() * 4, _stream())
+    args = (_p(_creal(k, "k")), _p(_creal(sens, "sens")), _p(out), int(out.shape[1]), n, c, h, w, _p(ws), ws.numel() * 4,
+            _stream())
+    # algorithmic bytes: read k and S (C planes each), write m (1 plane); E = H*W*8
+    _timed("fft_dc", float((2 * c + 1) * n * h * w * 8), "B", lambda: lib().call("san_sens_reduce", *args))
     return out
 
 
@@ -159,9 +197,11 @@ def sens_expand_dc(r_planar: torch.Tensor, sens: torch.Tensor, k: torch.Tensor, 
     _chk(r_planar, name="r_planar")
     assert r_planar.shape == (n, 2, h, w)
     ws = fft_workspace(n * c, h, w, k.device)
-    lib().call("san_sens_expand_dc", _p(r_planar), _p(_creal(sens, "sens")), _p(_creal(k, "k")), _p(_creal(k0, "k0")),
-               _p(_chk(mask, name="mask")), _p(_chk(dc_w, name="dc_w")), _p(_creal(k_out, "k_out")), n, c, h, w,
-               _p(ws), ws.numel() * 4, _stream())
+    args = (_p(r_planar), _p(_creal(sens, "sens")), _p(_creal(k, "k")), _p(_creal(k0, "k0")),
+            _p(_chk(mask, name="mask")), _p(_chk(dc_w, name="dc_w")), _p(_creal(k_out, "k_out")), n, c, h, w,
+            _p(ws), ws.numel() * 4, _stream())
+    # algorithmic bytes: read r (1 plane), S, k, k0 (C planes each), write k' (C planes)
+    _timed("fft_dc", float((4 * c + 1) * n * h * w * 8), "B", lambda: lib().call("san_sens_expand_dc", *args))
     return k_out
 
 
@@ -238,9 +278,10 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
     if stats:
         tiles = lib().query("san_conv_stat_tiles", h, w, cin, cout, ks)
         part = arena.get("part" + tag, (n, cout, tiles, 3), x.buf.device)
-    lib().call("san_conv2d_fwd", _p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope),
-               _p(wp), _p(bias), _p(y.buf), y.ctot, y.coff, cout, _p(out_scale), _p(out_shift), _p(part),
-               n, h, w, ks, _stream())
+    args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
+            y.ctot, y.coff, cout, _p(out_scale), _p(out_shift), _p(part), n, h, w, ks, _stream())
+    _timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
+           lambda: lib().call("san_conv2d_fwd", *args))
     return part
 
 
@@ -254,8 +295,9 @@ def tconv2x2(x: Act, weight: torch.Tensor, y: Act, stats: bool = False, arena: A
     if stats:
         tiles = lib().query("san_tconv_stat_tiles", x.h, x.w, cout)
         part = arena.get("tpart" + tag, (x.n, cout, tiles, 3), x.buf.device)
-    lib().call("san_tconv2x2_fwd", _p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope),
-               _p(wp), _p(y.buf), y.ctot, y.coff, cout, _p(part), x.n, x.h, x.w, _stream())
+    args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(y.buf), y.ctot, y.coff,
+            cout, _p(part), x.n, x.h, x.w, _stream())
+    _timed("tconv2x2", 2.0 * x.n * x.h * x.w * 4 * cout * cin, "FLOP", lambda: lib().call("san_tconv2x2_fwd", *args))
     return part
 
 
