@@ -117,9 +117,9 @@ int san_conv_pack_weights(const float* w, float* packed, int cout, int cin, int 
  * read at [n, x_coff + ci].
  * If part_stats != NULL the kernel also writes per-tile (count, mean, M2) of the
  * raw output for every (n, co): fp32 [n, cout, tiles, 3], tiles from
- * san_conv_stat_tiles(h, w, cin, cout, ks); feed them to san_norm_finalize.
+ * san_conv_stat_tiles(n, h, w, cin, cout, ks); feed them to san_norm_finalize.
  * Replaces F.conv2d at varnet.py:78,140,143 and unet.py:119-140,185-186. */
-int san_conv_stat_tiles(int h, int w, int cin, int cout, int ks);
+int san_conv_stat_tiles(int n, int h, int w, int cin, int cout, int ks);
 int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin,
                    const float* in_scale, const float* in_shift, float in_slope,
                    const float* w_packed, const float* bias,
@@ -155,9 +155,10 @@ int san_norm_finalize(const float* part, int n, int c, int tiles, int mode, floa
                       float* scale, float* shift, int sc_ctot, int sc_coff,
                       float* aux_a, float* aux_b, void* stream);
 
-/* Per-plane (count, mean, M2) partials of an existing tensor view, one tile per
- * plane: part [n, c, 1, 3].  Used for tensors no conv produced (ref image,
- * sens_reduce output). */
+/* (count, mean, M2) partials of an existing tensor view, san_plane_stat_tiles(hw)
+ * chunks per plane: part [n, c, tiles, 3].  Used for tensors no conv produced
+ * (ref image, sens_reduce output). */
+int san_plane_stat_tiles(int hw);
 int san_plane_stats(const float* x, int x_ctot, int x_coff, int c, int n, int hw,
                     float* part, void* stream);
 

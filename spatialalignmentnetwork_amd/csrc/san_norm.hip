@@ -70,21 +70,26 @@ norm_finalize_kernel(const float* __restrict__ part, int n, int c, int tiles, in
     }
 }
 
-// one workgroup per (c, n) plane: exact two-pass (mean, then centred M2)
+// `tiles` workgroups per (c, n) plane, each an exact two-pass (mean, then centred M2)
+// over its contiguous chunk; norm_finalize merges the chunks.  grid: (tiles, c, n)
 __global__ void __launch_bounds__(kThreads)
-plane_stats_kernel(const float* __restrict__ x, int x_ctot, int x_coff, int c, int hw, float* __restrict__ part) {
+plane_stats_kernel(const float* __restrict__ x, int x_ctot, int x_coff, int c, int hw, int tiles,
+                   float* __restrict__ part) {
     __shared__ float red[8];
-    const int ch = blockIdx.x, n = blockIdx.y;
-    const float* p = x + ((size_t)(n * x_ctot + x_coff + ch)) * hw;
+    const int t = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const int chunk = (hw + tiles - 1) / tiles;
+    const int lo = t * chunk;
+    const int cnt = max(0, min(hw, lo + chunk) - lo);
+    const float* p = x + ((size_t)(n * x_ctot + x_coff + ch)) * hw + lo;
     const int tid = threadIdx.x;
     float s = 0.f;
-    for (int i = tid; i < hw; i += kThreads) s += p[i];
+    for (int i = tid; i < cnt; i += kThreads) s += p[i];
     s = san_wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / (float)hw;
+    const float mean = cnt > 0 ? ((red[0] + red[1]) + (red[2] + red[3])) / (float)cnt : 0.f;
     float d = 0.f;
-    for (int i = tid; i < hw; i += kThreads) {
+    for (int i = tid; i < cnt; i += kThreads) {
         const float e = p[i] - mean;
         d = fmaf(e, e, d);
     }
@@ -92,8 +97,8 @@ plane_stats_kernel(const float* __restrict__ x, int x_ctot, int x_coff, int c, i
     if ((tid & 63) == 0) red[4 + (tid >> 6)] = d;
     __syncthreads();
     if (tid == 0) {
-        float* o = part + ((size_t)(n * c + ch)) * 3;
-        o[0] = (float)hw;
+        float* o = part + ((size_t)(n * c + ch) * tiles + t) * 3;
+        o[0] = (float)cnt;
         o[1] = mean;
         o[2] = (red[4] + red[5]) + (red[6] + red[7]);
     }
@@ -250,11 +255,17 @@ int san_norm_finalize(const float* part, int n, int c, int tiles, int mode, floa
     return SAN_OK;
 }
 
+int san_plane_stat_tiles(int hw) {
+    int t = san_cdiv(hw, 4096);
+    return t < 1 ? 1 : (t > 32 ? 32 : t);
+}
+
 int san_plane_stats(const float* x, int x_ctot, int x_coff, int c, int n, int hw, float* part, void* stream) {
     SAN_CHECK_ARG(x && part, "null pointer");
     SAN_CHECK_ARG(n > 0 && hw > 0 && check_view(x_ctot, x_coff, c), "bad dims");
-    hipLaunchKernelGGL(plane_stats_kernel, dim3(c, n), dim3(kThreads), 0, (hipStream_t)stream, x, x_ctot, x_coff, c,
-                       hw, part);
+    const int tiles = san_plane_stat_tiles(hw);
+    hipLaunchKernelGGL(plane_stats_kernel, dim3(tiles, c, n), dim3(kThreads), 0, (hipStream_t)stream, x, x_ctot,
+                       x_coff, c, hw, tiles, part);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -276,7 +276,7 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
     n, h, w = x.n, x.h, x.w
     part = None
     if stats:
-        tiles = lib().query("san_conv_stat_tiles", h, w, cin, cout, ks)
+        tiles = lib().query("san_conv_stat_tiles", n, h, w, cin, cout, ks)
         part = arena.get("part" + tag, (n, cout, tiles, 3), x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
             y.ctot, y.coff, cout, _p(out_scale), _p(out_shift), _p(part), n, h, w, ks, _stream())
@@ -310,7 +310,8 @@ def norm_finalize(part: torch.Tensor, mode: int, eps: float, scale: torch.Tensor
 
 
 def plane_stats(x: Act, arena: Arena = GLOBAL_ARENA, tag: str = "") -> torch.Tensor:
-    part = arena.get("pstat" + tag, (x.n, x.c, 1, 3), x.buf.device)
+    tiles = lib().query("san_plane_stat_tiles", x.h * x.w)
+    part = arena.get("pstat" + tag, (x.n, x.c, tiles, 3), x.buf.device)
     lib().call("san_plane_stats", _p(x.buf), x.ctot, x.coff, x.c, x.n, x.h * x.w, _p(part), _stream())
     return part
 
