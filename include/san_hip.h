@@ -101,11 +101,16 @@ int san_rss(const float* x, float* out, int n, int c, int hw, int is_complex, vo
 
 /* ------------------------------------------------------- conv / norm stack */
 
-/* Repack conv weights for the scalar-operand direct convolution:
- * w [cout, cin, ks, ks] -> packed [groups][cin][ks*ks][co_t], zero padded.
- * transposed != 0 reads a ConvTranspose2d weight [cin, cout, ks, ks].
- * san_conv_packed_floats gives the element count of `packed`. */
+/* Repack weights into the layout the kernels read (zero padded):
+ *   san_conv_pack_weights_fwd : Conv2d weight [cout, cin, ks, ks], ks in {1,3}, for
+ *                               san_conv2d_fwd (MFMA 4x4x1 outer-product layout
+ *                               [group][cin][tap][4][quads]);
+ *   san_conv_pack_weights     : transposed != 0: ConvTranspose2d weight [cin, cout, 2, 2]
+ *                               for san_tconv2x2_fwd (scalar-operand layout).
+ * san_conv_packed_floats(cout, cin, ks) gives the element count of `packed`
+ * (ks = 2 for the transposed convolution). */
 size_t san_conv_packed_floats(int cout, int cin, int ks);
+int san_conv_pack_weights_fwd(const float* w, float* packed, int cout, int cin, int ks, void* stream);
 int san_conv_pack_weights(const float* w, float* packed, int cout, int cin, int ks, int transposed,
                           void* stream);
 

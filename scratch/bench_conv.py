@@ -1,5 +1,5 @@
 import sys, torch, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatialalignmentnetwork_amd import ops
 dev='cuda:0'
 N=8

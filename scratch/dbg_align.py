@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spatialalignmentnetwork_amd import ops, synth, cross
 from oracle import cpu_ref as O
 from tests.conftest import philox, rel_err

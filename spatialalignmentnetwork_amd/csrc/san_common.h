@@ -40,6 +40,22 @@ __device__ __forceinline__ float san_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Total of all 64 lanes, returned wave-uniform.  Pure VALU (DPP butterflies inside each row
+// of 16 lanes, row_bcast across rows, readlane 63): no LDS crossbar traffic, unlike __shfl.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float san_dpp_get(float v) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float san_wave_total(float v) {
+    v += san_dpp_get<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v += san_dpp_get<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v += san_dpp_get<0x141, 0xf>(v);   // row_half_mirror
+    v += san_dpp_get<0x140, 0xf>(v);   // row_mirror: every lane holds its row's sum
+    v += san_dpp_get<0x142, 0xa>(v);   // row_bcast:15 into rows 1, 3
+    v += san_dpp_get<0x143, 0xc>(v);   // row_bcast:31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 __device__ __forceinline__ double san_wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1,0 +1,518 @@
+// fp32 convolution (3x3 / 1x1) on the CDNA4 matrix cores, built around
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products per
+// instruction.  Lane l = 4b + j supplies one A value (row j of block b) and one
+// B value (column j of block b) and receives D[i][lane] = A[4b+i] * B[4b+j]
+// (i = result register), verified on gfx950.  Mapping used here:
+//
+//      B operand : one activation per lane  -> 64 output pixels per instruction
+//      A operand : 4 weights (one output-channel quad) replicated in every block
+//      D         : lane l accumulates 4 output channels of ITS pixel
+//
+// i.e. the matrix core is used as a register-blocked outer-product engine with
+// 4-channel granularity: the U-Net's awkward channel counts cost at most
+// 18 -> 20 padding (10 %), nothing for 36/72/144/288/32/64, where 16- or 32-wide
+// MFMA tiles would waste 44 % / 25 % on the layers that hold half of the MACs,
+// and -- unlike the plain-VALU direct convolution this replaces -- the inner loop
+// has no VALU work at all: per input channel and tap a wave issues CQ*G MFMAs
+// (8 cycles each, exact fp32 FMA chains, bit-identical to fmaf) fed by G + 2
+// LDS reads.  fp32-input MFMA peaks at the fp32 vector rate (157 TF), so this is
+// about issue efficiency, not a higher roof.
+//
+// Workgroup = 4 waves.  WC waves share one staged input tile and take different
+// output-channel groups of CW = 4*CQ channels; WY waves stack in y.  A wave owns
+// G pixel groups of GW x GH = 64 lanes stacked in y.  Input tile: global ->
+// registers (prefetched one channel chunk ahead) -> lazy normalisation -> LDS.
+// Weights: packed [group][cin][tap][j][cq] so that a lane's CQ weights are
+// contiguous; staged per chunk to LDS by the same pipeline.
+//
+// Epilogue: bias, per-tile (count, mean, M2) statistics for Instance/BatchNorm,
+// optional per-(n, c) output affine, coalesced stores (a wave writes GW
+// consecutive pixels of one channel).
+#include "san_conv_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kCK = 4;        // input channels per staged chunk
+constexpr int kSlots = 5;     // staged input elements per thread per channel (<= 1280 per tile)
+constexpr int kMaxWSlots = 5; // staged weight float4s per thread per chunk (template WS in {1,2,3,5})
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct MGeom {
+    int cw;       // output channels per wave (4*CQ)
+    int cq, cqp;  // quads per wave, padded quad stride in the packed layout (multiple of 4)
+    int G;        // pixel groups per wave
+    int GW, GH;   // lanes per group along x / y (GW*GH <= 64)
+    int groups;   // ceil(cout / cw)
+    int WY, WC;
+    int TW, TH;
+    int tiles_x, tiles_y;
+    int pitch, rows_t;
+};
+
+struct MArgs {
+    const float* in_scale;
+    const float* in_shift;
+    const float* bias;
+    const float* out_scale;
+    const float* out_shift;
+    float* part;
+    float in_slope;
+    int x_ctot, x_coff, cin;
+    int y_ctot, y_coff, cout;
+    int N, H, W;
+    MGeom g;
+};
+
+// Output channels per wave: maximise (useful / padded channels) x (a preference for wide
+// waves: CQ quads share every activation read, narrow waves re-read the tile more often).
+int pick_cw(int cout) {
+    const int cand[4] = {20, 16, 8, 4};
+    const double pref[4] = {1.0, 1.0, 0.8, 0.6};
+    int best = 4;
+    double best_e = -1.0;
+    for (int i = 0; i < 4; ++i) {
+        const int cw = cand[i];
+        const double e = pref[i] * (double)cout / (double)(san_cdiv(cout, cw) * cw);
+        if (e > best_e + 1e-9) {
+            best_e = e;
+            best = cw;
+        }
+    }
+    return best;
+}
+
+MGeom mfma_geom(int N, int H, int W, int cout, int ks) {
+    MGeom g{};
+    g.cw = pick_cw(cout);
+    g.cq = g.cw / 4;
+    g.cqp = (g.cq + 3) & ~3;
+    g.groups = san_cdiv(cout, g.cw);
+    // WC = 1: every workgroup stages only its own output-channel group's weights.  Sharing one
+    // input tile between 2-4 groups (WC > 1) measured 0-50 % SLOWER on MI355X (more staging
+    // registers -> 2 waves/SIMD, more LDS write traffic per barrier), so it is not used.
+    g.WC = 1;
+    g.WY = 4 / g.WC;
+    const int pad = ks / 2;
+    const int gwc[7] = {64, 32, 16, 8, 20, 40, 10};
+    const int Gc[3] = {4, 2, 1};
+    const double Gw[3] = {1.0, 0.9, 0.75};      // fewer groups per wave = fewer MFMAs per weight read
+    double best = -1.0;
+    for (int ig = 0; ig < 3; ++ig) {
+        const int G = Gc[ig];
+        for (int iw = 0; iw < 7; ++iw) {
+            const int GW = gwc[iw], GH = 64 / GW;
+            const int TW = GW, TH = GH * G * g.WY;
+            if ((TW + 2 * pad) * (TH + 2 * pad) > kSlots * kThreads) continue;
+            const int tx = san_cdiv(W, TW), ty = san_cdiv(H, TH);
+            const double ex = (double)W / (tx * TW), ey = (double)H / (ty * TH);
+            const double el = (double)(GW * GH) / 64.0;
+            const double waves = (double)tx * ty * N * 4.0 * san_cdiv(g.groups, g.WC);
+            const double fill = waves >= 1024.0 ? 1.0 : (0.5 + 0.5 * waves / 1024.0);   // >= 1 wave per SIMD
+            const double halo = (double)(TW * TH) / ((TW + 2 * pad) * (TH + 2 * pad));
+            const double e = ex * ey * el * fill * Gw[ig] * (0.8 + 0.2 * halo);
+            if (e > best + 1e-9) {
+                best = e;
+                g.G = G;
+                g.GW = GW;
+                g.GH = GH;
+            }
+        }
+    }
+    g.TW = g.GW;
+    g.TH = g.GH * g.G * g.WY;
+    g.tiles_x = san_cdiv(W, g.TW);
+    g.tiles_y = san_cdiv(H, g.TH);
+    g.pitch = g.TW + 2 * pad;
+    if ((g.pitch & 1) == 0) g.pitch += 1;      // odd pitch: rows of a 2-/4-row pixel group fall on different banks
+    g.rows_t = g.TH + 2 * pad;
+    return g;
+}
+
+extern __shared__ __attribute__((aligned(16))) float mf_lds[];
+
+template <int CQ, int KS, int G, int WS>
+__global__ void __launch_bounds__(kThreads)
+conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, const MArgs a) {
+    constexpr int PAD = KS / 2;
+    constexpr int TAPS = KS * KS;
+    constexpr int CQP = (CQ + 3) & ~3;
+    constexpr int CW = 4 * CQ;
+    constexpr int WROW = 4 * CQP;                 // packed floats per (channel, tap) per group
+    const MGeom& M = a.g;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int wc = wave % M.WC;
+    const int wy = wave / M.WC;
+    const bool lane_ok = lane < M.GW * M.GH;
+    const int lrow = lane_ok ? lane / M.GW : 0;
+    const int lcol = lane_ok ? lane - lrow * M.GW : 0;
+    const int ty = blockIdx.x / M.tiles_x;
+    const int tx = blockIdx.x - ty * M.tiles_x;
+    const int x0 = tx * M.TW, y0 = ty * M.TH;
+    const int n = blockIdx.z;
+    const int grp0 = blockIdx.y * M.WC;           // first output-channel group of this workgroup
+    const int grp = grp0 + wc;                    // wave-uniform
+    const bool g_ok = grp < M.groups;
+    const int H = a.H, W = a.W;
+    const int pitch = M.pitch, rows_t = M.rows_t;
+    const int cols_t = M.TW + 2 * PAD;
+    const int tile_elems = rows_t * cols_t;
+    const int tile_stride = rows_t * pitch;
+    const size_t HW = (size_t)H * W;
+
+    float* lds_in = mf_lds;                                   // [kCK][rows_t][pitch]
+    const int w_chunk = kCK * TAPS * WROW;                    // weight floats per group per chunk
+    float* lds_w = mf_lds + ((kCK * tile_stride + kThreads + 3) & ~3);   // [WC][kCK][TAPS][4][CQP], 16-byte aligned
+    // 256 spare floats between the regions: slots that fall outside the tile store to their own
+    // dummy word (same-address LDS stores from many lanes serialise, one lane per cycle)
+    const int trash = kCK * tile_stride + tid;
+
+    // ---- staging maps (computed once): input halo tile and the weight chunk
+    int goff[kSlots], loff[kSlots];
+    bool inb[kSlots];
+#pragma unroll
+    for (int s = 0; s < kSlots; ++s) {
+        const int e = tid + s * kThreads;
+        const int r = e / cols_t, col = e - r * cols_t;
+        const int gy = y0 - PAD + r, gx = x0 - PAD + col;
+        const bool in_tile = e < tile_elems;
+        inb[s] = in_tile && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[s] = inb[s] ? gy * W + gx : 0;
+        loff[s] = in_tile ? r * pitch + col : -1 - 0 * r;
+    }
+    // weights: the chunk of group g is w_chunk contiguous floats at wp[(g*cin + c0) * TAPS * WROW];
+    // float4 slot q of this thread covers element (tid + q*256)*4 of the WC concatenated group chunks
+    const int w_total4 = M.WC * w_chunk / 4;
+
+    float stage[kCK][kSlots];
+    f4 wstage[WS];
+    auto prefetch = [&](int c0) {
+        const int cin_last = a.cin - 1;
+#pragma unroll
+        for (int ci = 0; ci < kCK; ++ci) {
+            const float* src = x + (size_t)(n * a.x_ctot + a.x_coff + min(c0 + ci, cin_last)) * HW;
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) stage[ci][s] = src[goff[s]];
+        }
+#pragma unroll
+        for (int q = 0; q < WS; ++q) {
+            const int e4 = tid + q * kThreads;
+            const int gsel = min((e4 * 4) / w_chunk, M.WC - 1);
+            const int within = e4 * 4 - gsel * w_chunk;       // float offset inside the group's chunk
+            const int gg = min(grp0 + gsel, M.groups - 1);
+            // the last chunk may run past cin: the packed buffer is padded by one chunk (zeros)
+            const float* src = wp + ((size_t)gg * a.cin + c0) * (TAPS * WROW) + within;
+            wstage[q] = (e4 < w_total4) ? *reinterpret_cast<const f4*>(src) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    f4 acc[G][CQ];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) acc[g][c] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int row0 = wy * (M.GH * G) + lrow;       // this lane's row inside the tile for group 0
+    const int in_base = row0 * pitch + lcol;
+    const int gstep = M.GH * pitch;                // LDS stride between pixel groups
+    const float* wl = lds_w + wc * w_chunk + (lane & 3) * CQP;
+    const int aff = n * a.x_ctot + a.x_coff;
+
+    prefetch(0);
+    for (int c0 = 0; c0 < a.cin; c0 += kCK) {
+        const int ckk = min(kCK, a.cin - c0);
+        __syncthreads();
+#pragma unroll
+        for (int ci = 0; ci < kCK; ++ci) {
+            float sc = 1.f, sh = 0.f;
+            if (a.in_scale) {
+                sc = a.in_scale[aff + min(c0 + ci, a.cin - 1)];
+                sh = a.in_shift[aff + min(c0 + ci, a.cin - 1)];
+            }
+#pragma unroll
+            for (int s = 0; s < kSlots; ++s) {
+                const float v = inb[s] ? san_act(stage[ci][s], sc, sh, a.in_slope) : 0.f;
+                lds_in[loff[s] >= 0 ? ci * tile_stride + loff[s] : trash] = v;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < WS; ++q) {
+            const int e4 = tid + q * kThreads;
+            if (e4 < w_total4) *reinterpret_cast<f4*>(lds_w + e4 * 4) = wstage[q];
+        }
+        __syncthreads();
+        if (c0 + kCK < a.cin) prefetch(c0 + kCK);
+        if (g_ok) {
+            // Software pipeline over (channel, tap) steps: the LDS reads of step s+1 (CQP weights
+            // + G activations per lane) are issued BEFORE the CQ*G MFMAs of step s, and
+            // sched_barrier keeps hipcc from sinking them back next to their first use, so LDS
+            // latency hides under ~160 cycles of matrix work instead of being exposed per tap.
+            float wcur[CQP], bcur[G];
+            auto load_step = [&](int ci, int tap, float (&wq)[CQP], float (&bq)[G]) {
+                const float* tw = wl + (ci * TAPS + tap) * WROW;
+#pragma unroll
+                for (int c4 = 0; c4 < CQP; c4 += 4) {
+                    const f4 t4 = *reinterpret_cast<const f4*>(tw + c4);
+                    wq[c4] = t4[0];
+                    wq[c4 + 1] = t4[1];
+                    wq[c4 + 2] = t4[2];
+                    wq[c4 + 3] = t4[3];
+                }
+                const float* tin = lds_in + ci * tile_stride + in_base + (tap / KS) * pitch + (tap % KS);
+#pragma unroll
+                for (int g = 0; g < G; ++g) bq[g] = tin[g * gstep];
+            };
+            load_step(0, 0, wcur, bcur);
+#pragma unroll 1
+            for (int ci = 0; ci < ckk; ++ci) {
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    float wnext[CQP], bnext[G];
+                    if (tap + 1 < TAPS) {
+                        load_step(ci, tap + 1, wnext, bnext);
+                    } else {
+                        load_step(min(ci + 1, kCK - 1), 0, wnext, bnext);   // clamped: the extra prefetch of the last step is unused
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < G; ++g)
+#pragma unroll
+                        for (int c = 0; c < CQ; ++c)
+                            acc[g][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wcur[c], bcur[g], acc[g][c], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int c = 0; c < CQP; ++c) wcur[c] = wnext[c];
+#pragma unroll
+                    for (int g = 0; g < G; ++g) bcur[g] = bnext[g];
+                }
+            }
+        }
+    }
+
+    // ------------------------------------------------------------ epilogue
+    const int ox = x0 + lcol;
+    bool valid[G];
+    int oyg[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        oyg[g] = y0 + row0 + g * M.GH;
+        valid[g] = lane_ok && g_ok && oyg[g] < H && ox < W;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int c = 0; c < CQ; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = grp * CW + 4 * c + i;
+                const float bv = (g_ok && co < a.cout) ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc[g][c][i] += bv;
+            }
+    }
+
+    if (a.part) {
+        // Per-WAVE statistics tile (no LDS, no barrier): single pass over the wave's G*64 outputs
+        // with every value shifted by a pilot sample c (one valid output of the same channel), so
+        //   mean = c + S1/n,  M2 = S2 - S1^2/n   with S1 = sum(x-c), S2 = sum((x-c)^2)
+        // has no catastrophic cancellation; wave totals by DPP butterflies (wave_total), partials
+        // merged later by san_norm_finalize (Chan).  Tile index = blockIdx.x * WY + wy.
+        const unsigned long long vm = __ballot(valid[0]);
+        const int src_lane = vm ? (int)__ffsll((long long)vm) - 1 : 0;
+        float cnt = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) cnt += valid[g] ? 1.f : 0.f;
+        cnt = san_wave_total(cnt);
+        const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+        float my_mean = 0.f, my_m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float pilot = __builtin_bit_cast(
+                    float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[0][c][i]), src_lane));
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const float e = valid[g] ? acc[g][c][i] - pilot : 0.f;
+                    s1 += e;
+                    s2 = fmaf(e, e, s2);
+                }
+                const float S1 = san_wave_total(s1), S2 = san_wave_total(s2);
+                if (lane == 4 * c + i) {
+                    my_mean = pilot + S1 * inv;
+                    my_m2 = fmaxf(S2 - S1 * S1 * inv, 0.f);
+                }
+            }
+        if (lane < CW && g_ok) {
+            const int co = grp * CW + lane;
+            if (co < a.cout) {
+                const int tiles = M.tiles_x * M.tiles_y * M.WY;
+                float* o = a.part + ((size_t)(n * a.cout + co) * tiles + blockIdx.x * M.WY + wy) * 3;
+                o[0] = cnt;
+                o[1] = cnt > 0.f ? my_mean : 0.f;
+                o[2] = cnt > 0.f ? my_m2 : 0.f;
+            }
+        }
+    }
+
+    if (!(lane_ok && g_ok) || ox >= W) return;
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = grp * CW + 4 * c + i;
+            if (co < a.cout) {
+                float os = 1.f, ob = 0.f;
+                if (a.out_scale) {
+                    os = a.out_scale[n * a.cout + co];
+                    ob = a.out_shift[n * a.cout + co];
+                }
+                float* dst = y + (size_t)(n * a.y_ctot + a.y_coff + co) * HW + ox;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (oyg[g] < H) dst[(size_t)oyg[g] * W] = fmaf(acc[g][c][i], os, ob);
+            }
+        }
+}
+
+// w [cout, cin, ks, ks] -> packed [groups][cin (+ kCK zero rows)][taps][4][CQP]; cout = g*CW + 4*cq + j
+__global__ void pack_mfma_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout, int cin, int taps,
+                                 int cw, int cqp, int groups) {
+    const int wrow = 4 * cqp;
+    const size_t total = (size_t)groups * cin * taps * wrow;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + (size_t)kCK * taps * wrow;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < total) {
+            const int cq = (int)(i % cqp);
+            const int j = (int)((i / cqp) % 4);
+            const int t = (int)((i / wrow) % taps);
+            const int ci = (int)((i / ((size_t)wrow * taps)) % cin);
+            const int g = (int)(i / ((size_t)wrow * taps * cin));
+            const int co = g * cw + 4 * cq + j;
+            if (4 * cq < cw && co < cout) v = w[((size_t)co * cin + ci) * taps + t];
+        }
+        packed[i] = v;
+    }
+}
+
+template <int CQ, int KS, int G>
+void launch_ws(const float* x, const float* wp, float* y, const MArgs& a, dim3 grid, size_t lds, int ws, hipStream_t s) {
+    if (KS == 1 || ws <= 1) {
+        hipLaunchKernelGGL((conv_mfma_kernel<CQ, KS, G, 1>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+    } else if (KS == 3 && ws == 2) {
+        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 2>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+    } else if (KS == 3 && ws == 3) {
+        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 3>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+    } else {
+        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 5>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+    }
+}
+
+template <int CQ, int KS>
+void launch_g(const float* x, const float* wp, float* y, const MArgs& a, dim3 grid, size_t lds, int ws, hipStream_t s) {
+    switch (a.g.G) {
+        case 4: launch_ws<CQ, KS, 4>(x, wp, y, a, grid, lds, ws, s); break;
+        case 2: launch_ws<CQ, KS, 2>(x, wp, y, a, grid, lds, ws, s); break;
+        default: launch_ws<CQ, KS, 1>(x, wp, y, a, grid, lds, ws, s); break;
+    }
+}
+
+template <int KS>
+int launch_mfma(const float* x, const float* wp, float* y, const MArgs& a, hipStream_t s) {
+    const MGeom& g = a.g;
+    dim3 grid(g.tiles_x * g.tiles_y, san_cdiv(g.groups, g.WC), a.N);
+    const int taps = KS * KS;
+    size_t in_fl = ((size_t)kCK * g.rows_t * g.pitch + kThreads + 3) & ~(size_t)3;
+    size_t w_fl = (size_t)g.WC * kCK * taps * 4 * g.cqp;
+    int ws = (int)((w_fl / 4 + kThreads - 1) / kThreads);
+    if (ws > kMaxWSlots) {
+        san_set_error("weight chunk too large for the staging slots");
+        return SAN_E_UNSUPPORTED;
+    }
+    ws = ws <= 1 ? 1 : (ws == 2 ? 2 : (ws == 3 ? 3 : 5));
+    size_t lds = (in_fl + w_fl) * sizeof(float);
+    size_t need = (size_t)(4 * g.cw * 2 + 4) * sizeof(float);
+    if (lds < need) lds = need;
+    switch (g.cq) {
+        case 1: launch_g<1, KS>(x, wp, y, a, grid, lds, ws, s); break;
+        case 2: launch_g<2, KS>(x, wp, y, a, grid, lds, ws, s); break;
+        case 4: launch_g<4, KS>(x, wp, y, a, grid, lds, ws, s); break;
+        case 5: launch_g<5, KS>(x, wp, y, a, grid, lds, ws, s); break;
+        default: san_set_error("bad cq %d", g.cq); return SAN_E_UNSUPPORTED;
+    }
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t san_conv_packed_floats(int cout, int cin, int ks) {
+    if (ks == 2) {  // ConvTranspose2d 2x2 keeps the scalar-operand layout (san_tconv.hip)
+        int ct = san_pick_co_t(cout);
+        return (size_t)san_cdiv(cout, ct) * ct * (size_t)cin * 4;
+    }
+    const int cw = pick_cw(cout);
+    const int cqp = ((cw / 4) + 3) & ~3;
+    return (size_t)san_cdiv(cout, cw) * cin * ks * ks * 4 * cqp + (size_t)kCK * ks * ks * 4 * cqp;
+}
+
+int san_conv_pack_weights_fwd(const float* w, float* packed, int cout, int cin, int ks, void* stream) {
+    SAN_CHECK_ARG(w && packed, "null pointer");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && (ks == 1 || ks == 3), "bad dims");
+    const int cw = pick_cw(cout);
+    const int cqp = ((cw / 4) + 3) & ~3;
+    const int groups = san_cdiv(cout, cw);
+    size_t total = (size_t)groups * cin * ks * ks * 4 * cqp;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cout, cin, ks * ks,
+                       cw, cqp, groups);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_conv_stat_tiles(int n, int h, int w, int cin, int cout, int ks) {
+    (void)cin;
+    MGeom g = mfma_geom(n, h, w, cout, ks);
+    return g.tiles_x * g.tiles_y * g.WY;   // one statistics tile per wave row
+}
+
+int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                   float in_slope, const float* w_packed, const float* bias, float* y, int y_ctot, int y_coff,
+                   int cout, const float* out_scale, const float* out_shift, float* part_stats, int n, int h, int w,
+                   int ks, void* stream) {
+    SAN_CHECK_ARG(x && w_packed && y, "null pointer");
+    SAN_CHECK_ARG(ks == 1 || ks == 3, "ks must be 1 or 3");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
+    SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + cout <= y_ctot, "bad channel view");
+    SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
+    SAN_CHECK_ARG((out_scale == nullptr) == (out_shift == nullptr), "out_scale/out_shift must come together");
+    MArgs a{};
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_slope = in_slope;
+    a.bias = bias;
+    a.out_scale = out_scale;
+    a.out_shift = out_shift;
+    a.part = part_stats;
+    a.x_ctot = x_ctot;
+    a.x_coff = x_coff;
+    a.cin = cin;
+    a.y_ctot = y_ctot;
+    a.y_coff = y_coff;
+    a.cout = cout;
+    a.N = n;
+    a.H = h;
+    a.W = w;
+    a.g = mfma_geom(n, h, w, cout, ks);
+    if (ks == 3) return launch_mfma<3>(x, w_packed, y, a, (hipStream_t)stream);
+    return launch_mfma<1>(x, w_packed, y, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -169,11 +169,6 @@ void tconv_geom(int H, int W, int cout, TconvArgs& a) {
 
 extern "C" {
 
-size_t san_conv_packed_floats(int cout, int cin, int ks) {
-    int ct = san_pick_co_t(cout);
-    return (size_t)san_cdiv(cout, ct) * ct * (size_t)cin * ks * ks;
-}
-
 int san_conv_pack_weights(const float* w, float* packed, int cout, int cin, int ks, int transposed, void* stream) {
     SAN_CHECK_ARG(w && packed, "null pointer");
     SAN_CHECK_ARG(cout > 0 && cin > 0 && ks >= 1 && ks <= 3, "bad dims");

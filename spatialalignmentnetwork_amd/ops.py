@@ -259,7 +259,10 @@ def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
         cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
     nfl = lib().query("san_conv_packed_floats", cout, cin, ks)
     packed = torch.empty(nfl, device=w.device, dtype=torch.float32)
-    lib().call("san_conv_pack_weights", _p(w.detach()), _p(packed), cout, cin, ks, int(transposed), _stream())
+    if transposed:
+        lib().call("san_conv_pack_weights", _p(w.detach()), _p(packed), cout, cin, ks, 1, _stream())
+    else:
+        lib().call("san_conv_pack_weights_fwd", _p(w.detach()), _p(packed), cout, cin, ks, _stream())
     w._san_packed = (tagv, packed)
     return packed
 

@@ -34,9 +34,12 @@ def test_error_path_without_gpu(built):
     with pytest.raises(RuntimeError, match="null"):
         lib.call("san_rss", None, None, 1, 1, 16, 0, None)
     assert "null" in lib.last_error()
-    assert lib.query("san_conv_packed_floats", 18, 3, 3) == 18 * 3 * 9
-    assert lib.query("san_conv_packed_floats", 36, 18, 3) == 36 * 18 * 9
-    assert lib.query("san_conv_packed_floats", 6, 4, 3) == 6 * 4 * 9
+    # MFMA layout [groups][cin + 4 pad rows][taps][4][quads padded to 4]: 18 -> one group of 20 (quads 5 -> 8)
+    assert lib.query("san_conv_packed_floats", 18, 3, 3) == 1 * (3 + 4) * 9 * 4 * 8
+    assert lib.query("san_conv_packed_floats", 36, 18, 3) == 2 * 18 * 9 * 32 + 4 * 9 * 32   # 36 -> 2 groups of 20
+    assert lib.query("san_conv_packed_floats", 64, 64, 1) == 4 * 64 * 1 * 16 + 4 * 1 * 16
+    # transposed conv keeps the scalar-operand layout [groups][cin][4 taps][co_t]
+    assert lib.query("san_conv_packed_floats", 18, 36, 2) == 18 * 36 * 4
     assert lib.query("san_fft_workspace_bytes", 8, 320, 320) == 8 * 320 * 320 * 8
 
 
