@@ -106,7 +106,8 @@ int san_rss(const float* x, float* out, int n, int c, int hw, int is_complex, vo
  *                               san_conv2d_fwd (MFMA 4x4x1 outer-product layout
  *                               [group][cin][tap][4][quads]);
  *   san_conv_pack_weights     : transposed != 0: ConvTranspose2d weight [cin, cout, 2, 2]
- *                               for san_tconv2x2_fwd (scalar-operand layout).
+ *                               for san_tconv2x2_fwd (same layout over 4*cout
+ *                               virtual channels); transposed == 0 forwards to _fwd.
  * san_conv_packed_floats(cout, cin, ks) gives the element count of `packed`
  * (ks = 2 for the transposed convolution). */
 size_t san_conv_packed_floats(int cout, int cin, int ks);
@@ -135,9 +136,11 @@ int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin,
 
 /* ConvTranspose2d 2x2 stride 2, no bias: y [n, cout, 2h, 2w].
  * w_packed from san_conv_pack_weights(..., ks=2, transposed=1).
- * part_stats: fp32 [n, cout, san_tconv_stat_tiles(h, w, cout), 3].
+ * Evaluated as a 1x1 convolution to 4*cout virtual channels (one per tap) on
+ * the MFMA kernel + a 2x2 pixel shuffle in the store.
+ * part_stats: fp32 [n, cout, san_tconv_stat_tiles(n, h, w, cout), 3].
  * Replaces nn.ConvTranspose2d at varnet.py:177-179. */
-int san_tconv_stat_tiles(int h, int w, int cout);
+int san_tconv_stat_tiles(int n, int h, int w, int cout);
 int san_tconv2x2_fwd(const float* x, int x_ctot, int x_coff, int cin,
                      const float* in_scale, const float* in_shift, float in_slope,
                      const float* w_packed,

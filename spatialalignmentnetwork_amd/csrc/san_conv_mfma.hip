@@ -28,7 +28,7 @@
 // Epilogue: bias, per-tile (count, mean, M2) statistics for Instance/BatchNorm,
 // optional per-(n, c) output affine, coalesced stores (a wave writes GW
 // consecutive pixels of one channel).
-#include "san_conv_common.h"
+#include "san_common.h"
 
 namespace {
 
@@ -62,6 +62,7 @@ struct MArgs {
     int x_ctot, x_coff, cin;
     int y_ctot, y_coff, cout;
     int N, H, W;
+    int shuffle;   // 1: ConvTranspose2d 2x2 s2 evaluated as a 1x1 conv to 4*cout channels + 2x2 pixel shuffle
     MGeom g;
 };
 
@@ -359,6 +360,27 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
     }
 
     if (!(lane_ok && g_ok) || ox >= W) return;
+    if (a.shuffle) {
+        // channel c' = 4*co + t holds tap t = 2*dy + dx of output channel co: a lane's f4 accumulator
+        // is exactly the 2x2 output block of its input pixel -> two 8-byte stores per channel,
+        // contiguous across lanes
+        const int OW = 2 * W;
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) {
+            const int cp = grp * CW + 4 * c;
+            if (cp < a.cout) {
+                float* dst = y + (size_t)(n * a.y_ctot + a.y_coff + (cp >> 2)) * (4 * HW) + 2 * ox;
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    if (oyg[g] < H) {
+                        float* d = dst + (size_t)(2 * oyg[g]) * OW;
+                        *reinterpret_cast<float2*>(d) = make_float2(acc[g][c][0], acc[g][c][1]);
+                        *reinterpret_cast<float2*>(d + OW) = make_float2(acc[g][c][2], acc[g][c][3]);
+                    }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < CQ; ++c)
 #pragma unroll
@@ -380,7 +402,7 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
 
 // w [cout, cin, ks, ks] -> packed [groups][cin (+ kCK zero rows)][taps][4][CQP]; cout = g*CW + 4*cq + j
 __global__ void pack_mfma_kernel(const float* __restrict__ w, float* __restrict__ packed, int cout, int cin, int taps,
-                                 int cw, int cqp, int groups) {
+                                 int cw, int cqp, int groups, int transposed) {
     const int wrow = 4 * cqp;
     const size_t total = (size_t)groups * cin * taps * wrow;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + (size_t)kCK * taps * wrow;
@@ -393,7 +415,9 @@ __global__ void pack_mfma_kernel(const float* __restrict__ w, float* __restrict_
             const int ci = (int)((i / ((size_t)wrow * taps)) % cin);
             const int g = (int)(i / ((size_t)wrow * taps * cin));
             const int co = g * cw + 4 * cq + j;
-            if (4 * cq < cw && co < cout) v = w[((size_t)co * cin + ci) * taps + t];
+            // transposed: cout = 4*Cout' virtual channels c' = 4*co + tap of a ConvTranspose2d weight [cin, Cout', 2, 2]
+            if (4 * cq < cw && co < cout)
+                v = transposed ? w[(size_t)ci * cout + co] : w[((size_t)co * cin + ci) * taps + t];
         }
         packed[i] = v;
     }
@@ -453,9 +477,9 @@ int launch_mfma(const float* x, const float* wp, float* y, const MArgs& a, hipSt
 extern "C" {
 
 size_t san_conv_packed_floats(int cout, int cin, int ks) {
-    if (ks == 2) {  // ConvTranspose2d 2x2 keeps the scalar-operand layout (san_tconv.hip)
-        int ct = san_pick_co_t(cout);
-        return (size_t)san_cdiv(cout, ct) * ct * (size_t)cin * 4;
+    if (ks == 2) {  // ConvTranspose2d 2x2 s2 == 1x1 conv to 4*cout virtual channels
+        cout *= 4;
+        ks = 1;
     }
     const int cw = pick_cw(cout);
     const int cqp = ((cw / 4) + 3) & ~3;
@@ -472,7 +496,7 @@ int san_conv_pack_weights_fwd(const float* w, float* packed, int cout, int cin, 
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cout, cin, ks * ks,
-                       cw, cqp, groups);
+                       cw, cqp, groups, 0);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
@@ -512,6 +536,54 @@ int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin, const float*
     a.W = w;
     a.g = mfma_geom(n, h, w, cout, ks);
     if (ks == 3) return launch_mfma<3>(x, w_packed, y, a, (hipStream_t)stream);
+    return launch_mfma<1>(x, w_packed, y, a, (hipStream_t)stream);
+}
+
+int san_conv_pack_weights(const float* w, float* packed, int cout, int cin, int ks, int transposed, void* stream) {
+    SAN_CHECK_ARG(w && packed, "null pointer");
+    if (!transposed) return san_conv_pack_weights_fwd(w, packed, cout, cin, ks, stream);
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && ks == 2, "transposed packing is for ConvTranspose2d 2x2 only");
+    const int cv = 4 * cout;
+    const int cw = pick_cw(cv);
+    const int cqp = ((cw / 4) + 3) & ~3;
+    const int groups = san_cdiv(cv, cw);
+    size_t total = (size_t)groups * cin * 4 * cqp;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cv, cin, 1, cw, cqp,
+                       groups, 1);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_tconv_stat_tiles(int n, int h, int w, int cout) {
+    MGeom g = mfma_geom(n, h, w, 4 * cout, 1);
+    return 4 * g.tiles_x * g.tiles_y * g.WY;   // 4 virtual channels (taps) per output channel
+}
+
+int san_tconv2x2_fwd(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                     float in_slope, const float* w_packed, float* y, int y_ctot, int y_coff, int cout,
+                     float* part_stats, int n, int h, int w, void* stream) {
+    SAN_CHECK_ARG(x && w_packed && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
+    SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + cout <= y_ctot, "bad channel view");
+    SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
+    MArgs a{};
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_slope = in_slope;
+    a.part = part_stats;
+    a.x_ctot = x_ctot;
+    a.x_coff = x_coff;
+    a.cin = cin;
+    a.y_ctot = y_ctot;
+    a.y_coff = y_coff;
+    a.cout = 4 * cout;
+    a.N = n;
+    a.H = h;
+    a.W = w;
+    a.shuffle = 1;
+    a.g = mfma_geom(n, h, w, 4 * cout, 1);
     return launch_mfma<1>(x, w_packed, y, a, (hipStream_t)stream);
 }
 

@@ -296,7 +296,7 @@ def tconv2x2(x: Act, weight: torch.Tensor, y: Act, stats: bool = False, arena: A
     wp = packed_weight(weight, transposed=True)
     part = None
     if stats:
-        tiles = lib().query("san_tconv_stat_tiles", x.h, x.w, cout)
+        tiles = lib().query("san_tconv_stat_tiles", x.n, x.h, x.w, cout)
         part = arena.get("tpart" + tag, (x.n, cout, tiles, 3), x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(y.buf), y.ctot, y.coff,
             cout, _p(part), x.n, x.h, x.w, _stream())

@@ -38,8 +38,8 @@ def test_error_path_without_gpu(built):
     assert lib.query("san_conv_packed_floats", 18, 3, 3) == 1 * (3 + 4) * 9 * 4 * 8
     assert lib.query("san_conv_packed_floats", 36, 18, 3) == 2 * 18 * 9 * 32 + 4 * 9 * 32   # 36 -> 2 groups of 20
     assert lib.query("san_conv_packed_floats", 64, 64, 1) == 4 * 64 * 1 * 16 + 4 * 1 * 16
-    # transposed conv keeps the scalar-operand layout [groups][cin][4 taps][co_t]
-    assert lib.query("san_conv_packed_floats", 18, 36, 2) == 18 * 36 * 4
+    # transposed 2x2 conv == 1x1 conv to 4*cout virtual channels: 72 -> 4 groups of 20
+    assert lib.query("san_conv_packed_floats", 18, 36, 2) == 4 * 36 * 32 + 4 * 32
     assert lib.query("san_fft_workspace_bytes", 8, 320, 320) == 8 * 320 * 320 * 8
 
 
