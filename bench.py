@@ -75,7 +75,7 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(num_cascades, h, w, budget_s=20.0):
+def cpu_baseline(num_cascades, h, w, budget_s=15.0):
     """The oracle on host cores: same arithmetic as the reference's CPU path
     (same ATen kernels), N=1 slices one at a time until ~budget_s is spent."""
     from oracle import cpu_ref as O
@@ -99,7 +99,7 @@ def cpu_baseline(num_cascades, h, w, budget_s=20.0):
         while True:
             run()
             done += 1
-            if time.perf_counter() - t0 > budget_s or done >= 16:
+            if time.perf_counter() - t0 > budget_s or done >= 256:
                 break
         dt = time.perf_counter() - t0
     return {"value": done / dt, "unit": "slices/s", "cores": cores, "kind": "port",
