@@ -368,6 +368,319 @@ __global__ void __launch_bounds__(kThreads) fft_cols_kernel(const FftArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Fast path for length-320 transforms (the benchmark size): one 64-lane wave per
+// workgroup owns 4 lines = 1280 complex values, 20 per lane, held in REGISTERS
+// across the four Stockham passes (radix 4, 4, 4, 5).  The first pass reads its
+// butterfly inputs straight from global memory and the last pass writes its
+// outputs straight to global memory (with the fused prologue / epilogue), so
+// only the three inter-pass exchanges go through LDS (10 KiB per wave), and a
+// single-wave workgroup needs no cross-wave barrier.  640 workgroups per pass
+// at N=8 -> 2.5 independent waves per CU whose load / compute / store phases
+// overlap, instead of 1.25 four-wave workgroups in lock step.
+//
+// MAP 0 (rows):    line = one image row,    lanes run along the row (8-byte coalesced)
+// MAP 1 (columns): line = one image column, lanes = 16 rows x 4 adjacent columns
+constexpr int kN320 = 320;
+constexpr int kL320 = 4;           // lines per wave
+constexpr int kP320 = 321;         // LDS pitch (float2)
+
+template <int MAP>
+struct Map320 {
+    // radix-4 passes: butterfly t of this lane -> (line, j), j in [0, 80)
+    __device__ static void r4(int lane, int t, int& line, int& j) {
+        if (MAP == 0) {
+            const int b = lane + 64 * t;
+            line = b / 80;
+            j = b - line * 80;
+        } else {
+            line = lane & 3;
+            j = (lane >> 2) + 16 * t;
+        }
+    }
+    // radix-5 pass: butterfly t -> (line, j), j in [0, 64)
+    __device__ static void r5(int lane, int t, int& line, int& j) {
+        if (MAP == 0) {
+            line = t;
+            j = lane;
+        } else {
+            line = lane & 3;
+            j = (lane >> 2) + 16 * t;
+        }
+    }
+};
+
+__device__ __forceinline__ void bfly4(float2 (&v)[4], float sgn) {
+    const float2 a = cadd(v[0], v[2]), b = csub(v[0], v[2]);
+    const float2 c = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+    const float2 dr = make_float2(sgn * d.y, -sgn * d.x);
+    v[0] = cadd(a, c);
+    v[1] = cadd(b, dr);
+    v[2] = csub(a, c);
+    v[3] = csub(b, dr);
+}
+
+__device__ __forceinline__ void bfly5(float2 (&v)[5], float sgn) {
+    const float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;
+    const float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;
+    const float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+    const float2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    const float2 o0 = make_float2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+    const float2 m1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x, v[0].y + c1 * t1.y + c2 * t2.y);
+    const float2 m2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x, v[0].y + c2 * t1.y + c1 * t2.y);
+    const float2 n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    const float2 n2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    // forward: o1 = m1 - i n1, o4 = m1 + i n1, o2 = m2 - i n2, o3 = m2 + i n2  (-i z = (z.y, -z.x))
+    const float2 r1 = make_float2(sgn * n1.y, -sgn * n1.x);
+    const float2 r2 = make_float2(sgn * n2.y, -sgn * n2.x);
+    v[0] = o0;
+    v[1] = cadd(m1, r1);
+    v[4] = csub(m1, r1);
+    v[2] = cadd(m2, r2);
+    v[3] = csub(m2, r2);
+}
+
+// The FFT core.  in[t][r] : pass-A inputs of butterfly t (element j + 80 r of its line).
+// out[t][r]: final outputs of radix-5 butterfly t (element j + 64 r of its line).
+template <int MAP>
+__device__ __forceinline__ void fft320_core(float2 (&in)[5][4], float2 (&out)[4][5], float2* lds,
+                                            const float2* __restrict__ twg, float sgn, int lane) {
+    int lineA[5], jA[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) Map320<MAP>::r4(lane, t, lineA[t], jA[t]);
+    // ---- pass A: radix 4, Ns = 1 (no twiddles); out index 4 j + r
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        bfly4(in[t], sgn);
+        float2* d = lds + lineA[t] * kP320 + 4 * jA[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] = in[t][r];
+    }
+    __syncthreads();
+    // ---- pass B: radix 4, Ns = 4; twiddle W^(r * kk * 20); out index jq*16 + kk + 4 r
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const float2* s = lds + lineA[t] * kP320 + jA[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in[t][r] = s[80 * r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int kk = jA[t] & 3, jq = jA[t] >> 2;
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            float2 w = twg[r * kk * 20];
+            w.y *= sgn;
+            in[t][r] = cmul(in[t][r], w);
+        }
+        bfly4(in[t], sgn);
+        float2* d = lds + lineA[t] * kP320 + jq * 16 + kk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[4 * r] = in[t][r];
+    }
+    __syncthreads();
+    // ---- pass C: radix 4, Ns = 16; twiddle W^(r * kk * 5); out index jq*64 + kk + 16 r
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const float2* s = lds + lineA[t] * kP320 + jA[t];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in[t][r] = s[80 * r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        const int kk = jA[t] & 15, jq = jA[t] >> 4;
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            float2 w = twg[r * kk * 5];
+            w.y *= sgn;
+            in[t][r] = cmul(in[t][r], w);
+        }
+        bfly4(in[t], sgn);
+        float2* d = lds + lineA[t] * kP320 + jq * 64 + kk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[16 * r] = in[t][r];
+    }
+    __syncthreads();
+    // ---- pass D: radix 5, Ns = 64; twiddle W^(r * j); out index j + 64 r
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int line, j;
+        Map320<MAP>::r5(lane, t, line, j);
+        const float2* s = lds + line * kP320 + j;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) out[t][r] = s[64 * r];
+#pragma unroll
+        for (int r = 1; r < 5; ++r) {
+            float2 w = twg[r * j];
+            w.y *= sgn;
+            out[t][r] = cmul(out[t][r], w);
+        }
+        bfly5(out[t], sgn);
+    }
+}
+
+// rows: grid (H/4, outer); plane = outer*inner + l
+__global__ void __launch_bounds__(64) fft320_rows_kernel(const FftArgs a) {
+    __shared__ float2 lds[kL320 * kP320];
+    const int lane = threadIdx.x;
+    const int W = kN320, H = a.H;
+    const int h0 = blockIdx.x * kL320;
+    const int outer = blockIdx.y;
+    float2 acc[4][5];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) acc[t][r] = make_float2(0.f, 0.f);
+
+    for (int l = 0; l < a.inner; ++l) {
+        const int plane = outer * a.inner + l;
+        const size_t base = ((size_t)plane * H + h0) * W;
+        float2 in[5][4], out[4][5];
+        if (l > 0) __syncthreads();
+        // ---- pass-A inputs straight from global: butterfly b = lane + 64 t -> row b/80, j = b%80
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            int line, j;
+            Map320<0>::r4(lane, t, line, j);
+            const bool ok = (h0 + line) < H;
+            const size_t e = base + (size_t)line * W + j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float2 v = make_float2(0.f, 0.f);
+                if (ok) {
+                    if (a.pro == RP_NONE) {
+                        v = a.in[e + 80 * r];
+                    } else {   // planar r [n,2,H,W] times S[n,c]
+                        const int n = plane / a.C;
+                        const size_t re = ((size_t)n * 2 * H + h0 + line) * W + j + 80 * r;
+                        v = cmul(make_float2(a.in_planar[re], a.in_planar[re + (size_t)H * W]), a.sens[e + 80 * r]);
+                    }
+                }
+                in[t][r] = v;
+            }
+        }
+        // epilogue operands are requested BEFORE the transform so their latency hides under it
+        float2 sv[4][5];
+        if (a.epi == RE_CONJ_SENS_SUM_PLANAR) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 5; ++r)
+                    sv[t][r] = (h0 + t < H) ? a.sens[base + (size_t)t * W + lane + 64 * r] : make_float2(0.f, 0.f);
+        }
+        fft320_core<0>(in, out, lds, a.tw, a.sgn, lane);
+        // ---- outputs: row t, element lane + 64 r
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (h0 + t >= H) continue;
+            const size_t e = base + (size_t)t * W + lane;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const float2 v = out[t][r];
+                if (a.epi == RE_STORE) {
+                    float s = a.scale;
+                    if (a.cm_out) s *= a.cm_out[lane + 64 * r];
+                    a.out[e + 64 * r] = make_float2(v.x * s, v.y * s);
+                } else if (a.epi == RE_STORE_PLANAR) {
+                    const size_t pe = ((size_t)plane * a.out_ctot * H + h0 + t) * W + lane + 64 * r;
+                    a.out_real[pe] = v.x * a.scale;
+                    a.out_real[pe + (size_t)H * W] = v.y * a.scale;
+                } else if (a.epi == RE_CONJ_SENS_SUM_PLANAR) {
+                    const float2 s = sv[t][r];
+                    acc[t][r].x += v.x * s.x + v.y * s.y;
+                    acc[t][r].y += v.y * s.x - v.x * s.y;
+                } else {
+                    acc[t][r].x += v.x * v.x + v.y * v.y;
+                }
+            }
+        }
+    }
+    if (a.epi == RE_CONJ_SENS_SUM_PLANAR || a.epi == RE_RSS) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (h0 + t >= H) continue;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                if (a.epi == RE_RSS) {
+                    a.out_real[((size_t)outer * H + h0 + t) * W + lane + 64 * r] = sqrtf(acc[t][r].x) * a.scale;
+                } else {
+                    const size_t pe = ((size_t)outer * a.out_ctot * H + h0 + t) * W + lane + 64 * r;
+                    a.out_real[pe] = acc[t][r].x * a.scale;
+                    a.out_real[pe + (size_t)H * W] = acc[t][r].y * a.scale;
+                }
+            }
+        }
+    }
+}
+
+// columns: grid (W/4, planes); transform along H == 320
+__global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
+    __shared__ float2 lds[kL320 * kP320];
+    const int lane = threadIdx.x;
+    const int W = a.W;
+    const int w0 = blockIdx.x * kL320;
+    const int plane = blockIdx.y;
+    const size_t base = (size_t)plane * kN320 * W + w0;
+    const int c = lane & 3;
+    const bool ok = (w0 + c) < W;
+    float2 in[5][4], out[4][5];
+    float cm = 1.f;
+    if (a.cm_in && ok) cm = a.cm_in[w0 + c];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        int line, j;
+        Map320<1>::r4(lane, t, line, j);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float2 v = make_float2(0.f, 0.f);
+            if (ok) v = a.in[base + (size_t)(j + 80 * r) * W + c];
+            in[t][r] = make_float2(v.x * cm, v.y * cm);
+        }
+    }
+    // soft-DC operands are requested BEFORE the transform so their latency hides under it
+    float2 kv[4][5], k0v[4][5];
+    float dcw = 0.f, m = 0.f;
+    if (a.epi == CE_DC) {
+        dcw = a.dcw[0];
+        m = ok ? a.mask[w0 + c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int line, j;
+            Map320<1>::r5(lane, t, line, j);
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const size_t idx = base + (size_t)(j + 64 * r) * W + c;
+                kv[t][r] = ok ? a.k[idx] : make_float2(0.f, 0.f);
+                k0v[t][r] = ok ? a.k0[idx] : make_float2(0.f, 0.f);
+            }
+        }
+    }
+    fft320_core<1>(in, out, lds, a.tw, a.sgn, lane);
+    if (!ok) return;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int line, j;
+        Map320<1>::r5(lane, t, line, j);
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const size_t idx = base + (size_t)(j + 64 * r) * W + c;
+            float2 R = out[t][r];
+            R.x *= a.scale;
+            R.y *= a.scale;
+            if (a.epi == CE_STORE) {
+                a.out[idx] = R;
+            } else {
+                const float2 kk = kv[t][r];
+                const float2 k0 = k0v[t][r];
+                const float2 dc = make_float2((kk.x - k0.x) * m * dcw, (kk.y - k0.y) * m * dcw);
+                a.out[idx] = make_float2((kk.x - dc.x) - R.x, (kk.y - dc.y) - R.y);
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------- host side
 struct Plan {
     int n = 0;
@@ -485,6 +798,11 @@ int pick_batch(int len, int lines, int max_b) {
 size_t lds_bytes(const FftArgs& a) { return sizeof(float2) * ((size_t)a.len + 2 * (size_t)a.B * a.pitch); }
 
 int launch_rows(FftArgs& a, int outer, hipStream_t s) {
+    if (a.len == kN320 && a.W == kN320) {
+        hipLaunchKernelGGL(fft320_rows_kernel, dim3(san_cdiv(a.H, kL320), outer), dim3(64), 0, s, a);
+        SAN_LAUNCH_CHECK();
+        return SAN_OK;
+    }
     a.B = pick_batch(a.len, a.H, 8);
     // the coil-reducing epilogues keep B*W/256 accumulators per thread (<= 24)
     while (a.B > 1 && a.B * a.W > 24 * kThreads) a.B >>= 1;
@@ -506,6 +824,11 @@ int launch_rows(FftArgs& a, int outer, hipStream_t s) {
 }
 
 int launch_cols(FftArgs& a, int planes, hipStream_t s) {
+    if (a.len == kN320 && a.H == kN320) {
+        hipLaunchKernelGGL(fft320_cols_kernel, dim3(san_cdiv(a.W, kL320), planes), dim3(64), 0, s, a);
+        SAN_LAUNCH_CHECK();
+        return SAN_OK;
+    }
     int maxb = 16;
     if ((long)san_cdiv(a.W, 16) * planes < 512) maxb = 8;
     a.B = pick_batch(a.len, a.W, maxb);
