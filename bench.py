@@ -118,20 +118,15 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from spatialalignmentnetwork_amd import dist as sdist
+    rank, local_rank, world = sdist.env_rank_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+    dist = sdist.init("nccl", dev)      # RCCL; None when world == 1
 
     from spatialalignmentnetwork_amd import ops, synth
     n, h, w = args.batch, args.size, args.size
@@ -159,10 +154,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER = None
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = sdist.max_over_ranks(dt, dist, dev)
 
     if rank == 0:
         total_slices = n * world * args.steps

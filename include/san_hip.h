@@ -218,6 +218,12 @@ int san_ssim_loss_fwd(const float* x, const float* y, float* loss, int n, int h,
 int san_lncc_loss_fwd(const float* i, const float* j, float* loss, int n, int h, int w, int win,
                       float* ws, void* stream);
 
+/* y [planes, h/2, w/2] = avg_pool2(conv2d(x, kern[ksize x ksize], zero pad ksize/2)):
+ * the Gaussian(sigma=3, 13 taps) + 2x average-pool step between the scales of
+ * ms_lncc_loss (lnccloss.py:58-65, miloss.py:6-24).  kern: device fp32 [ksize*ksize]. */
+int san_smooth_pool_fwd(const float* x, const float* kern, float* y, int planes, int h, int w, int ksize,
+                        void* stream);
+
 /* loss[0] = (mean(dW^2) + mean(dH^2))/2 of an offset field given as NCHW
  * [n, 2, h, w] (model.py:21-28 on the permuted view). */
 int san_gradient_loss_fwd(const float* offset, float* loss, int n, int h, int w, float* ws, void* stream);

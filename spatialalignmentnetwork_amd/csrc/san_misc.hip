@@ -148,6 +148,43 @@ window_loss_kernel(const float* __restrict__ X, const float* __restrict__ Y, flo
         partial[((size_t)n * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// y = avg_pool2(conv2d(x, K x K kernel, zero pad K/2)): the multi-scale LNCC down-sampler
+// (lnccloss.py:59-60 -> miloss.py:20-24 + avg_pool2d).  16x16 pooled outputs per workgroup;
+// the 32+K-1 square input window and the kernel sit in LDS; each lane owns one pooled pixel.
+template <int K>
+__global__ void __launch_bounds__(kThreads)
+smooth_pool_kernel(const float* __restrict__ x, const float* __restrict__ kern, float* __restrict__ y, int H, int W) {
+    constexpr int T = 16, IW = 2 * T + K - 1;
+    __shared__ float sx[IW][IW + 1];
+    __shared__ float sk[K * K];
+    const int plane = blockIdx.z;
+    const int OH = H >> 1, OW = W >> 1;
+    const int ox0 = blockIdx.x * T, oy0 = blockIdx.y * T;
+    const float* xp = x + (size_t)plane * H * W;
+    for (int e = threadIdx.x; e < K * K; e += kThreads) sk[e] = kern[e];
+    for (int e = threadIdx.x; e < IW * IW; e += kThreads) {
+        const int r = e / IW, c = e - r * IW;
+        const int gy = 2 * oy0 + r - K / 2, gx = 2 * ox0 + c - K / 2;
+        sx[r][c] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xp[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int ox = ox0 + lx, oy = oy0 + ly;
+    if (ox >= OW || oy >= OH) return;
+    float s00 = 0.f, s01 = 0.f, s10 = 0.f, s11 = 0.f;
+#pragma unroll 1
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const float w = sk[r * K + c];
+            s00 = fmaf(w, sx[2 * ly + r][2 * lx + c], s00);
+            s01 = fmaf(w, sx[2 * ly + r][2 * lx + c + 1], s01);
+            s10 = fmaf(w, sx[2 * ly + r + 1][2 * lx + c], s10);
+            s11 = fmaf(w, sx[2 * ly + r + 1][2 * lx + c + 1], s11);
+        }
+    y[(size_t)plane * OH * OW + (size_t)oy * OW + ox] = ((s00 + s01) + (s10 + s11)) * 0.25f;
+}
+
 // squared forward differences of an NCHW [n,2,h,w] offset field
 __global__ void __launch_bounds__(kThreads)
 gradient_partial_kernel(const float* __restrict__ off, float* __restrict__ partial, int H, int W) {
@@ -309,6 +346,19 @@ int san_lncc_loss_fwd(const float* i, const float* j, float* loss, int n, int h,
     SAN_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, (int)(grid.x * grid.y * grid.z),
                        loss, 0, 0.0, -1.0, (double)n * h * w, 1.0);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_smooth_pool_fwd(const float* x, const float* kern, float* y, int planes, int h, int w, int ksize, void* stream) {
+    SAN_CHECK_ARG(x && kern && y, "null pointer");
+    SAN_CHECK_ARG(planes > 0 && h >= 2 && w >= 2 && (h % 2 == 0) && (w % 2 == 0), "h, w must be even");
+    if (ksize != 13) {
+        san_set_error("smoothing kernel size %d unsupported (only 13 = sigma 3)", ksize);
+        return SAN_E_UNSUPPORTED;
+    }
+    dim3 grid(san_cdiv(w / 2, 16), san_cdiv(h / 2, 16), planes);
+    hipLaunchKernelGGL((smooth_pool_kernel<13>), grid, dim3(kThreads), 0, (hipStream_t)stream, x, kern, y, h, w);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

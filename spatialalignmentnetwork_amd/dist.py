@@ -1,0 +1,64 @@
+"""Data-parallel plumbing for the slice-sharded path (one process per GPU).
+
+Slices are independent (every norm on the VarNet path is per sample; BatchNorm in
+the alignment net keeps per-replica statistics, as the reference does), so
+inference needs NO data-path collective: each rank takes a contiguous shard of
+the global batch.  Only scalars (timing, metrics) cross ranks.  Backend is
+"nccl" (= RCCL over xGMI) on GPUs and "gloo" in the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import torch
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    """(rank, local_rank, world) from the torch.distributed.run environment."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend: str, device=None):
+    """Initialise torch.distributed if WORLD_SIZE > 1; returns the module or None."""
+    _, _, world = env_rank_world()
+    if world <= 1:
+        return None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    dist.init_process_group(backend, **kw)
+    return dist
+
+
+def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) of `total` slices owned by `rank`: contiguous, sizes differ by at most one,
+    every slice owned exactly once."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def max_over_ranks(value: float, dist, device="cpu") -> float:
+    """The slowest rank's time (bench.py's max-over-ranks rule)."""
+    if dist is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, dist, device="cpu") -> float:
+    if dist is None:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_metric_mean(local_sum: float, local_count: int, dist, device="cpu") -> float:
+    """Global mean of a per-slice metric from per-rank (sum, count)."""
+    s = sum_over_ranks(local_sum, dist, device)
+    c = sum_over_ranks(float(local_count), dist, device)
+    return s / max(c, 1.0)

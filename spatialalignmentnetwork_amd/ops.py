@@ -409,3 +409,14 @@ def gradient_loss_nchw(offset_nchw: torch.Tensor) -> torch.Tensor:
     lib().call("san_gradient_loss_fwd", _p(offset_nchw), _p(loss), n, h, w, _p(_loss_ws(n, h, w, offset_nchw.device)),
                _stream())
     return loss
+
+
+def smooth_pool(x: torch.Tensor, kern: torch.Tensor) -> torch.Tensor:
+    """avg_pool2(conv2d(x, kern, padding=k//2)) for a [N,1,H,W] tensor (multi-scale LNCC step)."""
+    _chk(x, name="x")
+    _chk(kern, name="kern")
+    n, c, h, w = x.shape
+    k = kern.shape[-1]
+    y = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.float32)
+    lib().call("san_smooth_pool_fwd", _p(x), _p(kern), _p(y), n * c, h, w, k, _stream())
+    return y

@@ -1,0 +1,58 @@
+"""world_size-2 gloo test (CPU) of the slice-sharding helpers the multi-GPU bench uses."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from spatialalignmentnetwork_amd import dist as sdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = sdist.init("gloo")
+    assert d is not None and d.get_world_size() == world
+    lo, hi = sdist.shard_bounds(total, rank, world)
+    # every rank "processes" its shard: value of slice i is i; time of rank r is 1 + r
+    local_sum = float(sum(range(lo, hi)))
+    mean = sdist.gather_metric_mean(local_sum, hi - lo, d)
+    tmax = sdist.max_over_ranks(1.0 + rank, d)
+    tot = sdist.sum_over_ranks(float(hi - lo), d)
+    d.barrier()
+    out[rank] = (lo, hi, mean, tmax, tot)
+    d.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [16, 17, 3])
+def test_shards_and_reductions_world2(total):
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, total, out), nprocs=world, join=True)
+    owned = []
+    for r in range(world):
+        lo, hi, mean, tmax, tot = out[r]
+        owned += list(range(lo, hi))
+        assert abs(mean - (total - 1) / 2.0) < 1e-12          # global mean of 0..total-1
+        assert tmax == 2.0                                     # slowest rank
+        assert tot == total
+    assert sorted(owned) == list(range(total))                 # each slice exactly once
+
+
+def test_shard_bounds_properties():
+    for total in range(0, 40):
+        for world in (1, 2, 3, 8):
+            spans = [sdist.shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -210,6 +210,7 @@ def test_warp_and_losses_golden(S, ops_golden):
     b = (a + 0.1 * philox("loss.b", (2, 1, 40, 56))).clamp(0, 1)
     assert abs(S.ssim.ssimloss(g(a), g(b)).item() - float(ops_golden["ssimloss"])) < 2e-6
     assert abs(S.lncc.lncc_loss(g(a), g(b)).item() - float(ops_golden["lncc"])) < 2e-6
+    assert abs(S.lncc.ms_lncc_loss(g(a), g(b)).item() - float(ops_golden["ms_lncc"])) < 2e-6
     gl = S.ops.gradient_loss_nchw(g(off_nchw)).item()
     assert abs(gl - float(ops_golden["gradient_loss"])) < 1e-6 * max(1.0, float(ops_golden["gradient_loss"]))
 
