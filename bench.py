@@ -184,7 +184,8 @@ def main():
             "config": {"workload": f"inference pass set_input+align+warp+VarNet{args.cascades}+SSIM, "
                                    f"{n} slices/GPU of {h}x{w} single-coil, 4x equispaced mask, random-init weights",
                        "slices_per_gpu": n, "global_batch": n * world, "cascades": args.cascades,
-                       "parallelism": f"dp{world} (independent slice shards, no data-path collective)"},
+                       "parallelism": f"dp{world} (independent slice shards, no data-path collective)",
+                       "scalar_backend": sdist.BACKEND},
         }
         if timer is not None:
             tot = timer.totals()

@@ -20,16 +20,44 @@ def env_rank_world() -> Tuple[int, int, int]:
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+BACKEND = None   # the backend actually in use (bench.py reports it)
+
+
 def init(backend: str, device=None):
-    """Initialise torch.distributed if WORLD_SIZE > 1; returns the module or None."""
+    """Initialise torch.distributed if WORLD_SIZE > 1; returns the module or None.
+    backend "nccl" is RCCL on ROCm.  The slice-sharded inference path exchanges only scalars, so
+    if RCCL cannot come up (e.g. IPC disabled on the host) the scalars go over gloo instead of
+    losing the whole multi-GPU run; the choice is recorded in ``BACKEND``."""
+    global BACKEND
     _, _, world = env_rank_world()
     if world <= 1:
         return None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
-    dist.init_process_group(backend, **kw)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":
+        try:
+            kw = {"device_id": device} if device is not None else {}
+            dist.init_process_group("nccl", **kw)
+            t = torch.zeros(1, device=device)
+            dist.all_reduce(t)                      # fail here, not inside the timed region
+            torch.cuda.synchronize()
+            BACKEND = "nccl"
+            return dist
+        except Exception as e:                     # pragma: no cover (needs a multi-GPU box)
+            print(f"[dist] RCCL unavailable ({type(e).__name__}: {e}); scalars fall back to gloo", flush=True)
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
+            backend = "gloo"
+    dist.init_process_group(backend)
+    BACKEND = backend
     return dist
+
+
+def _scalar_device(device):
+    return device if BACKEND == "nccl" else "cpu"
 
 
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -44,7 +72,7 @@ def max_over_ranks(value: float, dist, device="cpu") -> float:
     """The slowest rank's time (bench.py's max-over-ranks rule)."""
     if dist is None:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -52,7 +80,7 @@ def max_over_ranks(value: float, dist, device="cpu") -> float:
 def sum_over_ranks(value: float, dist, device="cpu") -> float:
     if dist is None:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
