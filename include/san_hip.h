@@ -134,6 +134,28 @@ int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin,
                    float* part_stats,
                    int n, int h, int w, int ks, void* stream);
 
+/* ---- backward building blocks (training path; forward semantics above) ----
+ * Data gradient of san_conv2d_fwd: dx = san_conv2d_fwd(dy, packed_dgrad, cin' = cout, cout' = cin)
+ * with packed_dgrad = san_conv_pack_weights_dgrad(w_forward) (flipped taps, swapped channel
+ * axes; buffer of san_conv_packed_floats(cin, cout, ks) floats).
+ * Weight gradient: dw [cout, cin, ks, ks] (+)= sum_{n,y,x} dy[n,co,y,x] * T(x)[n,ci,y+ky-p,x+kx-p];
+ * partial: fp32 [san_conv_wgrad_partitions(n,h,w,cin,cout) * cout*cin*ks*ks] scratch.
+ * san_act_bwd: gradient through the lazy (scale, shift, LeakyReLU) read of a raw tensor y:
+ *   yh = sc*y + sh, u = g * (yh >= 0 ? 1 : slope);
+ *   mode 0: dy = sc*u;  mode 1 (InstanceNorm): dy = sc*(u - mean(u) - yh*mean(u*yh)) per plane;
+ *   part: fp32 [n, c, san_bwd_stat_tiles(hw), 2] scratch (mode 1). */
+int san_conv_pack_weights_dgrad(const float* w, float* packed, int cout, int cin, int ks, void* stream);
+int san_conv_wgrad_partitions(int n, int h, int w, int cin, int cout);
+int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin,
+                     const float* in_scale, const float* in_shift, float in_slope,
+                     const float* dy, int dy_ctot, int dy_coff, int cout,
+                     float* dw, int accumulate, float* partial,
+                     int n, int h, int w, int ks, void* stream);
+int san_bwd_stat_tiles(int hw);
+int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
+                const float* sc, const float* sh, float slope, int mode, float* part,
+                float* dy, int d_ctot, int d_coff, int n, int c, int hw, void* stream);
+
 /* ConvTranspose2d 2x2 stride 2, no bias: y [n, cout, 2h, 2w].
  * w_packed from san_conv_pack_weights(..., ks=2, transposed=1).
  * Evaluated as a 1x1 convolution to 4*cout virtual channels (one per tap) on

@@ -1,0 +1,315 @@
+// Backward building blocks for the conv / norm stack (gfx950).
+//
+//   * data gradient of a convolution  = the forward MFMA kernel (san_conv_mfma.hip) run on dy
+//     with flipped + transposed weights (san_conv_pack_weights_dgrad): no new conv code;
+//   * weight gradient                 = conv_wgrad_kernel below: the 4x4x1 MFMA with the PIXEL
+//     axis as the sixteen independent blocks (each block accumulates the 4x4 outer product
+//     dy[4 co] x a[4 ci] of its own pixel; the blocks are summed once at the end), per-partition
+//     partials + a deterministic second-stage reduction (no float atomics);
+//   * InstanceNorm + LeakyReLU backward through the lazy-normalisation representation:
+//     bwd_stats (two plane reductions) + act_bwd (element-wise), see the formulas at the kernels.
+#include "san_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ wgrad
+constexpr int kCOB = 8;      // output channels per workgroup (2 quads, every wave)
+constexpr int kCIB = 16;     // input channels per workgroup (1 quad per wave)
+constexpr int kTW = 64, kTH = 4;   // pixel tile per iteration
+
+struct WgradArgs {
+    const float* x;          // forward input (raw) + its lazy affine
+    const float* in_scale;
+    const float* in_shift;
+    const float* dy;         // gradient wrt the conv output (materialised)
+    float* partial;          // [P][cout][cin][taps]
+    float in_slope;
+    int x_ctot, x_coff, cin;
+    int dy_ctot, dy_coff, cout;
+    int N, H, W;
+    int tiles_x, tiles_y, P;
+};
+
+template <int KS>
+__global__ void __launch_bounds__(kThreads) conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int PAD = KS / 2;
+    constexpr int TAPS = KS * KS;
+    constexpr int AW = kTW + 2 * PAD, AH = kTH + 2 * PAD;
+    constexpr int AP = AW + 1, DP = kTW + 1;         // LDS pitches
+    __shared__ float aT[kCIB][AH][AP];
+    __shared__ float dT[kCOB][kTH][DP];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int b = lane >> 2, q = lane & 3;
+    const int co0 = blockIdx.y * kCOB;
+    const int ci0 = blockIdx.z * kCIB;
+    const int H = a.H, W = a.W;
+    const size_t HW = (size_t)H * W;
+
+    f4 acc[2][TAPS];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[c][t] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int total_tiles = tiles_per_img * a.N;
+    for (int tile = blockIdx.x; tile < total_tiles; tile += a.P) {
+        const int n = tile / tiles_per_img;
+        const int tr = tile - n * tiles_per_img;
+        const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+        const int x0 = tx * kTW, y0 = ty * kTH;
+        __syncthreads();
+        // ---- stage the activated input tile (zero outside the image / channel range)
+        for (int e = tid; e < kCIB * AH * AW; e += kThreads) {
+            const int c = e / (AH * AW);
+            const int rem = e - c * (AH * AW);
+            const int r = rem / AW, col = rem - r * AW;
+            const int gy = y0 - PAD + r, gx = x0 - PAD + col;
+            const int ci = ci0 + c;
+            float v = 0.f;
+            if (ci < a.cin && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                float sc = 1.f, sh = 0.f;
+                if (a.in_scale) {
+                    sc = a.in_scale[n * a.x_ctot + a.x_coff + ci];
+                    sh = a.in_shift[n * a.x_ctot + a.x_coff + ci];
+                }
+                v = san_act(a.x[(size_t)(n * a.x_ctot + a.x_coff + ci) * HW + (size_t)gy * W + gx], sc, sh, a.in_slope);
+            }
+            aT[c][r][col] = v;
+        }
+        for (int e = tid; e < kCOB * kTH * kTW; e += kThreads) {
+            const int c = e / (kTH * kTW);
+            const int rem = e - c * (kTH * kTW);
+            const int r = rem / kTW, col = rem - r * kTW;
+            const int gy = y0 + r, gx = x0 + col;
+            const int co = co0 + c;
+            float v = 0.f;
+            if (co < a.cout && gy < H && gx < W)
+                v = a.dy[(size_t)(n * a.dy_ctot + a.dy_coff + co) * HW + (size_t)gy * W + gx];
+            dT[c][r][col] = v;
+        }
+        __syncthreads();
+        // ---- 16 pixel groups (4 rows x 4 x-groups of 16): block b of the MFMA = pixel b of the group
+#pragma unroll 1
+        for (int r = 0; r < kTH; ++r)
+#pragma unroll 1
+            for (int xg = 0; xg < kTW / 16; ++xg) {
+                const int px = xg * 16 + b;
+                const float a0 = dT[q][r][px], a1 = dT[4 + q][r][px];
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const float bv = aT[4 * wave + q][r + ky][px + kx];
+                        acc[0][ky * KS + kx] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bv, acc[0][ky * KS + kx], 0, 0, 0);
+                        acc[1][ky * KS + kx] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, bv, acc[1][ky * KS + kx], 0, 0, 0);
+                    }
+            }
+    }
+    // ---- sum the 16 blocks: lanes 4b + j, b = 0..15, hold partial D[i][j]
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc[c][t][i];
+                v += __shfl_xor(v, 4, 64);
+                v += __shfl_xor(v, 8, 64);
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                acc[c][t][i] = v;
+            }
+    if (b == 0) {
+        const int ci = ci0 + 4 * wave + q;          // lane (0, j = q)
+        if (ci < a.cin) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int co = co0 + 4 * c + i;
+                    if (co < a.cout) {
+                        float* o = a.partial + (((size_t)blockIdx.x * a.cout + co) * a.cin + ci) * TAPS;
+#pragma unroll
+                        for (int t = 0; t < TAPS; ++t) o[t] = acc[c][t][i];
+                    }
+                }
+        }
+    }
+}
+
+// dW[i] (+)= sum_p partial[p][i], fixed order
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int count, int P,
+                                    int accumulate) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int p = 0; p < P; ++p) s += partial[(size_t)p * count + i];
+        dw[i] = accumulate ? dw[i] + s : s;
+    }
+}
+
+int wgrad_partitions(int n, int h, int w, int cin, int cout) {
+    const int tiles = san_cdiv(w, kTW) * san_cdiv(h, kTH) * n;
+    const int blocks = san_cdiv(cout, kCOB) * san_cdiv(cin, kCIB);
+    int P = san_cdiv(1024, blocks);
+    if (P > tiles) P = tiles;
+    if (P > 256) P = 256;
+    if (P < 1) P = 1;
+    return P;
+}
+
+// ------------------------------------------------- norm + activation backward
+// Forward (lazy):  yh = sc*y + sh,  a = lrelu(yh, slope).   Given G = dL/da:
+//   u  = G * (yh >= 0 ? 1 : slope)
+//   mode 0 (plain affine, e.g. eval BatchNorm / identity): dy = sc * u
+//   mode 1 (InstanceNorm, biased var):  dy = sc * (u - mean(u) - yh * mean(u*yh))   per (n, c) plane
+// bwd_stats writes per-chunk (sum u, sum u*yh) partials; act_bwd sums the chunks itself.
+__global__ void __launch_bounds__(kThreads)
+bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
+                 const float* __restrict__ sc, const float* __restrict__ sh, float slope, int c, int hw, int tiles,
+                 float* __restrict__ part) {
+    __shared__ float red[8];
+    const int t = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const int chunk = (hw + tiles - 1) / tiles;
+    const int lo = t * chunk;
+    const int cnt = max(0, min(hw, lo + chunk) - lo);
+    const float* gp = g + ((size_t)(n * g_ctot + g_coff + ch)) * hw + lo;
+    const float* yp = y + ((size_t)(n * y_ctot + y_coff + ch)) * hw + lo;
+    const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
+    const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < cnt; i += kThreads) {
+        const float yh = fmaf(yp[i], s, b);
+        const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
+        s1 += u;
+        s2 = fmaf(u, yh, s2);
+    }
+    s1 = san_wave_total(s1);
+    s2 = san_wave_total(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s1;
+        red[4 + (threadIdx.x >> 6)] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = part + ((size_t)(n * c + ch) * tiles + t) * 2;
+        o[0] = (red[0] + red[1]) + (red[2] + red[3]);
+        o[1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+__global__ void __launch_bounds__(kThreads)
+act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
+               const float* __restrict__ sc, const float* __restrict__ sh, float slope, const float* __restrict__ part,
+               int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw) {
+    const int ch = blockIdx.y, n = blockIdx.z;
+    const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
+    const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
+    float m1 = 0.f, m2 = 0.f;
+    if (mode == 1) {
+        double t1 = 0.0, t2 = 0.0;
+        const float* p = part + ((size_t)(n * c + ch) * tiles) * 2;
+        for (int t = 0; t < tiles; ++t) {
+            t1 += (double)p[2 * t];
+            t2 += (double)p[2 * t + 1];
+        }
+        m1 = (float)(t1 / hw);
+        m2 = (float)(t2 / hw);
+    }
+    const float* gp = g + ((size_t)(n * g_ctot + g_coff + ch)) * hw;
+    const float* yp = y + ((size_t)(n * y_ctot + y_coff + ch)) * hw;
+    float* dp = dy + ((size_t)(n * d_ctot + d_coff + ch)) * hw;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads) {
+        const float yh = fmaf(yp[i], s, b);
+        const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
+        dp[i] = s * (u - m1 - yh * m2);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int san_conv_wgrad_partitions(int n, int h, int w, int cin, int cout) { return wgrad_partitions(n, h, w, cin, cout); }
+
+int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                     float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                     float* partial, int n, int h, int w, int ks, void* stream) {
+    SAN_CHECK_ARG(x && dy && dw && partial, "null pointer");
+    SAN_CHECK_ARG(ks == 1 || ks == 3, "ks must be 1 or 3");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
+    SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && dy_coff >= 0 && dy_coff + cout <= dy_ctot, "bad channel view");
+    SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
+    WgradArgs a{};
+    a.x = x;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_slope = in_slope;
+    a.dy = dy;
+    a.partial = partial;
+    a.x_ctot = x_ctot;
+    a.x_coff = x_coff;
+    a.cin = cin;
+    a.dy_ctot = dy_ctot;
+    a.dy_coff = dy_coff;
+    a.cout = cout;
+    a.N = n;
+    a.H = h;
+    a.W = w;
+    a.tiles_x = san_cdiv(w, kTW);
+    a.tiles_y = san_cdiv(h, kTH);
+    a.P = wgrad_partitions(n, h, w, cin, cout);
+    dim3 grid(a.P, san_cdiv(cout, kCOB), san_cdiv(cin, kCIB));
+    hipStream_t s = (hipStream_t)stream;
+    if (ks == 3)
+        hipLaunchKernelGGL((conv_wgrad_kernel<3>), grid, dim3(kThreads), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(kThreads), 0, s, a);
+    SAN_LAUNCH_CHECK();
+    const int count = cout * cin * ks * ks;
+    int blocks = san_cdiv(count, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, count, a.P, accumulate);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_bwd_stat_tiles(int hw) {
+    int t = san_cdiv(hw, 4096);
+    return t < 1 ? 1 : (t > 32 ? 32 : t);
+}
+
+int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, int n, int c,
+                int hw, void* stream) {
+    SAN_CHECK_ARG(g && y && dy, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    SAN_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (affine) or 1 (instance norm)");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    SAN_CHECK_ARG(mode == 0 || part != nullptr, "instance-norm backward needs the partial buffer");
+    SAN_CHECK_ARG(g_coff >= 0 && g_coff + c <= g_ctot && y_coff >= 0 && y_coff + c <= y_ctot && d_coff >= 0 &&
+                      d_coff + c <= d_ctot, "bad channel view");
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = san_bwd_stat_tiles(hw);
+    if (mode == 1) {
+        hipLaunchKernelGGL(bwd_stats_kernel, dim3(tiles, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot,
+                           y_coff, sc, sh, slope, c, hw, tiles, part);
+        SAN_LAUNCH_CHECK();
+    }
+    int bx = san_cdiv(hw, kThreads * 4);
+    long cap = 4096 / ((long)c * n);
+    if (cap < 1) cap = 1;
+    if (bx > cap) bx = (int)cap;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(bx, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc,
+                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+}  // extern "C"

@@ -416,8 +416,13 @@ __global__ void pack_mfma_kernel(const float* __restrict__ w, float* __restrict_
             const int g = (int)(i / ((size_t)wrow * taps * cin));
             const int co = g * cw + 4 * cq + j;
             // transposed: cout = 4*Cout' virtual channels c' = 4*co + tap of a ConvTranspose2d weight [cin, Cout', 2, 2]
-            if (4 * cq < cw && co < cout)
-                v = transposed ? w[(size_t)ci * cout + co] : w[((size_t)co * cin + ci) * taps + t];
+            // transposed == 2: data-gradient weights of a Conv2d [cin_fwd = cout here ... ]: the forward
+            // weight is [ci][co][taps] in THIS kernel's naming (its cout = forward cin), taps flipped
+            if (4 * cq < cw && co < cout) {
+                if (transposed == 1) v = w[(size_t)ci * cout + co];
+                else if (transposed == 2) v = w[((size_t)ci * cout + co) * taps + (taps - 1 - t)];
+                else v = w[((size_t)co * cin + ci) * taps + t];
+            }
         }
         packed[i] = v;
     }
@@ -497,6 +502,23 @@ int san_conv_pack_weights_fwd(const float* w, float* packed, int cout, int cin, 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cout, cin, ks * ks,
                        cw, cqp, groups, 0);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_conv_pack_weights_dgrad(const float* w, float* packed, int cout, int cin, int ks, void* stream) {
+    // w is the FORWARD weight [cout, cin, ks, ks]; the packed result drives san_conv2d_fwd with
+    // cin' = cout, cout' = cin (buffer size: san_conv_packed_floats(cin, cout, ks))
+    SAN_CHECK_ARG(w && packed, "null pointer");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && (ks == 1 || ks == 3), "bad dims");
+    const int cw = pick_cw(cin);
+    const int cqp = ((cw / 4) + 3) & ~3;
+    const int groups = san_cdiv(cin, cw);
+    size_t total = (size_t)groups * cout * ks * ks * 4 * cqp;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cin, cout, ks * ks,
+                       cw, cqp, groups, 2);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

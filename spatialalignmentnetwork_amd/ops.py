@@ -423,3 +423,53 @@ def smooth_pool(x: torch.Tensor, kern: torch.Tensor) -> torch.Tensor:
     y = torch.empty((n, c, h // 2, w // 2), device=x.device, dtype=torch.float32)
     lib().call("san_smooth_pool_fwd", _p(x), _p(kern), _p(y), n * c, h, w, k, _stream())
     return y
+
+
+# ---------------------------------------------------------------------------
+# backward building blocks
+# ---------------------------------------------------------------------------
+def packed_weight_dgrad(w: torch.Tensor) -> torch.Tensor:
+    """Flipped / channel-swapped packing of a Conv2d weight: conv2d(dy, this) = dL/dx."""
+    tagv = (w._version, w.data_ptr(), "dgrad")
+    hit = getattr(w, "_san_packed_dgrad", None)
+    if hit is not None and hit[0] == tagv:
+        return hit[1]
+    _chk(w, name="weight")
+    cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+    packed = torch.empty(lib().query("san_conv_packed_floats", cin, cout, ks), device=w.device, dtype=torch.float32)
+    lib().call("san_conv_pack_weights_dgrad", _p(w.detach()), _p(packed), cout, cin, ks, _stream())
+    w._san_packed_dgrad = (tagv, packed)
+    return packed
+
+
+def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
+    """dx.buf[:, dx.coff:+cin] = dL/d(conv input) for dy = dL/d(conv output) (materialised)."""
+    cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
+    assert dy.c == cout and dx.c == cin
+    wp = packed_weight_dgrad(weight)
+    lib().call("san_conv2d_fwd", _p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope),
+               _p(wp), _p(None), _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), _p(None), _p(None),
+               dy.n, dy.h, dy.w, ks, _stream())
+
+
+def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
+    """dw [cout, cin, ks, ks] (+)= correlation of dy with the lazily activated forward input x."""
+    cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
+    assert x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
+    P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout)
+    partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
+    lib().call("san_conv2d_wgrad", _p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope),
+               _p(dy.buf), dy.ctot, dy.coff, cout, _p(_chk(dw, name="dw")), int(accumulate), _p(partial),
+               x.n, x.h, x.w, ks, _stream())
+
+
+def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA) -> None:
+    """Gradient through y's lazy (scale, shift, LeakyReLU) read: g = dL/d(activation) -> dy = dL/dy_raw."""
+    assert g.c == y.c == dy.c
+    hw = y.h * y.w
+    part = None
+    if instance_norm:
+        tiles = lib().query("san_bwd_stat_tiles", hw)
+        part = arena.get("bwd_part", (y.n, y.c, tiles, 2), y.buf.device)
+    lib().call("san_act_bwd", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+               float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, hw, _stream())

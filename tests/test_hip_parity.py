@@ -300,3 +300,48 @@ def test_e2e_full_320_golden(S):
     psnr = S.O.psnr(ref32, o["img_rec"].cpu())
     print(f"PSNR(hip, ref32) = {psnr:.1f} dB")
     assert psnr > 80.0
+
+
+# ------------------------------------------------------- backward building blocks
+@pytest.mark.parametrize("cin,cout,h,w,ks", [(3, 18, 32, 32, 3), (18, 18, 64, 64, 3), (36, 18, 40, 24, 3),
+                                              (20, 9, 17, 70, 3), (18, 2, 32, 32, 1), (64, 64, 20, 20, 1)])
+def test_conv_dgrad_wgrad_vs_autograd(S, cin, cout, h, w, ks):
+    n = 2
+    x = philox("bw.x", (n, cin, h, w))
+    wt = philox("bw.w", (cout, cin, ks, ks)) * (1.0 / (cin * ks * ks) ** 0.5)
+    sc, sh = philox("bw.sc", (n, cin), lo=0.5, hi=1.5), philox("bw.sh", (n, cin))
+    dy = philox("bw.dy", (n, cout, h, w))
+    xa = torch.nn.functional.leaky_relu(x * sc[:, :, None, None] + sh[:, :, None, None], 0.2).double().requires_grad_(True)
+    w64 = wt.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xa, w64, None, padding=ks // 2).backward(dy.double())
+    dx = torch.empty((n, cin, h, w), device=DEV)
+    S.ops.conv2d_dgrad(S.ops.full(g(dy)), g(wt), S.ops.full(dx))
+    assert rel_err(dx.cpu(), xa.grad.float()) < 3e-6
+    dw = torch.empty((cout, cin, ks, ks), device=DEV)
+    S.ops.conv2d_wgrad(S.ops.Act(g(x), 0, cin, g(sc), g(sh), 0.2), S.ops.full(g(dy)), dw)
+    assert rel_err(dw.cpu(), w64.grad.float()) < 1e-5
+    S.ops.conv2d_wgrad(S.ops.Act(g(x), 0, cin, g(sc), g(sh), 0.2), S.ops.full(g(dy)), dw, accumulate=True)
+    assert rel_err(dw.cpu(), 2 * w64.grad.float()) < 1e-5
+
+
+def test_instance_norm_act_backward(S):
+    n, c, h, w = 2, 5, 24, 40
+    y = philox("ib.y", (n, c, h, w)) * 2 + 0.3
+    gout = philox("ib.g", (n, c, h, w))
+    y64 = y.double().requires_grad_(True)
+    mean = y64.mean(dim=(2, 3), keepdim=True)
+    var = y64.var(dim=(2, 3), unbiased=False, keepdim=True)
+    a = torch.nn.functional.leaky_relu((y64 - mean) / torch.sqrt(var + 1e-5), 0.2)
+    a.backward(gout.double())
+    # forward lazy affine through the library (plane stats -> finalize)
+    ya = S.ops.Act(g(y), 0, c, torch.empty((n, c), device=DEV), torch.empty((n, c), device=DEV), 0.2)
+    S.ops.norm_finalize(S.ops.plane_stats(ya), S.ops.NORM_INSTANCE, 1e-5, ya.scale, ya.shift, 0)
+    dy = torch.empty((n, c, h, w), device=DEV)
+    S.ops.act_bwd(S.ops.full(g(gout)), ya, S.ops.full(dy), instance_norm=True)
+    assert rel_err(dy.cpu(), y64.grad.float()) < 2e-5
+    # plain affine mode
+    sc, sh = philox("ib.sc", (n, c), lo=0.5, hi=1.5), philox("ib.sh", (n, c))
+    y64 = y.double().requires_grad_(True)
+    torch.nn.functional.leaky_relu(y64 * sc[:, :, None, None].double() + sh[:, :, None, None].double(), 0.01).backward(gout.double())
+    S.ops.act_bwd(S.ops.full(g(gout)), S.ops.Act(g(y), 0, c, g(sc), g(sh), 0.01), S.ops.full(dy), instance_norm=False)
+    assert rel_err(dy.cpu(), y64.grad.float()) < 2e-6
