@@ -208,6 +208,11 @@ int san_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, co
                      float* y, int y_ctot, int y_coff, int n, int c, int h, int w, void* stream);
 int san_upsample2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
                       float* y, int y_ctot, int y_coff, int n, int c, int h, int w, void* stream);
+/* y[n, 4c+2dy+dx, i, j] = x[n, c, 2i+dy, 2j+dx]: x [n,c,2h,2w] -> y [n,4c,h,w] (h, w = OUTPUT dims).
+ * Turns the transposed convolution's output gradient into the 4*cout virtual channels of its
+ * 1x1-conv form, so its data / weight gradients reuse the conv kernels. */
+int san_unshuffle2_fwd(const float* x, int x_ctot, int x_coff, float* y, int y_ctot, int y_coff,
+                       int n, int c, int h, int w, void* stream);
 int san_add_fwd(const float* a, int a_ctot, int a_coff, const float* a_sc, const float* a_sh, float a_slope,
                 const float* b, int b_ctot, int b_coff, const float* b_sc, const float* b_sh, float b_slope,
                 float* y, int y_ctot, int y_coff, int n, int c, int hw, void* stream);

@@ -176,6 +176,24 @@ __global__ void __launch_bounds__(kThreads) upsample2_kernel(const EwArgs a) {
     }
 }
 
+// inverse pixel shuffle of the transposed convolution: y[n, 4c + 2dy + dx, i, j] = x[n, c, 2i+dy, 2j+dx]
+// (a.h, a.w are the OUTPUT plane dims; grid.y runs over the c input channels)
+__global__ void __launch_bounds__(kThreads) unshuffle2_kernel(const EwArgs a) {
+    const int ch = blockIdx.y, n = blockIdx.z;
+    const int h = a.h, w = a.w, iw = 2 * a.w;
+    const float* xp = a.x + ((size_t)(n * a.x_ctot + a.x_coff + ch)) * (size_t)(4 * h * w);
+    float* yp = a.y + ((size_t)(n * a.y_ctot + a.y_coff + 4 * ch)) * (size_t)(h * w);
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < h * w; i += gridDim.x * kThreads) {
+        const int iy = i / w, ix = i - iy * w;
+        const float2 r0 = *reinterpret_cast<const float2*>(xp + (size_t)(2 * iy) * iw + 2 * ix);
+        const float2 r1 = *reinterpret_cast<const float2*>(xp + (size_t)(2 * iy + 1) * iw + 2 * ix);
+        yp[i] = r0.x;
+        yp[(size_t)h * w + i] = r0.y;
+        yp[(size_t)2 * h * w + i] = r1.x;
+        yp[(size_t)3 * h * w + i] = r1.y;
+    }
+}
+
 // h*w passed as a.h (a.w == 1)
 __global__ void __launch_bounds__(kThreads) add_kernel(const EwArgs a) {
     const int ch = blockIdx.y, n = blockIdx.z;
@@ -304,6 +322,19 @@ int san_upsample2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, c
     a.x = x; a.sc = sc; a.sh = sh; a.slope = slope; a.x_ctot = x_ctot; a.x_coff = x_coff;
     a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff; a.n = n; a.c = c; a.h = h; a.w = w;
     hipLaunchKernelGGL(upsample2_kernel, ew_grid(h * w * 4, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_unshuffle2_fwd(const float* x, int x_ctot, int x_coff, float* y, int y_ctot, int y_coff, int n, int c, int h,
+                       int w, void* stream) {
+    SAN_CHECK_ARG(x && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0, "bad dims");
+    SAN_CHECK_ARG(check_view(x_ctot, x_coff, c) && check_view(y_ctot, y_coff, 4 * c), "bad channel view");
+    EwArgs a{};
+    a.x = x; a.x_ctot = x_ctot; a.x_coff = x_coff; a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff;
+    a.n = n; a.c = c; a.h = h; a.w = w;
+    hipLaunchKernelGGL(unshuffle2_kernel, ew_grid(h * w * 4, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

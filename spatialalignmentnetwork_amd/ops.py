@@ -473,3 +473,9 @@ def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_
         part = arena.get("bwd_part", (y.n, y.c, tiles, 2), y.buf.device)
     lib().call("san_act_bwd", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
                float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, hw, _stream())
+
+
+def unshuffle2(x: Act, y: Act) -> None:
+    """y[n, 4c+2dy+dx, i, j] = x[n, c, 2i+dy, 2j+dx] (x is read raw: pass a materialised gradient)."""
+    assert y.c == 4 * x.c and x.h == 2 * y.h and x.w == 2 * y.w
+    lib().call("san_unshuffle2_fwd", _p(x.buf), x.ctot, x.coff, _p(y.buf), y.ctot, y.coff, x.n, x.c, y.h, y.w, _stream())

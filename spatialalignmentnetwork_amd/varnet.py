@@ -53,6 +53,22 @@ class ConvBlock(nn.Module):
         ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
         return out
 
+    def run_bwd(self, g_out: Act, x: Act, mid: Act, out: Act, g_in: Optional[Act]) -> None:
+        """g_out = dL/d(lrelu(IN(out))) (materialised).  Accumulates both weight gradients and,
+        if g_in is given, writes dL/d(T(x)) (gradient wrt the lazily activated block input)."""
+        n, h, w, dev = x.n, x.h, x.w, x.buf.device
+        wa, wb = self.layers[0].weight, self.layers[3].weight
+        dyb = Act(ARENA.get("bwd.dy", (n, out.c, h, w), dev), 0, out.c)
+        ops.act_bwd(g_out, out, dyb, instance_norm=True)
+        ops.conv2d_wgrad(mid, dyb, _grad_of(wb), accumulate=True)
+        g_mid = Act(ARENA.get("bwd.gmid", (n, mid.c, h, w), dev), 0, mid.c)
+        ops.conv2d_dgrad(dyb, wb, g_mid)
+        dya = Act(ARENA.get("bwd.dy", (n, mid.c, h, w), dev), 0, mid.c)
+        ops.act_bwd(g_mid, mid, dya, instance_norm=True)
+        ops.conv2d_wgrad(x, dya, _grad_of(wa), accumulate=True)
+        if g_in is not None:
+            ops.conv2d_dgrad(dya, wa, g_in)
+
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         n, _, h, w = image.shape
         dev = image.device
@@ -81,6 +97,24 @@ class TransposeConvBlock(nn.Module):
         ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
         return out
 
+    def run_bwd(self, g_out: Act, x: Act, out: Act, g_in: Act) -> None:
+        """Backward of tconv + IN + LReLU.  The transposed conv is a 1x1 conv to 4*Cout virtual
+        channels (tap-major) + pixel shuffle, so after un-shuffling dy both gradients are plain
+        1x1-conv gradients: dgrad with the weight viewed as [Cin, 4*Cout, 1, 1]."""
+        wt = self.layers[0].weight                       # [Cin, Cout, 2, 2]
+        cin, cout = wt.shape[0], wt.shape[1]
+        n, h, w, dev = x.n, x.h, x.w, x.buf.device
+        dyt = Act(ARENA.get("bwd.dyt", (n, cout, 2 * h, 2 * w), dev), 0, cout)
+        ops.act_bwd(g_out, out, dyt, instance_norm=True)
+        dyp = Act(ARENA.get("bwd.dyp", (n, 4 * cout, h, w), dev), 0, 4 * cout)
+        ops.unshuffle2(dyt, dyp)
+        wv = _view_cached(wt, (cin, 4 * cout, 1, 1))
+        # dL/dx[ci] = sum_c' Wv[ci, c'] dy'[c']  == forward 1x1 conv with weight [cout'=Cin, cin'=4Cout]
+        ops.conv2d(dyp, wv, None, g_in)
+        dwv = ARENA.get("bwd.dwv", (4 * cout, cin, 1, 1), dev)
+        ops.conv2d_wgrad(x, dyp, dwv, accumulate=False)
+        _grad_of(wt).add_(dwv.view(4 * cout, cin).t().reshape(cin, cout, 2, 2))
+
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         n, _, h, w = image.shape
         out = _new_act(n, self.out_chans, 2 * h, 2 * w, image.device, 0.2)
@@ -88,6 +122,33 @@ class TransposeConvBlock(nn.Module):
         y = torch.empty_like(out.buf)
         ops.apply(out, ops.full(y))
         return y
+
+
+def _grad_of(p: torch.Tensor) -> torch.Tensor:
+    """The parameter's .grad buffer (zero-initialised on first use, accumulated into afterwards)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _view_cached(w: torch.Tensor, shape) -> torch.Tensor:
+    key = (w._version, w.data_ptr(), tuple(shape))
+    hit = getattr(w, "_san_view", None)
+    if hit is None or hit[0] != key:
+        hit = (key, w.detach().view(*shape))
+        w._san_view = hit
+    return hit[1]
+
+
+def _const_affine(name: str, n: int, c: int, value: float, dev):
+    """[n, c] scale filled with `value` and a zero shift (lazy 'multiply by constant')."""
+    sc = ARENA.get(f"{name}.sc{value}", (n, c), dev)
+    sh = ARENA.get(f"{name}.sh0", (n, c), dev)
+    if not getattr(sc, "_san_filled", False):
+        sc.fill_(value)
+        sh.zero_()
+        sc._san_filled = True
+    return sc, sh
 
 
 def _new_act(n, c, h, w, dev, slope) -> Act:
@@ -120,6 +181,7 @@ class Unet(nn.Module):
             ch //= 2
         self.up_transpose_conv.append(TransposeConvBlock(ch * 2, ch))
         self.up_conv.append(nn.Sequential(ConvBlock(ch * 2, ch), nn.Conv2d(ch, self.out_chans, kernel_size=1, stride=1)))
+        self._tapes = {}          # key -> activations retained by run() for run_bwd()
 
     def run(self, x: Act, out: Act, out_scale: Optional[torch.Tensor] = None,
             out_shift: Optional[torch.Tensor] = None, key: str = "unet") -> Act:
@@ -128,6 +190,7 @@ class Unet(nn.Module):
         come from the shared arena (inference: cascades reuse them)."""
         P = self.num_pool_layers
         n, h, w, dev = x.n, x.h, x.w, x.buf.device
+        tape = {"x": x, "blocks": [], "pooled": [], "ups": []}
         if (h % (1 << P)) or (w % (1 << P)):
             raise NotImplementedError(
                 f"U-Net input {h}x{w} not divisible by 2^{P}: the reflect-pad path (varnet.py:107-114) "
@@ -141,13 +204,16 @@ class Unet(nn.Module):
             cat = _arena_act(f"{tagp}.cat{i}", n, 2 * ch, hh, ww, dev, 0.2)   # [0,ch): up path, [ch,2ch): skip
             mid = _arena_act(f"{tagp}.mid{i}", n, ch, hh, ww, dev, 0.2)
             self.down_sample_layers[i].run(cur, mid, cat.view(ch, ch), tagp)
+            tape["blocks"].append((cur, mid, cat.view(ch, ch)))
             cats.append(cat)
             pooled = Act(ARENA.get(f"{tagp}.pool{i}", (n, ch, hh // 2, ww // 2), dev), 0, ch)
             ops.avgpool2(cat.view(ch, ch), pooled)
+            tape["pooled"].append(pooled)
             cur = pooled
             hh, ww, ch = hh // 2, ww // 2, ch * 2
         mid = _arena_act(f"{tagp}.midb", n, ch, hh, ww, dev, 0.2)
         bot = _arena_act(f"{tagp}.bot", n, ch, hh, ww, dev, 0.2)
+        tape["bott"] = (cur, mid, bot)
         cur = self.conv.run(cur, mid, bot, tagp)
         for i in range(P):
             ch //= 2
@@ -158,10 +224,56 @@ class Unet(nn.Module):
             mid = _arena_act(f"{tagp}.umid{lvl}", n, ch, hh, ww, dev, 0.2)
             up = _arena_act(f"{tagp}.up{lvl}", n, ch, hh, ww, dev, 0.2)
             block = self.up_conv[i] if i < P - 1 else self.up_conv[i][0]
+            tape["ups"].append((cur, cat, mid, up))      # cur = the transposed conv's input
             cur = block.run(cat, mid, up, tagp)
         last = self.up_conv[P - 1][1]
         ops.conv2d(cur, last.weight, last.bias, out, stats=False, out_scale=out_scale, out_shift=out_shift)
+        tape["last_in"] = cur
+        self._tapes[key] = tape
         return out
+
+    def run_bwd(self, g_conv: torch.Tensor, key: str = "unet") -> torch.Tensor:
+        """Backward of the last ``run(..., key=key)``.  g_conv [N, out_chans, H, W] is the gradient
+        wrt the final 1x1 conv's output BEFORE the optional output affine.  Accumulates every
+        parameter gradient and returns dL/d(T(x)) [N, in_chans, H, W] for the lazily read input."""
+        tape = self._tapes[key]
+        P = self.num_pool_layers
+        x = tape["x"]
+        n, dev = x.n, x.buf.device
+        last = self.up_conv[P - 1][1]
+        cur = tape["last_in"]
+        gc = ops.full(g_conv.contiguous())
+        # final 1x1 conv (+bias): bias gradient = plane sums of g
+        part = ops.plane_stats(gc, tag="bgrad")
+        _grad_of(last.bias).add_((part[..., 0] * part[..., 1]).sum(dim=(0, 2)))
+        ops.conv2d_wgrad(cur, gc, _grad_of(last.weight), accumulate=True)
+        g = Act(ARENA.get(f"bwd.g.{cur.c}.{cur.h}", (n, cur.c, cur.h, cur.w), dev), 0, cur.c)
+        ops.conv2d_dgrad(gc, last.weight, g)
+        skip_g = [None] * P
+        for i in reversed(range(P)):
+            tin, cat, mid, up = tape["ups"][i]
+            lvl = P - 1 - i
+            ch = up.c
+            block = self.up_conv[i] if i < P - 1 else self.up_conv[i][0]
+            g_cat = Act(ARENA.get(f"bwd.gcat{lvl}", (n, 2 * ch, cat.h, cat.w), dev), 0, 2 * ch)
+            block.run_bwd(g, cat, mid, up, g_cat)
+            skip_g[lvl] = g_cat.view(ch, ch)
+            g = Act(ARENA.get(f"bwd.g.{tin.c}.{tin.h}", (n, tin.c, tin.h, tin.w), dev), 0, tin.c)
+            self.up_transpose_conv[i].run_bwd(g_cat.view(0, ch), tin, cat.view(0, ch), g)
+        bx, bmid, bot = tape["bott"]
+        g_pool = Act(ARENA.get(f"bwd.gp.{bx.c}.{bx.h}", (n, bx.c, bx.h, bx.w), dev), 0, bx.c)
+        self.conv.run_bwd(g, bx, bmid, bot, g_pool)
+        for i in reversed(range(P)):
+            bin_, bmid_, bout = tape["blocks"][i]
+            ch = bout.c
+            # avg-pool backward (x0.25, nearest up-sampling) + the skip connection's gradient
+            sc, sh = _const_affine("bwd.quarter", n, ch, 0.25, dev)
+            up = Act(ARENA.get(f"bwd.pup{i}", (n, ch, bout.h, bout.w), dev), 0, ch)
+            ops.upsample2(Act(g_pool.buf, 0, ch, sc, sh, 1.0), up)
+            ops.add(up, skip_g[i], up)
+            g_pool = Act(ARENA.get(f"bwd.gp.{bin_.c}.{bin_.h}", (n, bin_.c, bin_.h, bin_.w), dev), 0, bin_.c)
+            self.down_sample_layers[i].run_bwd(up, bin_, bmid_, bout, g_pool)
+        return g_pool.buf
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         assert not torch.is_complex(image)

@@ -345,3 +345,28 @@ def test_instance_norm_act_backward(S):
     torch.nn.functional.leaky_relu(y64 * sc[:, :, None, None].double() + sh[:, :, None, None].double(), 0.01).backward(gout.double())
     S.ops.act_bwd(S.ops.full(g(gout)), S.ops.Act(g(y), 0, c, g(sc), g(sh), 0.01), S.ops.full(dy), instance_norm=False)
     assert rel_err(dy.cpu(), y64.grad.float()) < 2e-6
+
+
+def test_unet_backward_vs_oracle_autograd(S):
+    """Unet.run_bwd (hand-written backward on the HIP kernels) against autograd of the oracle."""
+    n, h, w = 2, 32, 48
+    net = S.varnet.Unet(3, 2, chans=4, num_pool_layers=2)
+    params = S.synth.fill_params([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=77)
+    net.load_state_dict(params)
+    net.to(DEV)
+    x = philox("ub.x", (n, 3, h, w))
+    gout = philox("ub.g", (n, 2, h, w))
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    x64 = x.double().requires_grad_(True)
+    S.O.unet_forward(p64, "", x64, 2).backward(gout.double())
+    y = torch.empty((n, 2, h, w), device=DEV)
+    net.run(S.ops.full(g(x)), S.ops.full(y), key="t")
+    assert rel_err(y.cpu(), S.O.unet_forward(params, "", x, 2)) < 1e-5
+    gx = net.run_bwd(g(gout), key="t")
+    assert rel_err(gx.cpu(), x64.grad.float()) < 1e-4
+    worst = 0.0
+    for name, prm in net.named_parameters():
+        want = p64[name].grad.float()
+        err = (prm.grad.cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+        worst = max(worst, err)
+    assert worst < 2e-4, worst
