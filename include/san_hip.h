@@ -152,6 +152,11 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin,
                      float* dw, int accumulate, float* partial,
                      int n, int h, int w, int ks, void* stream);
 int san_bwd_stat_tiles(int hw);
+/* part[n, c, san_bwd_stat_tiles(hw), 2] = per-chunk (sum u, sum u*yh), yh = sc*y+sh,
+ * u = g*(yh >= 0 ? 1 : slope): the two plane reductions every normalisation backward needs. */
+int san_plane_dot_stats(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
+                        const float* sc, const float* sh, float slope, float* part,
+                        int n, int c, int hw, void* stream);
 int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                 const float* sc, const float* sh, float slope, int mode, float* part,
                 float* dy, int d_ctot, int d_coff, int n, int c, int hw, void* stream);

@@ -279,6 +279,20 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const floa
     return SAN_OK;
 }
 
+int san_plane_dot_stats(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                        const float* sh, float slope, float* part, int n, int c, int hw, void* stream) {
+    SAN_CHECK_ARG(g && y && part, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    SAN_CHECK_ARG(g_coff >= 0 && g_coff + c <= g_ctot && y_coff >= 0 && y_coff + c <= y_ctot, "bad channel view");
+    int tiles = san_cdiv(hw, 4096);
+    tiles = tiles < 1 ? 1 : (tiles > 32 ? 32 : tiles);
+    hipLaunchKernelGGL(bwd_stats_kernel, dim3(tiles, c, n), dim3(kThreads), 0, (hipStream_t)stream, g, g_ctot, g_coff, y,
+                       y_ctot, y_coff, sc, sh, slope, c, hw, tiles, part);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
 int san_bwd_stat_tiles(int hw) {
     int t = san_cdiv(hw, 4096);
     return t < 1 ? 1 : (t > 32 ? 32 : t);

@@ -479,3 +479,15 @@ def unshuffle2(x: Act, y: Act) -> None:
     """y[n, 4c+2dy+dx, i, j] = x[n, c, 2i+dy, 2j+dx] (x is read raw: pass a materialised gradient)."""
     assert y.c == 4 * x.c and x.h == 2 * y.h and x.w == 2 * y.w
     lib().call("san_unshuffle2_fwd", _p(x.buf), x.ctot, x.coff, _p(y.buf), y.ctot, y.coff, x.n, x.c, y.h, y.w, _stream())
+
+
+def plane_dot_sums(g: Act, y: Act):
+    """(sum u, sum u*yh) per (n, c) with yh = y's lazy affine value and u = g * lrelu'(yh): [n, c] each."""
+    assert g.c == y.c
+    hw = y.h * y.w
+    tiles = lib().query("san_bwd_stat_tiles", hw)
+    part = torch.empty((y.n, y.c, tiles, 2), device=y.buf.device, dtype=torch.float32)
+    lib().call("san_plane_dot_stats", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+               float(y.slope), _p(part), y.n, y.c, hw, _stream())
+    s = part.double().sum(dim=2)
+    return s[..., 0], s[..., 1]

@@ -297,6 +297,7 @@ class NormUnet(nn.Module):
         if use_ref:
             self.ref_norm = nn.InstanceNorm2d(in_chans)
         self.in_chans, self.out_chans = in_chans, out_chans
+        self._tapes = {}
 
     # -- fused path -------------------------------------------------------
     def input_buffer(self, b: int, h: int, w: int, dev, key: str) -> Act:
@@ -324,7 +325,50 @@ class NormUnet(nn.Module):
         part = ops.plane_stats(xin.view(0, 2), tag="gn")
         ops.norm_finalize(part, ops.NORM_GROUP, 1e-6, xin.scale, xin.shift, 0, aux_a=std, aux_b=mean)
         self.unet.run(xin, ops.full(out_planar), out_scale=std, out_shift=mean, key=key)
+        self._tapes[key] = (xin, out_planar, std, mean)
         return out_planar
+
+    def run_bwd(self, g_out: torch.Tensor, key: str, want_ref_grad: bool = False):
+        """Backward of the last run(key).  g_out: dL/d(output) planar [B,2,H,W].  Returns
+        (dL/d(input planar) [B,2,H,W], dL/d(ref) [B,1,H,W] or None); parameter gradients accumulate.
+
+        With x^ = (m - mu)/(sigma + eps) (sigma = unbiased std of the plane), U = unet(x^, ref^) and
+        out = U*sigma + mu:
+            dL/dU   = g_out * sigma
+            dmu     = sum(g_out)   - sum(g_x^)/(sigma+eps)
+            dsigma  = sum(g_out*U) - sum(g_x^ * x^)/(sigma+eps)
+            dL/dm   = g_x^/(sigma+eps) + dmu/n + dsigma * (m - mu)/((n-1)*sigma)."""
+        xin, out_planar, std, mean = self._tapes[key]
+        b, h, w, dev = xin.n, xin.h, xin.w, xin.buf.device
+        nel = h * w
+        g_out = g_out.contiguous()
+        isd = (1.0 / std).contiguous()
+        B1, B2 = ops.plane_dot_sums(ops.full(g_out), Act(out_planar, 0, 2, isd, (-mean * isd).contiguous(), 1.0))
+        g_u = ARENA.get("bwd.g_u", (b, 2, h, w), dev)
+        ops.apply(Act(g_out, 0, 2, std, torch.zeros_like(std), 1.0), ops.full(g_u))
+        g_xh = self.unet.run_bwd(g_u, key)                         # [B, 2 or 3, H, W]
+        ctot = g_xh.shape[1]
+        A1, A2 = ops.plane_dot_sums(Act(g_xh, 0, 2), xin.view(0, 2))
+        s = xin.scale[:, 0:2].double()
+        t = xin.shift[:, 0:2].double()
+        dmu = B1 - A1 * s
+        dsig = B2 - A2 * s
+        cco = dsig / (s * (nel - 1) * std.double())
+        a_sc = torch.zeros((b, ctot), device=dev)
+        a_sh = torch.zeros((b, ctot), device=dev)
+        a_sc[:, 0:2] = s.float()
+        a_sh[:, 0:2] = (dmu / nel).float()
+        m_sc = torch.zeros((b, xin.ctot), device=dev)
+        m_sh = torch.zeros((b, xin.ctot), device=dev)
+        m_sc[:, 0:2] = (cco * s).float()
+        m_sh[:, 0:2] = (cco * t).float()
+        g_m = torch.empty((b, 2, h, w), device=dev)
+        ops.add(Act(g_xh, 0, 2, a_sc, a_sh, 1.0), Act(xin.buf, xin.coff, 2, m_sc, m_sh, 1.0), ops.full(g_m))
+        g_ref = None
+        if self.use_ref and want_ref_grad:
+            g_ref = torch.empty((b, 1, h, w), device=dev)
+            ops.act_bwd(Act(g_xh, 2, 1), xin.view(2, 1), ops.full(g_ref), instance_norm=True)
+        return g_m, g_ref
 
     # -- reference-compatible entry --------------------------------------
     def forward(self, x: torch.Tensor, ref: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -370,3 +370,40 @@ def test_unet_backward_vs_oracle_autograd(S):
         err = (prm.grad.cpu() - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
         worst = max(worst, err)
     assert worst < 2e-4, worst
+
+
+@pytest.mark.parametrize("use_ref", [True, False])
+def test_normunet_backward_vs_oracle_autograd(S, use_ref):
+    n, h, w = 2, 32, 48
+    net = S.varnet.NormUnet(4, 2, use_ref=use_ref)
+    params = S.synth.fill_params([(k, tuple(v.shape)) for k, v in net.state_dict().items()], seed=78)
+    net.load_state_dict(params)
+    net.to(DEV)
+    x = cplx("nb.x", (n, 1, h, w)) * 2 + 0.5
+    ref = philox("nb.ref", (n, 1, h, w), lo=0.0, hi=1.0) if use_ref else None
+    gout = cplx("nb.g", (n, 1, h, w))
+    p64 = {k: v.double().requires_grad_(True) for k, v in params.items()}
+    x64 = x.to(torch.complex128).requires_grad_(True)
+    r64 = ref.double().requires_grad_(True) if use_ref else None
+    y64 = S.O.normunet_forward(p64, "", x64, r64, 2, use_ref)
+    (y64.real * gout.real.double() + y64.imag * gout.imag.double()).sum().backward()
+    # HIP path through the fused entry points
+    xin = net.input_buffer(n, h, w, DEV, "nbt")
+    planar = torch.cat([x.real, x.imag], 1)
+    S.ops.apply(S.ops.full(g(planar)), xin.view(0, 2))
+    if use_ref:
+        net.set_ref(xin, g(ref))
+    out = torch.empty((n, 2, h, w), device=DEV)
+    net.run(xin, out, "nbt")
+    assert rel_err(torch.complex(out[:, 0:1], out[:, 1:2]).cpu(), y64.detach().to(torch.complex64)) < 2e-5
+    g_planar = torch.cat([gout.real, gout.imag], 1)
+    g_m, g_ref = net.run_bwd(g(g_planar), "nbt", want_ref_grad=use_ref)
+    want = torch.cat([x64.grad.real, x64.grad.imag], 1).float()
+    assert rel_err(g_m.cpu(), want) < 2e-4
+    if use_ref:
+        assert rel_err(g_ref.cpu(), r64.grad.float()) < 2e-4
+    worst = 0.0
+    for name, prm in net.named_parameters():
+        wantp = p64[name].grad.float()
+        worst = max(worst, (prm.grad.cpu() - wantp).abs().max().item() / max(wantp.abs().max().item(), 1e-12))
+    assert worst < 3e-4, worst
