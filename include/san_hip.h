@@ -161,6 +161,24 @@ int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ct
                 const float* sc, const float* sh, float slope, int mode, float* part,
                 float* dy, int d_ctot, int d_coff, int n, int c, int hw, void* stream);
 
+/* k-space / loss backward pieces (PyTorch's complex-gradient convention g = dL/dRe + i dL/dIm):
+ *   san_dc_weight_grad    : partial[256] chunks of  -sum mask[w] * Re(conj(G)*(k-k0))  (varnet.py:527-528)
+ *   san_sens_grad_acc     : gS[n,c] += sign1*conj(r[n])*t1[n,c] + x[n,c]*conj(gm[n])  (r, gm planar [n,2,hw]):
+ *                           the sensitivity-map gradient of one cascade (sens_expand + sens_reduce)
+ *   san_sens_normalize_bwd: backward of S = est/(rss(est)+1e-6)                        (varnet.py:418-419)
+ *   san_rss_bwd           : gx_c = g * x_c / rss                                        (signal_utils.py:24-26)
+ *   san_ssim_loss_bwd     : gy = gscale * d(1 - mean SSIM(x, y))/dy; ws: fp32 [3*n*(h-6)*(w-6)]  (ssimloss.py:11-40) */
+int san_dc_weight_grad(const float* g, const float* k, const float* k0, const float* mask, float* partial,
+                       int planes, int h, int w, void* stream);
+int san_sens_grad_acc(float* gs, const float* r_planar, const float* t1, const float* x, const float* gm_planar,
+                      float sign1, int n, int c, int hw, void* stream);
+int san_sens_normalize_bwd(const float* est_planar, const float* gs, float* gest_planar, int n, int c, int hw,
+                           void* stream);
+int san_rss_bwd(const float* x, const float* y, const float* g, float* gx, int n, int c, int hw, int is_complex,
+                void* stream);
+int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, int n, int h, int w, float* ws,
+                      void* stream);
+
 /* ConvTranspose2d 2x2 stride 2, no bias: y [n, cout, 2h, 2w].
  * w_packed from san_conv_pack_weights(..., ks=2, transposed=1).
  * Evaluated as a 1x1 convolution to 4*cout virtual channels (one per tap) on

@@ -231,6 +231,167 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
     }
 }
 
+
+// ---------------------------------------------------------- k-space / loss backward pieces
+// dL/d(dc_weight) partial sums: -sum M[w] * Re(conj(G) * (k - k0)) over one plane chunk
+__global__ void __launch_bounds__(kThreads)
+dc_weight_grad_kernel(const float2* __restrict__ G, const float2* __restrict__ k, const float2* __restrict__ k0,
+                      const float* __restrict__ mask, float* __restrict__ partial, size_t total, int W) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (size_t)gridDim.x * kThreads) {
+        const float m = mask[i % W];
+        const float2 g = G[i], a = k[i], b = k0[i];
+        s -= m * (g.x * (a.x - b.x) + g.y * (a.y - b.y));
+    }
+    s = san_wave_total(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// gS[n,c] += sign1 * conj(r[n]) * t1[n,c] + x[n,c] * conj(gm[n]);  r, gm planar [n,2,hw]
+__global__ void __launch_bounds__(kThreads)
+sens_grad_acc_kernel(float2* __restrict__ gS, const float* __restrict__ r, const float2* __restrict__ t1,
+                     const float2* __restrict__ x, const float* __restrict__ gm, float sign1, int C, int HW) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < HW; i += gridDim.x * kThreads) {
+        const float rr = r[(size_t)n * 2 * HW + i], ri = r[(size_t)n * 2 * HW + HW + i];
+        const float gr = gm[(size_t)n * 2 * HW + i], gi = gm[(size_t)n * 2 * HW + HW + i];
+        for (int c = 0; c < C; ++c) {
+            const size_t e = ((size_t)n * C + c) * HW + i;
+            const float2 t = t1[e], xv = x[e];
+            float2 acc = gS[e];
+            // conj(r) * t = (rr - i ri)(t.x + i t.y)
+            acc.x += sign1 * (rr * t.x + ri * t.y);
+            acc.y += sign1 * (rr * t.y - ri * t.x);
+            // x * conj(gm) = (x.x + i x.y)(gr - i gi)
+            acc.x += xv.x * gr + xv.y * gi;
+            acc.y += xv.y * gr - xv.x * gi;
+            gS[e] = acc;
+        }
+    }
+}
+
+// S_c = e_c / d, d = sqrt(sum |e_c|^2) + eps:  g_e_c = G_c/d - T * e_c / rss,  T = Re(sum conj(G_c) e_c) / d^2
+__global__ void __launch_bounds__(kThreads)
+sens_normalize_bwd_kernel(const float* __restrict__ est, const float2* __restrict__ gS, float* __restrict__ gest, int C,
+                          int HW) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < HW; i += gridDim.x * kThreads) {
+        float ss = 0.f, dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const size_t b = ((size_t)(n * C + c) * 2) * HW + i;
+            const float re = est[b], im = est[b + HW];
+            const float2 g = gS[((size_t)n * C + c) * HW + i];
+            ss += re * re + im * im;
+            dot += g.x * re + g.y * im;
+        }
+        const float rs = sqrtf(ss);
+        const float d = rs + 1e-6f;
+        const float T = dot / (d * d);
+        const float inv_rs = rs > 0.f ? 1.f / rs : 0.f;
+        for (int c = 0; c < C; ++c) {
+            const size_t b = ((size_t)(n * C + c) * 2) * HW + i;
+            const float re = est[b], im = est[b + HW];
+            const float2 g = gS[((size_t)n * C + c) * HW + i];
+            gest[b] = g.x / d - T * re * inv_rs;
+            gest[b + HW] = g.y / d - T * im * inv_rs;
+        }
+    }
+}
+
+// y = sqrt(sum_c |x_c|^2): gx_c = g * x_c / y   (complex interleaved or real x)
+__global__ void __launch_bounds__(kThreads)
+rss_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ g,
+               float* __restrict__ gx, int C, int HW, int is_complex) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < HW; i += gridDim.x * kThreads) {
+        const float yv = y[(size_t)n * HW + i];
+        const float f = yv > 0.f ? g[(size_t)n * HW + i] / yv : 0.f;
+        for (int c = 0; c < C; ++c) {
+            const size_t e = ((size_t)n * C + c) * HW + i;
+            if (is_complex) {
+                const float2 v = *reinterpret_cast<const float2*>(x + 2 * e);
+                *reinterpret_cast<float2*>(gx + 2 * e) = make_float2(v.x * f, v.y * f);
+            } else {
+                gx[e] = x[e] * f;
+            }
+        }
+    }
+}
+
+// SSIM backward, stage 1: per window position the derivatives of S wrt (uy, uyy, uxy)
+__global__ void __launch_bounds__(kThreads)
+ssim_bwd_coef_kernel(const float* __restrict__ X, const float* __restrict__ Y, float* __restrict__ coef, int H, int W,
+                     int OH, int OW) {
+    constexpr int K = 7, TW = 32, TH = 8, IW = TW + K - 1, IH = TH + K - 1;
+    __shared__ float sx[IH][IW + 1];
+    __shared__ float sy[IH][IW + 1];
+    const int n = blockIdx.z;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const float* xp = X + (size_t)n * H * W;
+    const float* yp = Y + (size_t)n * H * W;
+    for (int e = threadIdx.x; e < IH * IW; e += kThreads) {
+        const int r = e / IW, c = e - r * IW;
+        const int gy = oy0 + r, gx = ox0 + c;
+        const bool ok = gy < H && gx < W;
+        sx[r][c] = ok ? xp[(size_t)gy * W + gx] : 0.f;
+        sy[r][c] = ok ? yp[(size_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int ox = ox0 + lx, oy = oy0 + ly;
+    if (ox >= OW || oy >= OH) return;
+    float s_x = 0.f, s_y = 0.f, s_xx = 0.f, s_yy = 0.f, s_xy = 0.f;
+#pragma unroll
+    for (int r = 0; r < K; ++r)
+#pragma unroll
+        for (int c = 0; c < K; ++c) {
+            const float a = sx[ly + r][lx + c], b = sy[ly + r][lx + c];
+            s_x += a;
+            s_y += b;
+            s_xx = fmaf(a, a, s_xx);
+            s_yy = fmaf(b, b, s_yy);
+            s_xy = fmaf(a, b, s_xy);
+        }
+    const float inv = 1.f / 49.f, cov = 49.f / 48.f, C1 = 1e-4f, C2 = 9e-4f;
+    const float ux = s_x * inv, uy = s_y * inv, uxx = s_xx * inv, uyy = s_yy * inv, uxy = s_xy * inv;
+    const float vx = cov * (uxx - ux * ux), vy = cov * (uyy - uy * uy), vxy = cov * (uxy - ux * uy);
+    const float A1 = 2.f * ux * uy + C1, A2 = 2.f * vxy + C2, B1 = ux * ux + uy * uy + C1, B2 = vx + vy + C2;
+    const float Sv = (A1 * A2) / (B1 * B2);
+    const float dA1 = A2 / (B1 * B2), dA2 = A1 / (B1 * B2), dB1 = -Sv / B1, dB2 = -Sv / B2;
+    const float d_uy = dA1 * 2.f * ux - dA2 * 2.f * cov * ux + dB1 * 2.f * uy - dB2 * 2.f * cov * uy;
+    const float d_uyy = dB2 * cov;
+    const float d_uxy = dA2 * 2.f * cov;
+    const size_t o = ((size_t)n * OH + oy) * OW + ox;
+    const size_t plane = (size_t)gridDim.z * OH * OW;
+    coef[o] = d_uy;
+    coef[plane + o] = d_uyy;
+    coef[2 * plane + o] = d_uxy;
+}
+
+// stage 2: g_Y[q] = scale/49 * sum_{windows p containing q} (d_uy[p] + 2 Y[q] d_uyy[p] + X[q] d_uxy[p])
+__global__ void __launch_bounds__(kThreads)
+ssim_bwd_gather_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ coef,
+                       float* __restrict__ gY, int N, int H, int W, int OH, int OW, float scale) {
+    const int n = blockIdx.y;
+    const size_t plane = (size_t)N * OH * OW;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < H * W; i += gridDim.x * kThreads) {
+        const int qy = i / W, qx = i - qy * W;
+        float a = 0.f, b = 0.f, c = 0.f;
+        for (int py = max(qy - 6, 0); py <= min(qy, OH - 1); ++py)
+            for (int px = max(qx - 6, 0); px <= min(qx, OW - 1); ++px) {
+                const size_t o = ((size_t)n * OH + py) * OW + px;
+                a += coef[o];
+                b += coef[plane + o];
+                c += coef[2 * plane + o];
+            }
+        const size_t e = (size_t)n * H * W + i;
+        gY[e] = scale * (1.f / 49.f) * (a + 2.f * Y[e] * b + X[e] * c);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -322,6 +483,70 @@ int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ct
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(bx, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc,
                        sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_dc_weight_grad(const float* g, const float* k, const float* k0, const float* mask, float* partial, int planes,
+                       int h, int w, void* stream) {
+    SAN_CHECK_ARG(g && k && k0 && mask && partial, "null pointer");
+    SAN_CHECK_ARG(planes > 0 && h > 0 && w > 0, "bad dims");
+    hipLaunchKernelGGL(dc_weight_grad_kernel, dim3(256), dim3(kThreads), 0, (hipStream_t)stream, (const float2*)g,
+                       (const float2*)k, (const float2*)k0, mask, partial, (size_t)planes * h * w, w);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_sens_grad_acc(float* gs, const float* r_planar, const float* t1, const float* x, const float* gm_planar,
+                      float sign1, int n, int c, int hw, void* stream) {
+    SAN_CHECK_ARG(gs && r_planar && t1 && x && gm_planar, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    int bx = san_cdiv(hw, kThreads);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(sens_grad_acc_kernel, dim3(bx, n), dim3(kThreads), 0, (hipStream_t)stream, (float2*)gs, r_planar,
+                       (const float2*)t1, (const float2*)x, gm_planar, sign1, c, hw);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_sens_normalize_bwd(const float* est_planar, const float* gs, float* gest_planar, int n, int c, int hw,
+                           void* stream) {
+    SAN_CHECK_ARG(est_planar && gs && gest_planar, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    int bx = san_cdiv(hw, kThreads);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(sens_normalize_bwd_kernel, dim3(bx, n), dim3(kThreads), 0, (hipStream_t)stream, est_planar,
+                       (const float2*)gs, gest_planar, c, hw);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_rss_bwd(const float* x, const float* y, const float* g, float* gx, int n, int c, int hw, int is_complex,
+                void* stream) {
+    SAN_CHECK_ARG(x && y && g && gx, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    int bx = san_cdiv(hw, kThreads);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(rss_bwd_kernel, dim3(bx, n), dim3(kThreads), 0, (hipStream_t)stream, x, y, g, gx, c, hw,
+                       is_complex);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, int n, int h, int w, float* ws,
+                      void* stream) {
+    SAN_CHECK_ARG(x && y && gy && ws, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h >= 7 && w >= 7, "image smaller than the 7x7 window");
+    const int oh = h - 6, ow = w - 6;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ssim_bwd_coef_kernel, dim3(san_cdiv(ow, 32), san_cdiv(oh, 8), n), dim3(kThreads), 0, s, x, y, ws,
+                       h, w, oh, ow);
+    SAN_LAUNCH_CHECK();
+    int bx = san_cdiv(h * w, kThreads);
+    if (bx > 512) bx = 512;
+    // loss = 1 - mean(S)  ->  dL/dS = -gscale / (n*oh*ow)
+    hipLaunchKernelGGL(ssim_bwd_gather_kernel, dim3(bx, n), dim3(kThreads), 0, s, x, y, ws, gy, n, h, w, oh, ow,
+                       -gscale / ((float)n * oh * ow));
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

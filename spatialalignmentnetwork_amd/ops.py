@@ -491,3 +491,51 @@ def plane_dot_sums(g: Act, y: Act):
                float(y.slope), _p(part), y.n, y.c, hw, _stream())
     s = part.double().sum(dim=2)
     return s[..., 0], s[..., 1]
+
+
+def dc_weight_grad(G: torch.Tensor, k: torch.Tensor, k0: torch.Tensor, mask_f: torch.Tensor) -> torch.Tensor:
+    """dL/d(dc_weight) of k' = k - w*M*(k-k0) - R given G = dL/dk' (0-d tensor)."""
+    n, c, h, w = k.shape
+    part = torch.empty(256, device=k.device, dtype=torch.float32)
+    lib().call("san_dc_weight_grad", _p(_creal(G, "G")), _p(_creal(k, "k")), _p(_creal(k0, "k0")), _p(mask_f), _p(part),
+               n * c, h, w, _stream())
+    return part.double().sum().float()
+
+
+def sens_grad_acc(gS: torch.Tensor, r_planar: torch.Tensor, t1: torch.Tensor, x: torch.Tensor, gm_planar: torch.Tensor,
+                  sign1: float) -> None:
+    n, c, h, w = gS.shape
+    lib().call("san_sens_grad_acc", _p(_creal(gS, "gS")), _p(_chk(r_planar, name="r")), _p(_creal(t1, "t1")),
+               _p(_creal(x, "x")), _p(_chk(gm_planar, name="gm")), float(sign1), n, c, h * w, _stream())
+
+
+def sens_normalize_bwd(est_planar: torch.Tensor, gS: torch.Tensor) -> torch.Tensor:
+    n, c, h, w = gS.shape
+    out = torch.empty_like(est_planar)
+    lib().call("san_sens_normalize_bwd", _p(_chk(est_planar, name="est")), _p(_creal(gS, "gS")), _p(out), n, c, h * w,
+               _stream())
+    return out
+
+
+def rss_bwd(x: torch.Tensor, y: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """gradient of y = rss(x) wrt x (complex or real x)."""
+    n, c = x.shape[:2]
+    hw = x.shape[2] * x.shape[3]
+    gx = torch.empty_like(x)
+    if torch.is_complex(x):
+        lib().call("san_rss_bwd", _p(_creal(x, "x")), _p(_chk(y, name="y")), _p(_chk(g, name="g")),
+                   _p(torch.view_as_real(gx)), n, c, hw, 1, _stream())
+    else:
+        lib().call("san_rss_bwd", _p(_chk(x, name="x")), _p(_chk(y, name="y")), _p(_chk(g, name="g")), _p(gx), n, c, hw,
+                   0, _stream())
+    return gx
+
+
+def ssim_loss_bwd(x: torch.Tensor, y: torch.Tensor, gscale: float = 1.0) -> torch.Tensor:
+    """gscale * d ssimloss(x, y) / dy."""
+    n, c, h, w = x.shape
+    ws = GLOBAL_ARENA.get("ssim_bwd_ws", (3 * n * (h - 6) * (w - 6),), x.device)
+    gy = torch.empty_like(y)
+    lib().call("san_ssim_loss_bwd", _p(_chk(x, name="x")), _p(_chk(y, name="y")), _p(gy), float(gscale), n, h, w, _p(ws),
+               _stream())
+    return gy

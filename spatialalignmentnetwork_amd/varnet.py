@@ -418,7 +418,14 @@ class SensitivityModel(nn.Module):
         ops.ifft2c_planar(masked_kspace, acs, xin.buf)
         est = ARENA.get("sens.est", (n * c, 2, h, w), dev)
         self.norm_unet.run(xin, est, "sens")
+        self._tape = (est, n, c)
         return ops.sens_normalize(est, n, c)
+
+    def backward(self, g_sens: torch.Tensor) -> None:
+        """dL/d(sens maps) -> parameter gradients (the masked k-space input needs none)."""
+        est, n, c = self._tape
+        g_est = ops.sens_normalize_bwd(est, g_sens)
+        self.norm_unet.run_bwd(g_est, "sens", want_ref_grad=False)
 
 
 _ACS_CACHE = {}
@@ -449,7 +456,37 @@ class VarNetBlock(nn.Module):
         r = ARENA.get(f"{key}.r", (n, 2, h, w), k.device)
         self.model.run(xin, r, key)
         ops.sens_expand_dc(r, sens, k, k0, mask_f, self.dc_weight.detach(), k_out)
+        self._tape = (k, k0, mask_f, sens, r, key)
         return k_out
+
+    def run_bwd(self, g_kout: torch.Tensor, g_sens: Optional[torch.Tensor], want_ref_grad: bool):
+        """Backward of the last run().  g_kout = dL/dk' (complex).  Returns (dL/dk, dL/d ref or None);
+        accumulates parameter gradients and, if g_sens is given, the sensitivity-map gradient.
+
+          R = fft2(r*S):           dL/dr = -sum_c conj(S_c) ifft2(g)_c          = -sens_reduce(g, S)
+          m = sum_c ifft2(k)_c conj(S_c), r = NormUnet(m):  dL/dk += fft2(g_m * S)
+          soft DC:                 dL/dk += g * (1 - w*M);  dL/dw = -sum M Re(conj(g) (k - k0))
+        so dL/dk = sens_expand_dc(r := -g_m, S, k := g, k0 := 0): the forward kernel again."""
+        k, k0, mask_f, sens, r, key = self._tape
+        n, c, h, w = k.shape
+        dev = k.device
+        hbuf = ARENA.get("bwd.h", (n, 2, h, w), dev)
+        ops.sens_reduce(g_kout, sens, hbuf)
+        neg_sc, neg_sh = _const_affine("bwd.neg", n, 2, -1.0, dev)
+        g_r = ARENA.get("bwd.g_r", (n, 2, h, w), dev)
+        ops.apply(Act(hbuf, 0, 2, neg_sc, neg_sh, 1.0), ops.full(g_r))
+        g_m, g_ref = self.model.run_bwd(g_r, key, want_ref_grad)
+        if g_sens is not None:
+            t1 = ops.fft2c(g_kout, inverse=True)          # ifft2(g); the R-term carries sign -1
+            x = ops.fft2c(k, inverse=True)
+            ops.sens_grad_acc(g_sens, r, t1, x, g_m, -1.0)
+        _grad_of(self.dc_weight).add_(ops.dc_weight_grad(g_kout, k, k0, mask_f))
+        neg_gm = ARENA.get("bwd.neg_gm", (n, 2, h, w), dev)
+        ops.apply(Act(g_m, 0, 2, neg_sc, neg_sh, 1.0), ops.full(neg_gm))
+        zeros = ARENA.get("bwd.zero_k", (n, c, h, w), dev, dtype=torch.complex64, zero=True)
+        g_k = torch.empty_like(g_kout)
+        ops.sens_expand_dc(neg_gm, sens, g_kout, zeros, mask_f, self.dc_weight.detach(), g_k)
+        return g_k, g_ref
 
     def forward(self, current_kspace: torch.Tensor, ref_kspace: torch.Tensor, mask: torch.Tensor,
                 sens_maps: torch.Tensor, ref_image: Optional[torch.Tensor]) -> torch.Tensor:
@@ -483,18 +520,56 @@ class VarNet(nn.Module):
         masked_kspace = masked_kspace.contiguous()
         n, c, h, w = masked_kspace.shape
         dev = masked_kspace.device
+        retain = self.training and torch.is_grad_enabled()
         sens = self.sens_net(masked_kspace, num_low_frequencies)
         mask_f = mask.reshape(-1).to(torch.float32).contiguous()
         assert mask_f.numel() == w, "mask must be a [W] column mask (broadcast like the reference's [1,1,1,W])"
-        xin = self.cascades[0].model.input_buffer(n, h, w, dev, "cas")
+        ref1 = None
         if self.use_ref:
-            ref1 = ops.rss(ref.contiguous())            # varnet.py:475-476
-            self.cascades[0].model.set_ref(xin, ref1)
-        k_buf = ARENA.get("cas.k", (n, c, h, w), dev, dtype=torch.complex64)
+            ref = ref.contiguous()
+            ref1 = ops.rss(ref)                          # varnet.py:475-476
         k = masked_kspace                                # cascade 0 reads k0 itself: no clone (varnet.py:473)
-        for cascade in self.cascades:
-            k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_buf, "cas")
-        return ops.ifft2_rss(k)
+        if not retain:
+            xin = self.cascades[0].model.input_buffer(n, h, w, dev, "cas")
+            if self.use_ref:
+                self.cascades[0].model.set_ref(xin, ref1)
+            k_buf = ARENA.get("cas.k", (n, c, h, w), dev, dtype=torch.complex64)
+            for cascade in self.cascades:
+                k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_buf, "cas")
+            return ops.ifft2_rss(k)
+        # training: every cascade keeps its own activations and its own k-space buffers
+        for j, cascade in enumerate(self.cascades):
+            key = f"cas{j}"
+            xin = cascade.model.input_buffer(n, h, w, dev, key)
+            if self.use_ref:
+                cascade.model.set_ref(xin, ref1)
+            k_out = ARENA.get(f"{key}.kout", (n, c, h, w), dev, dtype=torch.complex64)
+            k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_out, key)
+        out = ops.ifft2_rss(k)
+        self._train_state = (k, out, ref, ref1)
+        return out
+
+    def backward(self, g_img: torch.Tensor, want_ref_grad: bool = False) -> Optional[torch.Tensor]:
+        """Backward of the last training-mode forward().  g_img = dL/d(output image) [N,1,H,W].
+        Accumulates every parameter gradient (cascades, dc weights, sensitivity net) and returns
+        dL/d(ref) (the `ref` argument of forward) when asked."""
+        k_last, out, ref, ref1 = self._train_state
+        x = ops.fft2c(k_last, inverse=True)
+        g_x = ops.rss_bwd(x, out, g_img.contiguous())
+        g_k = ops.fft2c(g_x)                             # adjoint of the ortho ifft2
+        g_sens = torch.zeros_like(k_last)
+        g_ref1 = None
+        for cascade in reversed(self.cascades):
+            g_k, g_ref = cascade.run_bwd(g_k, g_sens, want_ref_grad and self.use_ref)
+            if g_ref is not None:
+                if g_ref1 is None:
+                    g_ref1 = g_ref
+                else:
+                    ops.add(ops.full(g_ref1), ops.full(g_ref), ops.full(g_ref1))
+        self.sens_net.backward(g_sens)
+        if g_ref1 is None:
+            return None
+        return ops.rss_bwd(ref, ref1, g_ref1)            # through ref = rss(ref)
 
 
 def _unused(*_):  # keep math imported for API parity with the reference module

@@ -407,3 +407,42 @@ def test_normunet_backward_vs_oracle_autograd(S, use_ref):
         wantp = p64[name].grad.float()
         worst = max(worst, (prm.grad.cpu() - wantp).abs().max().item() / max(wantp.abs().max().item(), 1e-12))
     assert worst < 3e-4, worst
+
+
+def test_ssim_backward(S):
+    a = philox("sb.a", (2, 1, 40, 56), lo=0.0, hi=1.0)
+    b = (a + 0.1 * philox("sb.b", (2, 1, 40, 56))).clamp(0, 1)
+    b64 = b.double().requires_grad_(True)
+    (S.O.ssimloss(a.double(), b64) * 0.7).backward()
+    got = S.ops.ssim_loss_bwd(g(a), g(b), 0.7)
+    assert rel_err(got.cpu(), b64.grad.float()) < 1e-4
+
+
+@pytest.mark.parametrize("tag,shape", [("32", (2, 1, 32, 32)), ("48x80c3", (2, 3, 48, 80))])
+def test_varnet_backward_vs_golden_grads(S, tag, shape):
+    """VarNet.backward (all cascades, dc weights, sensitivity net) against the gradients the
+    REFERENCE produced for the same weights and inputs (tests/golden, 'Rec' objective)."""
+    gold = load_golden(f"e2e_small_{tag}.npz")
+    n, c, h, w = shape
+    net_R = S.varnet.VarNet(num_cascades=2, sens_chans=2, sens_pools=2, chans=4, pools=2, use_ref=True)
+    net_R.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net_R.state_dict().items()], seed=42))
+    net_R.to(DEV).train()
+    pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+    k_samp = g(as_t(gold["train.img_k_sampled"], True))
+    warped = g(as_t(gold["train.img_warped"]))           # teacher-forced: the reference's own train-mode warp
+    full_rss = g(as_t(gold["train.img_full_rss"]))
+    rec = net_R(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32))
+    assert rel_err(rec.cpu(), as_t(gold["train.img_rec"])) < 1e-4
+    g_img = S.ops.ssim_loss_bwd(full_rss, rec, 1.0)      # weight_sim = 1
+    net_R.backward(g_img, want_ref_grad=False)
+    worst, worst_name = 0.0, ""
+    for name, prm in net_R.named_parameters():
+        want = as_t(gold["grad.R." + name])
+        scale = want.abs().max().item()
+        if scale < 1e-12:
+            continue
+        err = (prm.grad.cpu() - want).abs().max().item() / scale
+        if err > worst:
+            worst, worst_name = err, name
+    print("worst relative gradient error", worst, worst_name)
+    assert worst < 5e-3, (worst, worst_name)
