@@ -179,6 +179,20 @@ int san_rss_bwd(const float* x, const float* y, const float* g, float* gx, int n
 int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, int n, int h, int w, float* ws,
                       void* stream);
 
+/* san_act_bwd_coef: dy = sc*(u - m1 - (p*yh + q)*m2) with coef[n, c, 4] = (m1, m2, p, q) given by
+ *   the caller (BatchNorm training backward: statistics over N,H,W reduced on the host from
+ *   san_plane_dot_stats, unet.py:125).
+ * san_warp_bwd_grid: gradient of the bilinear warp wrt the sampling grid, as NCHW [n,2,h,w]
+ *   (= gradient wrt the predicted offset field; cross.py:29-34).
+ * san_gradient_loss_bwd: g (+)= gscale * d gradient_loss / d offset (model.py:21-28). */
+int san_act_bwd_coef(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
+                     const float* sc, const float* sh, float slope, const float* coef,
+                     float* dy, int d_ctot, int d_coff, int n, int c, int hw, void* stream);
+int san_warp_bwd_grid(const float* img, const float* grid, const float* g, float* g_off,
+                      int n, int c, int h, int w, void* stream);
+int san_gradient_loss_bwd(const float* offset, float* g, float gscale, int accumulate, int n, int h, int w,
+                          void* stream);
+
 /* ConvTranspose2d 2x2 stride 2, no bias: y [n, cout, 2h, 2w].
  * w_packed from san_conv_pack_weights(..., ks=2, transposed=1).
  * Evaluated as a 1x1 convolution to 4*cout virtual channels (one per tap) on

@@ -42,7 +42,21 @@ class SpatialTransformer(torch.nn.Module):
         ops.lib().call("san_warp_fwd", ops._p(None), ops._p(offset_nchw), ops._p(None), ops._p(grid), n, 0, h, w, 0,
                        ops._stream())
         self._last_offset_nchw = offset_nchw
+        self._feat = feat
         return offset_nchw.permute(0, 2, 3, 1), grid
+
+    def backward(self, g_offset_nchw: torch.Tensor) -> None:
+        """dL/d(offset) (NCHW [N,2,H,W]: the sum of the warp's grid gradient and the smoothness
+        term) -> gradients of every alignment-network parameter (training-mode forward required)."""
+        from .unet import _grad_of
+        head, feat = self.net[2], self._feat
+        dy = ops.full(g_offset_nchw.contiguous())
+        part = ops.plane_stats(dy, tag="st.b")
+        _grad_of(head.bias).add_((part[..., 0] * part[..., 1]).sum(dim=(0, 2)))
+        ops.conv2d_wgrad(feat, dy, _grad_of(head.weight), accumulate=True)
+        g_feat = Act(ARENA.get("align.g_feat", tuple(feat.buf.shape), feat.buf.device), 0, feat.c)
+        ops.conv2d_dgrad(dy, head.weight, g_feat)
+        self.net[0].run_bwd(feat, g_feat)
 
     def warp(self, img, grid, interp=False):
         """Bilinear, zeros padding, align_corners=False; inputs forced to fp32 (cross.py:32-38)."""

@@ -392,6 +392,79 @@ ssim_bwd_gather_kernel(const float* __restrict__ X, const float* __restrict__ Y,
     }
 }
 
+// generic normalisation backward with host-provided per-(n,c) coefficients (m1, m2, p, q):
+//   yh = sc*y + sh, u = g*(yh >= 0 ? 1 : slope),  dy = sc * (u - m1 - (p*yh + q) * m2)
+// (BatchNorm training: m1 = mean(u), m2 = mean(u*yn) over N,H,W with yn = (yh - beta)/gamma)
+__global__ void __launch_bounds__(kThreads)
+act_bwd_coef_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot,
+                    int y_coff, const float* __restrict__ sc, const float* __restrict__ sh, float slope,
+                    const float* __restrict__ coef, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw) {
+    const int ch = blockIdx.y, n = blockIdx.z;
+    const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
+    const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
+    const float* cf = coef + ((size_t)n * c + ch) * 4;
+    const float m1 = cf[0], m2 = cf[1], p = cf[2], q = cf[3];
+    const float* gp = g + ((size_t)(n * g_ctot + g_coff + ch)) * hw;
+    const float* yp = y + ((size_t)(n * y_ctot + y_coff + ch)) * hw;
+    float* dp = dy + ((size_t)(n * d_ctot + d_coff + ch)) * hw;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads) {
+        const float yh = fmaf(yp[i], s, b);
+        const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
+        dp[i] = s * (u - m1 - fmaf(p, yh, q) * m2);
+    }
+}
+
+// bilinear warp backward wrt the sampling grid (zeros padding, align_corners = False):
+// g_off[n, 0/1, i, j] = sum_c g[n,c,i,j] * d out / d (x, y)   in normalised units (ix = ((x+1)W-1)/2)
+__global__ void __launch_bounds__(kThreads)
+warp_bwd_grid_kernel(const float* __restrict__ img, const float* __restrict__ grid, const float* __restrict__ g,
+                     float* __restrict__ g_off, int C, int H, int W) {
+    const int n = blockIdx.y;
+    const int HW = H * W;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < HW; i += gridDim.x * kThreads) {
+        const float2 gg = *reinterpret_cast<const float2*>(grid + ((size_t)n * HW + i) * 2);
+        const float ix = ((gg.x + 1.f) * (float)W - 1.f) * 0.5f;
+        const float iy = ((gg.y + 1.f) * (float)H - 1.f) * 0.5f;
+        const float fx = floorf(ix), fy = floorf(iy);
+        const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const bool xin0 = x0 >= 0 && x0 < W, xin1 = x1 >= 0 && x1 < W;
+        const bool yin0 = y0 >= 0 && y0 < H, yin1 = y1 >= 0 && y1 < H;
+        float gx = 0.f, gy = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float* p = img + ((size_t)n * C + c) * HW;
+            const float v00 = (yin0 && xin0) ? p[y0 * W + x0] : 0.f;
+            const float v01 = (yin0 && xin1) ? p[y0 * W + x1] : 0.f;
+            const float v10 = (yin1 && xin0) ? p[y1 * W + x0] : 0.f;
+            const float v11 = (yin1 && xin1) ? p[y1 * W + x1] : 0.f;
+            const float go = g[((size_t)n * C + c) * HW + i];
+            gx += go * ((v01 - v00) * wy0 + (v11 - v10) * wy1);
+            gy += go * ((v10 - v00) * wx0 + (v11 - v01) * wx1);
+        }
+        g_off[((size_t)n * 2 + 0) * HW + i] = gx * (0.5f * (float)W);
+        g_off[((size_t)n * 2 + 1) * HW + i] = gy * (0.5f * (float)H);
+    }
+}
+
+// d/ds of gscale * (mean(dW^2) + mean(dH^2))/2 for an NCHW [n,2,h,w] field; accumulates into g
+__global__ void __launch_bounds__(kThreads)
+gradient_loss_bwd_kernel(const float* __restrict__ off, float* __restrict__ g, int H, int W, float cx, float cy,
+                         int accumulate) {
+    const int plane = blockIdx.y;
+    const float* p = off + (size_t)plane * H * W;
+    float* gp = g + (size_t)plane * H * W;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < H * W; i += gridDim.x * kThreads) {
+        const int y = i / W, x = i - y * W;
+        const float v = p[i];
+        float d = 0.f;
+        if (x > 0) d += cx * (v - p[i - 1]);
+        if (x + 1 < W) d -= cx * (p[i + 1] - v);
+        if (y > 0) d += cy * (v - p[i - W]);
+        if (y + 1 < H) d -= cy * (p[i + W] - v);
+        gp[i] = accumulate ? gp[i] + d : d;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -547,6 +620,52 @@ int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, i
     // loss = 1 - mean(S)  ->  dL/dS = -gscale / (n*oh*ow)
     hipLaunchKernelGGL(ssim_bwd_gather_kernel, dim3(bx, n), dim3(kThreads), 0, s, x, y, ws, gy, n, h, w, oh, ow,
                        -gscale / ((float)n * oh * ow));
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_act_bwd_coef(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                     const float* sh, float slope, const float* coef, float* dy, int d_ctot, int d_coff, int n, int c,
+                     int hw, void* stream) {
+    SAN_CHECK_ARG(g && y && dy && coef, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    SAN_CHECK_ARG(g_coff >= 0 && g_coff + c <= g_ctot && y_coff >= 0 && y_coff + c <= y_ctot && d_coff >= 0 &&
+                      d_coff + c <= d_ctot, "bad channel view");
+    int bx = san_cdiv(hw, kThreads * 4);
+    long cap = 4096 / ((long)c * n);
+    if (cap < 1) cap = 1;
+    if (bx > cap) bx = (int)cap;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(act_bwd_coef_kernel, dim3(bx, c, n), dim3(kThreads), 0, (hipStream_t)stream, g, g_ctot, g_coff, y,
+                       y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, c, hw);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_warp_bwd_grid(const float* img, const float* grid, const float* g, float* g_off, int n, int c, int h, int w,
+                      void* stream) {
+    SAN_CHECK_ARG(img && grid && g && g_off, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && h > 0 && w > 0, "bad dims");
+    int bx = san_cdiv(h * w, kThreads);
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(warp_bwd_grid_kernel, dim3(bx, n), dim3(kThreads), 0, (hipStream_t)stream, img, grid, g, g_off, c,
+                       h, w);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_gradient_loss_bwd(const float* offset, float* g, float gscale, int accumulate, int n, int h, int w,
+                          void* stream) {
+    SAN_CHECK_ARG(offset && g, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h > 1 && w > 1, "bad dims");
+    // loss = gscale/2 * (sum dx^2 / cnt_x + sum dy^2 / cnt_y);  d(dx^2)/ds = 2 dx
+    const float cx = gscale / ((float)n * h * (w - 1) * 2);
+    const float cy = gscale / ((float)n * (h - 1) * w * 2);
+    int bx = san_cdiv(h * w, kThreads);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(gradient_loss_bwd_kernel, dim3(bx, n * 2), dim3(kThreads), 0, (hipStream_t)stream, offset, g, h, w,
+                       cx, cy, accumulate);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

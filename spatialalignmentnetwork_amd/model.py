@@ -37,7 +37,7 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
 class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.memo_init = set(self.__dict__.keys()) | {"memo_init"}
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -80,6 +80,7 @@ class CSModel(BaseModel):
     def forwardT(self):
         """model.py:142-155."""
         aux_abs = ops.cabs(self.img_aux)
+        self._aux_abs = aux_abs
         self.img_offset, self.img_grid = self.net_T(moving=aux_abs, fixed=ops.cabs(self.img_sampled))
         self.img_warped = self.net_T.warp(aux_abs, self.img_grid)
         self.img_warped_rss = rss(self.img_warped)
@@ -96,10 +97,44 @@ class CSModel(BaseModel):
         self.loss_sim = ssimloss(self.img_full_rss, self.img_rec)
         self.loss_all = self.loss_all + self.loss_sim * self.cfg.weight_sim
 
+    def backward(self, train_T: bool) -> None:
+        """Hand-written backward of loss_all = weight_smooth*loss_smooth + weight_sim*loss_sim through
+        forwardR (VarNet) and, when train_T, through the warp into forwardT (alignment network).
+        Replaces ``scalar.scale(loss_all).backward()`` (model.py:203-214)."""
+        g_rec = ops.ssim_loss_bwd(self.img_full_rss, self.img_rec, float(self.cfg.weight_sim))
+        g_warped = self.net_R.backward(g_rec, want_ref_grad=train_T)
+        if not train_T:
+            return
+        off = self.net_T._last_offset_nchw
+        # dL/d(offset): through warp -> rss is already folded by VarNet.backward (returns dL/d warped)
+        g_off = ops.warp_bwd_grid(self._aux_abs, self.img_grid, g_warped)
+        ops.gradient_loss_bwd(off, g_off, float(self.cfg.weight_smooth), True)
+        self.net_T.backward(g_off)
+
     def update(self):
-        raise NotImplementedError(
-            "training step (hand-written backward kernels + AdamW) is not built yet; "
-            "the HIP path currently covers set_input / forwardT / forwardR / test")
+        """One optimisation step.  Regimes 'None' (train R, T frozen) and 'Rec' (train T and R through
+        the warp), model.py:193-216; the GAN regimes are out of scope.  fp32 throughout: the
+        GradScaler of the reference's AMP path is a no-op here."""
+        assert self.training is True
+        reg = self.cfg.reg
+        if reg not in ("None", "Rec"):
+            raise NotImplementedError(f"regime {reg!r}: the GAN branch (Mixed / GAN-Only) is out of scope")
+        train_T = reg == "Rec"
+        self.loss_all = 0
+        if train_T:
+            self.forwardT()
+        else:
+            with torch.no_grad():
+                self.forwardT()
+            self.loss_all = 0
+        self.forwardR()
+        opts = [self.optim_R] + ([self.optim_T] if train_T else [])
+        for o in opts:
+            o.zero_grad(set_to_none=False)
+        self.backward(train_T)
+        for o in opts:
+            o.step()
+        del self.loss_all
 
     def test(self):
         """model.py:265-286 without the GAN branch; returns -PSNR."""

@@ -539,3 +539,25 @@ def ssim_loss_bwd(x: torch.Tensor, y: torch.Tensor, gscale: float = 1.0) -> torc
     lib().call("san_ssim_loss_bwd", _p(_chk(x, name="x")), _p(_chk(y, name="y")), _p(gy), float(gscale), n, h, w, _p(ws),
                _stream())
     return gy
+
+
+def act_bwd_coef(g: Act, y: Act, coef: torch.Tensor, dy: Act) -> None:
+    """dy = sc*(u - m1 - (p*yh + q)*m2), coef [n, c, 4] = (m1, m2, p, q)."""
+    assert g.c == y.c == dy.c and coef.shape == (y.n, y.c, 4)
+    lib().call("san_act_bwd_coef", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+               float(y.slope), _p(_chk(coef, name="coef")), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, y.h * y.w, _stream())
+
+
+def warp_bwd_grid(img: torch.Tensor, grid: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """dL/d(offset) NCHW [N,2,H,W] of out = grid_sample(img, grid) given g = dL/d out."""
+    n, c, h, w = img.shape
+    out = torch.empty((n, 2, h, w), device=img.device, dtype=torch.float32)
+    lib().call("san_warp_bwd_grid", _p(_chk(img, name="img")), _p(_chk(grid, name="grid")), _p(_chk(g, name="g")),
+               _p(out), n, c, h, w, _stream())
+    return out
+
+
+def gradient_loss_bwd(offset_nchw: torch.Tensor, g: torch.Tensor, gscale: float, accumulate: bool) -> None:
+    n, two, h, w = offset_nchw.shape
+    lib().call("san_gradient_loss_bwd", _p(_chk(offset_nchw, name="offset")), _p(_chk(g, name="g")), float(gscale),
+               int(accumulate), n, h, w, _stream())

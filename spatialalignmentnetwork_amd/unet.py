@@ -16,7 +16,7 @@ BatchNorm + LeakyReLU(0.01) applied lazily by whichever kernel reads the tensor:
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List, Optional  # noqa: F401
 
 import torch
 
@@ -109,8 +109,13 @@ class UNet(torch.nn.Module):
             ResSequential(*[Conv2d(current_layer, current_layer) for _ in range(num_convs - 1)]),
             torch.nn.Conv2d(current_layer, out_channels, 3, padding=1))
         self.in_channels, self.out_channels = in_channels, out_channels
+        self._tape = None
+        self._produced = {}
 
     # ------------------------------------------------------------------ fused executor
+    # Every op goes through one of five recorders (conv+BN, bare conv, add, avg-pool, up-sample) so
+    # that run_bwd() can replay the tape in reverse; activations are identified by (buffer, channel
+    # range), gradients are materialised per activation and summed when an activation has two readers.
     def _cba(self, seq, conv_i: int, x: Act, out: Act, tag: str, count_scale: int = 1) -> Act:
         """conv(+bias) raw into ``out`` and the lazy BatchNorm affine into out.scale/shift."""
         conv, bn = seq[conv_i], seq[conv_i + 1]
@@ -126,7 +131,17 @@ class UNet(torch.nn.Module):
             ops.conv2d(x, conv.weight, conv.bias, out, stats=False)
             ops.bn_eval_affine(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, BN_EPS,
                                out.scale, out.shift, out.coff)
+        self._record(("cba", conv, bn, x, out), out)
         return out
+
+    def _record(self, op, out: Act) -> None:
+        if self._tape is not None:
+            self._tape.append(op)
+            self._produced.setdefault(out.buf.data_ptr(), []).append((out.coff, out.c))
+
+    def _add(self, a: Act, b: Act, out: Act) -> None:
+        ops.add(a, b, out)
+        self._record(("add", a, b, out), out)
 
     def _res(self, res: ResSequential, x: Act, out: Act, key: str) -> Act:
         """out = x + subnet(x); x is read lazily, out is materialised (identity affine)."""
@@ -134,7 +149,7 @@ class UNet(torch.nn.Module):
         for i, seq in enumerate(res.subnet):
             t = _arena_act(f"{key}.r{i}", x.n, seq[0].weight.shape[0], x.h, x.w, x.buf.device)
             cur = self._cba(seq, 0, cur, t, key)
-        ops.add(x, cur, out)
+        self._add(x, cur, out)
         return out
 
     def _level(self, cat: CatSequential, x: Act, up_out: Act, key: str) -> None:
@@ -144,6 +159,7 @@ class UNet(torch.nn.Module):
         c_cur = m[0][1].weight.shape[0]
         pooled = Act(ARENA.get(f"{key}.pool", (n, x.c, h, w), dev), 0, x.c)
         ops.avgpool2(x, pooled)
+        self._record(("pool", x, pooled), pooled)
         d = _arena_act(f"{key}.down", n, c_cur, h, w, dev)
         self._cba(m[0], 1, pooled, d, key)
         has_inner = isinstance(m[2], CatSequential)
@@ -165,6 +181,7 @@ class UNet(torch.nn.Module):
         u = _arena_act(f"{key}.uplow", n, up_seq[1].weight.shape[0], h, w, dev)
         self._cba(up_seq, 1, src, u, key, count_scale=4)
         ops.upsample2(u, up_out)
+        self._record(("up", u, up_out), up_out)
 
     def run(self, x: Act, out: Act, key: str = "align") -> Act:
         """x: materialised [N, in_channels, H, W]; out: raw [N, out_channels, H, W]."""
@@ -173,6 +190,9 @@ class UNet(torch.nn.Module):
         depth = len(self.layer_channels) - 1
         if (h % (1 << depth)) or (w % (1 << depth)):
             raise NotImplementedError(f"alignment U-Net needs H, W divisible by {1 << depth}, got {h}x{w}")
+        retain = self.training and torch.is_grad_enabled()
+        self._tape = [] if retain else None
+        self._produced = {}
         c0 = s[0][0].weight.shape[0]
         c_low = s[2].module[-1][1].weight.shape[0]
         t0 = _arena_act(f"{key}.t0", n, c0, h, w, dev)
@@ -185,13 +205,134 @@ class UNet(torch.nn.Module):
         r2 = Act(ARENA.get(f"{key}.res2_0", (n, c0, h, w), dev), 0, c0)
         self._res(s[4], t, r2, key + ".res2")
         ops.conv2d(r2, s[5].weight, s[5].bias, out, stats=False)
+        self._record(("conv", s[5], r2, out), out)
         return out
+
+    # ------------------------------------------------------------------ backward (tape replay)
+    def run_bwd(self, out: Act, g_out: Act) -> None:
+        """Replay the tape of the last training-mode run() in reverse.  g_out = dL/d(lrelu-read of
+        `out`) materialised, i.e. the gradient wrt the activation the NEXT layer read from ``out``
+        (its scale/shift/slope describe that read).  Accumulates all parameter gradients."""
+        assert self._tape is not None, "run() was not in training mode"
+        grads = {}
+        counter = [0]
+
+        def tmp(c, h, w, n):
+            counter[0] += 1
+            return Act(ARENA.get(f"abwd.t{counter[0]}", (n, c, h, w), out.buf.device), 0, c)
+
+        def accum_input(x: Act, g: Act):
+            """g covers x's channels; split it over the activations that produced x's buffer."""
+            ranges = self._produced.get(x.buf.data_ptr())
+            if not ranges:
+                return                                    # network input: no gradient needed
+            for coff, c in ranges:
+                if coff >= x.coff and coff + c <= x.coff + x.c:
+                    key = (x.buf.data_ptr(), coff, c)
+                    piece = g.view(coff - x.coff, c)
+                    if key in grads:
+                        ops.add(grads[key], piece, grads[key])
+                    else:
+                        grads[key] = piece
+
+        def take(a: Act) -> Optional[Act]:
+            return grads.get((a.buf.data_ptr(), a.coff, a.c))
+
+        grads[(out.buf.data_ptr(), out.coff, out.c)] = g_out
+        for op in reversed(self._tape):
+            kind = op[0]
+            if kind in ("cba", "conv"):
+                if kind == "cba":
+                    _, conv, bn, x, o = op
+                else:
+                    _, conv, x, o = op
+                    bn = None
+                g = take(o)
+                if g is None:
+                    continue
+                n, h, w = o.n, o.h, o.w
+                dy = tmp(o.c, h, w, n)
+                if bn is not None and bn.training:
+                    S1, S2 = ops.plane_dot_sums(g, o)            # per (n, c): sum u, sum u*yh
+                    S1, S2 = S1.sum(0), S2.sum(0)
+                    gamma, beta = bn.weight.detach().double(), bn.bias.detach().double()
+                    cnt = float(n * h * w)
+                    dbeta = S1
+                    dgamma = (S2 - beta * S1) / gamma            # sum u * yn, yn = (yh - beta)/gamma
+                    _grad_of(bn.weight).add_(dgamma.float())
+                    _grad_of(bn.bias).add_(dbeta.float())
+                    coef = torch.stack([dbeta / cnt, dgamma / cnt, 1.0 / gamma, -beta / gamma], dim=1).float()
+                    ops.act_bwd_coef(g, o, coef[None].expand(n, -1, -1).contiguous(), dy)
+                else:
+                    ops.act_bwd(g, o, dy, instance_norm=False)   # eval BN / plain activation read
+                    if bn is not None:
+                        raise NotImplementedError("backward through eval-mode BatchNorm parameters")
+                part = ops.plane_stats(dy, tag="abwd.b")
+                _grad_of(conv.bias).add_((part[..., 0] * part[..., 1]).sum(dim=(0, 2)))
+                ops.conv2d_wgrad(x, dy, _grad_of(conv.weight), accumulate=True)
+                if self._produced.get(x.buf.data_ptr()):
+                    gx = tmp(x.c, h, w, n)
+                    ops.conv2d_dgrad(dy, conv.weight, gx)
+                    accum_input(x, gx)
+            elif kind == "add":
+                _, a, b, o = op
+                g = take(o)
+                if g is None:
+                    continue
+                accum_input(a, g)
+                g2 = tmp(o.c, o.h, o.w, o.n)
+                ops.apply(g, g2)                                  # second reader gets its own copy
+                accum_input(b, g2)
+            elif kind == "pool":
+                _, x, o = op
+                g = take(o)
+                if g is None:
+                    continue
+                sc, sh = _const_affine("abwd.q", o.n, o.c, 0.25, o.buf.device)
+                gx = tmp(x.c, x.h, x.w, x.n)
+                ops.upsample2(Act(g.buf, g.coff, g.c, _expand_aff(sc, g), _expand_aff(sh, g), 1.0), gx)
+                accum_input(x, gx)
+            elif kind == "up":
+                _, u, o = op
+                g = take(o)
+                if g is None:
+                    continue
+                sc, sh = _const_affine("abwd.f", u.n, u.c, 4.0, u.buf.device)
+                gu = tmp(u.c, u.h, u.w, u.n)
+                ops.avgpool2(Act(g.buf, g.coff, g.c, _expand_aff(sc, g), _expand_aff(sh, g), 1.0), gu)
+                accum_input(u, gu)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         n, _, h, w = x.shape
         y = torch.empty((n, self.out_channels, h, w), device=x.device)
         self.run(ops.full(x.contiguous()), ops.full(y))
         return y
+
+
+def _grad_of(p: torch.Tensor) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)
+    return p.grad
+
+
+def _const_affine(name: str, n: int, c: int, value: float, dev):
+    sc = ARENA.get(f"{name}.sc{value}", (n, c), dev)
+    sh = ARENA.get(f"{name}.sh0", (n, c), dev)
+    if not getattr(sc, "_san_filled", False):
+        sc.fill_(value)
+        sh.zero_()
+        sc._san_filled = True
+    return sc, sh
+
+
+def _expand_aff(a: torch.Tensor, g: Act) -> torch.Tensor:
+    """Affine arrays are laid out like their buffer's channel axis ([n, ctot], read at coff + ch):
+    place a per-view [n, c] constant array at the view's offset of a [n, ctot] array."""
+    if g.coff == 0 and g.ctot == a.shape[1]:
+        return a
+    full = torch.zeros((a.shape[0], g.ctot), device=a.device)
+    full[:, g.coff:g.coff + g.c] = a
+    return full
 
 
 def _arena_act(name, n, c, h, w, dev) -> Act:

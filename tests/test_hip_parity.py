@@ -446,3 +446,70 @@ def test_varnet_backward_vs_golden_grads(S, tag, shape):
             worst, worst_name = err, name
     print("worst relative gradient error", worst, worst_name)
     assert worst < 5e-3, (worst, worst_name)
+
+
+def test_warp_and_smoothness_backward(S):
+    img = philox("wb.img", (2, 3, 24, 40), lo=0.0, hi=1.0)
+    off = (philox("wb.off", (2, 24, 40, 2)) * 0.2)
+    off[0, :2] += 1.5
+    gout = philox("wb.g", (2, 3, 24, 40))
+    o64 = off.double().requires_grad_(True)
+    grid64 = S.O.identity_grid(24, 40, torch.float64) + o64
+    out = torch.nn.functional.grid_sample(img.double(), grid64, align_corners=False)
+    (out * gout.double()).sum().backward()
+    off_nchw = off.permute(0, 3, 1, 2).contiguous()
+    _, grid = S.ops.warp(g(img), g(off_nchw))
+    got = S.ops.warp_bwd_grid(g(img), grid, g(gout))
+    want = o64.grad.permute(0, 3, 1, 2).float()
+    assert rel_err(got.cpu(), want) < 2e-4
+    # smoothness term, accumulated on top
+    o64 = off.double().requires_grad_(True)
+    (S.O.gradient_loss(o64) * 1000.0).backward()
+    S.ops.gradient_loss_bwd(g(off_nchw), got, 1000.0, True)
+    assert rel_err(got.cpu(), want + o64.grad.permute(0, 3, 1, 2).float()) < 2e-4
+
+
+@pytest.mark.parametrize("tag,shape", [("32", (2, 1, 32, 32)), ("48x80c3", (2, 3, 48, 80))])
+def test_full_rec_step_gradients_vs_golden(S, tag, shape):
+    """CSModel-style 'Rec' step: train-mode forward of T and R, hand-written backward through SSIM,
+    VarNet, warp and the BatchNorm alignment network; losses, BatchNorm running statistics and EVERY
+    parameter gradient against what the reference produced (tests/golden)."""
+    from spatialalignmentnetwork_amd.basemodel import Config
+    from spatialalignmentnetwork_amd.model import CSModel
+    gold = load_golden(f"e2e_small_{tag}.npz")
+    n, c, h, w = shape
+    cfg = Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                 weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=2, chans=4,
+                 sens_chans=2, pools=2, sens_pools=2)
+    net = CSModel(cfg)
+    net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+    net.net_T.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net.net_T.state_dict().items()], seed=41))
+    net.net_R.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net.net_R.state_dict().items()], seed=42))
+    net.to(DEV).train()
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    net.set_input(g(img_full), g(img_aux))
+    net.loss_all = 0
+    net.forwardT()
+    net.forwardR()
+    assert rel_err(net.img_warped.cpu(), as_t(gold["train.img_warped"])) < 5e-5
+    assert rel_err(net.img_rec.cpu(), as_t(gold["train.img_rec"])) < 1e-4
+    assert abs(net.loss_all.item() - float(gold["train.loss_all"])) < 1e-4 * max(1.0, abs(float(gold["train.loss_all"])))
+    net.backward(train_T=True)
+    for pre, mod in (("grad.R.", net.net_R), ("grad.T.", net.net_T)):
+        worst, worst_name = 0.0, ""
+        for name, prm in mod.named_parameters():
+            want = as_t(gold[pre + name])
+            scale = want.abs().max().item()
+            got = prm.grad.cpu() if prm.grad is not None else torch.zeros_like(want)
+            if scale < 1e-7:
+                assert got.abs().max().item() < 1e-5, name      # conv bias in front of BatchNorm: exactly 0 in theory
+                continue
+            err = (got - want).abs().max().item() / scale
+            if err > worst:
+                worst, worst_name = err, name
+        print(pre, "worst relative gradient error", worst, worst_name)
+        assert worst < 1e-2, (pre, worst, worst_name)
+    for k in gold.files:
+        if k.startswith("bn_after.T."):
+            got = dict(net.net_T.named_buffers())[k[len("bn_after.T."):]]
+            assert torch.allclose(got.cpu(), as_t(gold[k]), rtol=2e-4, atol=2e-6), k
