@@ -62,6 +62,13 @@ def one_step(net, img_full, img_aux):
     return net.img_rec
 
 
+def train_step(net, img_full, img_aux):
+    """set_input + update(): forward of T and R, hand-written backward, (RCCL grad all-reduce when
+    world > 1,) AdamW for both networks -- the reference's 'Rec' regime (model.py:206-216)."""
+    net.set_input(img_full, img_aux)
+    net.update()
+
+
 def usable_cores(cap=32):
     """Host threads the baseline may really use: the affinity mask and the cgroup CPU quota,
     not os.cpu_count() (a 256-thread oneDNN team on a quota-limited box crawls), capped."""
@@ -114,6 +121,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="slices per GPU")
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--cascades", type=int, default=12)
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -140,10 +148,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if args.mode == "train":
+        net.train()
+        step = lambda: train_step(net, img_full, img_aux)
+    else:
+        step = lambda: one_step(net, img_full, img_aux)
     for _ in range(args.warmup):
-        one_step(net, img_full, img_aux)
+        step()
     torch.cuda.synchronize()
-    step = lambda: one_step(net, img_full, img_aux)
     if args.graph:
         # the arena, packed weights, twiddles and masks exist after warm-up, so the step neither
         # allocates through the library nor synchronises: it is capture-safe
@@ -181,7 +193,7 @@ def main():
             "metric": "slices/sec (320x320, 12-cascade VarNet+align)", "value": total_slices / dt, "unit": "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"inference pass set_input+align+warp+VarNet{args.cascades}+SSIM, "
+            "config": {"workload": ("train step (regime Rec: fwd + hand-written bwd + grad all-reduce + AdamW) " if args.mode == "train" else "inference pass ") + f"set_input+align+warp+VarNet{args.cascades}+SSIM, "
                                    f"{n} slices/GPU of {h}x{w} single-coil, 4x equispaced mask, random-init weights",
                        "slices_per_gpu": n, "global_batch": n * world, "cascades": args.cascades,
                        "parallelism": f"dp{world} (independent slice shards, no data-path collective)",

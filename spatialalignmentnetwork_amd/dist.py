@@ -90,3 +90,30 @@ def gather_metric_mean(local_sum: float, local_count: int, dist, device="cpu") -
     s = sum_over_ranks(local_sum, dist, device)
     c = sum_over_ranks(float(local_count), dist, device)
     return s / max(c, 1.0)
+
+
+class GradBucket:
+    """One flat fp32 gradient buffer for a set of parameters; every ``p.grad`` is a view into it, so
+    the data-parallel exchange is a single in-place all-reduce with no packing copies.  (Bucketing
+    per cascade to overlap the exchange with the rest of the backward pass is the next step.)"""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else "cpu"
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce_mean(self, dist) -> None:
+        """Average the gradients over all ranks (sum, then divide by the world size)."""
+        if dist is None:
+            return
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(dist.get_world_size())

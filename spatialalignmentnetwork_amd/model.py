@@ -37,7 +37,7 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
 class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs"}
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_buckets"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -129,12 +129,27 @@ class CSModel(BaseModel):
             self.loss_all = 0
         self.forwardR()
         opts = [self.optim_R] + ([self.optim_T] if train_T else [])
-        for o in opts:
-            o.zero_grad(set_to_none=False)
+        buckets = self._grad_buckets()
+        for name in (["R"] + (["T"] if train_T else [])):
+            buckets[name].zero()
         self.backward(train_T)
+        dist = _active_dist()
+        if dist is not None:                    # data parallel: gradients averaged over ranks (RCCL on GPUs)
+            for name in (["R"] + (["T"] if train_T else [])):
+                buckets[name].allreduce_mean(dist)
         for o in opts:
             o.step()
         del self.loss_all
+
+    def _grad_buckets(self):
+        """Flat per-network gradient buffers (built once; p.grad are views, see dist.GradBucket)."""
+        b = self.__dict__.get("_buckets")
+        dev = next(self.net_R.parameters()).device
+        if b is None or b["R"].flat.device != dev:
+            from .dist import GradBucket
+            b = {"R": GradBucket(self.net_R.parameters()), "T": GradBucket(self.net_T.parameters())}
+            self._buckets = b
+        return b
 
     def test(self):
         """model.py:265-286 without the GAN branch; returns -PSNR."""
@@ -169,6 +184,11 @@ class CSModel(BaseModel):
         if content in (None, "histograms"):
             vis["histograms"] = {"weights": {"values": self.net_mask.weight.detach()}}
         return vis
+
+
+def _active_dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
 _KEEP_CACHE = {}

@@ -56,3 +56,28 @@ def test_shard_bounds_properties():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _grad_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = sdist.init("gloo")
+    torch.manual_seed(0)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Linear(7, 3))
+    bucket = sdist.GradBucket(lin.parameters())
+    assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in lin.parameters())
+    bucket.zero()
+    for i, p in enumerate(lin.parameters()):
+        p.grad.add_(float(rank + 1) * (i + 1))          # rank-dependent "gradient", written through the views
+    bucket.allreduce_mean(d)
+    out[rank] = [float(p.grad.flatten()[0]) for p in lin.parameters()]
+    d.destroy_process_group()
+
+
+def test_grad_bucket_allreduce_mean_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_grad_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        assert out[r] == [1.5 * (i + 1) for i in range(4)]   # mean of (1, 2) * (i + 1) on every rank
