@@ -39,6 +39,7 @@ __global__ void __launch_bounds__(kThreads) conv_wgrad_kernel(const WgradArgs a)
     constexpr int TAPS = KS * KS;
     constexpr int AW = kTW + 2 * PAD, AH = kTH + 2 * PAD;
     constexpr int AP = AW + 1, DP = kTW + 1;         // LDS pitches
+    constexpr int ASLOTS = (AH * AW + kThreads - 1) / kThreads;   // 2 (3x3) or 1 (1x1) staged elements per channel
     __shared__ float aT[kCIB][AH][AP];
     __shared__ float dT[kCOB][kTH][DP];
     const int tid = threadIdx.x;
@@ -56,44 +57,75 @@ __global__ void __launch_bounds__(kThreads) conv_wgrad_kernel(const WgradArgs a)
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) acc[c][t] = f4{0.f, 0.f, 0.f, 0.f};
 
+    // per-thread staging slots (tile-relative, computed once): input halo tile and dy tile
+    int ar[ASLOTS], ac[ASLOTS];
+    bool a_in[ASLOTS];
+#pragma unroll
+    for (int s = 0; s < ASLOTS; ++s) {
+        const int e = tid + s * kThreads;
+        a_in[s] = e < AH * AW;
+        ar[s] = a_in[s] ? e / AW : 0;
+        ac[s] = a_in[s] ? e - ar[s] * AW : 0;
+    }
+    const int dr = tid / kTW, dc = tid - dr * kTW;     // 256 threads == kTH * kTW dy elements per channel
+
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int total_tiles = tiles_per_img * a.N;
-    for (int tile = blockIdx.x; tile < total_tiles; tile += a.P) {
+    float sa[kCIB][ASLOTS], sd[kCOB];
+    bool a_ok[ASLOTS];
+    bool d_ok = false;
+    int tn = 0;
+    // global -> registers for one tile (loads are unconditional on clamped addresses)
+    auto prefetch = [&](int tile) {
         const int n = tile / tiles_per_img;
         const int tr = tile - n * tiles_per_img;
         const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
         const int x0 = tx * kTW, y0 = ty * kTH;
+        tn = n;
+        int aoff[ASLOTS];
+#pragma unroll
+        for (int s = 0; s < ASLOTS; ++s) {
+            const int gy = y0 - PAD + ar[s], gx = x0 - PAD + ac[s];
+            a_ok[s] = a_in[s] && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            aoff[s] = a_ok[s] ? gy * W + gx : 0;
+        }
+#pragma unroll
+        for (int c = 0; c < kCIB; ++c) {
+            const int ci = min(ci0 + c, a.cin - 1);
+            const float* src = a.x + (size_t)(n * a.x_ctot + a.x_coff + ci) * HW;
+#pragma unroll
+            for (int s = 0; s < ASLOTS; ++s) sa[c][s] = src[aoff[s]];
+        }
+        const int gy = y0 + dr, gx = x0 + dc;
+        d_ok = gy < H && gx < W;
+        const int doff = d_ok ? gy * W + gx : 0;
+#pragma unroll
+        for (int c = 0; c < kCOB; ++c) {
+            const int co = min(co0 + c, a.cout - 1);
+            sd[c] = a.dy[(size_t)(n * a.dy_ctot + a.dy_coff + co) * HW + doff];
+        }
+    };
+
+    if ((int)blockIdx.x < total_tiles) prefetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < total_tiles; tile += a.P) {
         __syncthreads();
-        // ---- stage the activated input tile (zero outside the image / channel range)
-        for (int e = tid; e < kCIB * AH * AW; e += kThreads) {
-            const int c = e / (AH * AW);
-            const int rem = e - c * (AH * AW);
-            const int r = rem / AW, col = rem - r * AW;
-            const int gy = y0 - PAD + r, gx = x0 - PAD + col;
-            const int ci = ci0 + c;
-            float v = 0.f;
-            if (ci < a.cin && gy >= 0 && gy < H && gx >= 0 && gx < W) {
-                float sc = 1.f, sh = 0.f;
-                if (a.in_scale) {
-                    sc = a.in_scale[n * a.x_ctot + a.x_coff + ci];
-                    sh = a.in_shift[n * a.x_ctot + a.x_coff + ci];
-                }
-                v = san_act(a.x[(size_t)(n * a.x_ctot + a.x_coff + ci) * HW + (size_t)gy * W + gx], sc, sh, a.in_slope);
+        // ---- registers -> LDS with the lazy activation; zero outside the image / channel range
+#pragma unroll
+        for (int c = 0; c < kCIB; ++c) {
+            const bool ch_ok = (ci0 + c) < a.cin;
+            float sc = 1.f, sh = 0.f;
+            if (a.in_scale) {
+                sc = a.in_scale[tn * a.x_ctot + a.x_coff + min(ci0 + c, a.cin - 1)];
+                sh = a.in_shift[tn * a.x_ctot + a.x_coff + min(ci0 + c, a.cin - 1)];
             }
-            aT[c][r][col] = v;
+#pragma unroll
+            for (int s = 0; s < ASLOTS; ++s)
+                if (a_in[s]) aT[c][ar[s]][ac[s]] = (ch_ok && a_ok[s]) ? san_act(sa[c][s], sc, sh, a.in_slope) : 0.f;
         }
-        for (int e = tid; e < kCOB * kTH * kTW; e += kThreads) {
-            const int c = e / (kTH * kTW);
-            const int rem = e - c * (kTH * kTW);
-            const int r = rem / kTW, col = rem - r * kTW;
-            const int gy = y0 + r, gx = x0 + col;
-            const int co = co0 + c;
-            float v = 0.f;
-            if (co < a.cout && gy < H && gx < W)
-                v = a.dy[(size_t)(n * a.dy_ctot + a.dy_coff + co) * HW + (size_t)gy * W + gx];
-            dT[c][r][col] = v;
-        }
+#pragma unroll
+        for (int c = 0; c < kCOB; ++c) dT[c][dr][dc] = (d_ok && (co0 + c) < a.cout) ? sd[c] : 0.f;
         __syncthreads();
+        if (tile + a.P < total_tiles) prefetch(tile + a.P);     // next tile's loads fly during the MFMAs
         // ---- 16 pixel groups (4 rows x 4 x-groups of 16): block b of the MFMA = pixel b of the group
 #pragma unroll 1
         for (int r = 0; r < kTH; ++r)
