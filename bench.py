@@ -82,9 +82,10 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(num_cascades, h, w, budget_s=15.0):
+def cpu_baseline(num_cascades, h, w, mode="infer", budget_s=15.0):
     """The oracle on host cores: same arithmetic as the reference's CPU path
-    (same ATen kernels), N=1 slices one at a time until ~budget_s is spent."""
+    (same ATen kernels), N=1 slices one at a time until ~budget_s is spent.
+    mode 'train' times forward + autograd backward of the 'Rec' objective (no optimiser step)."""
     from oracle import cpu_ref as O
     from spatialalignmentnetwork_amd import synth
     from spatialalignmentnetwork_amd.cross import SpatialTransformer
@@ -96,10 +97,21 @@ def cpu_baseline(num_cascades, h, w, budget_s=15.0):
     pT, pR = synth.fill_params(t_shapes, seed=1), synth.fill_params(r_shapes, seed=2)
     img_full, img_aux = synth.phantom_pair(1, 1, h, w, seed=1234)
     pruned = synth.equispaced_pruned(w, 0.25, 0)
-    run = lambda: O.recon_align_forward(pT, pR, img_full, img_aux, pruned, shape=w, sparsity=0.25,
-                                        num_cascades=num_cascades)
+    train = mode == "train"
+    if train:
+        for d in (pT, pR):
+            for k, v in d.items():
+                if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                    v.requires_grad_(True)
+
+    def run():
+        o = O.recon_align_forward(pT, pR, img_full, img_aux, pruned, shape=w, sparsity=0.25,
+                                  num_cascades=num_cascades, training=train)
+        if train:
+            o["loss_all"].backward()
+
     warm = lambda: O.recon_align_forward(pT, pR, img_full, img_aux, pruned, shape=w, sparsity=0.25, num_cascades=1)
-    with torch.no_grad():
+    with torch.set_grad_enabled(train):
         warm()                      # warm-up on a 1-cascade pass (thread pools, oneDNN primitives)
         t0 = time.perf_counter()
         done = 0
@@ -109,8 +121,10 @@ def cpu_baseline(num_cascades, h, w, budget_s=15.0):
             if time.perf_counter() - t0 > budget_s or done >= 256:
                 break
         dt = time.perf_counter() - t0
+    what = "forward + autograd backward (no optimiser step)" if train else "forward"
     return {"value": done / dt, "unit": "slices/s", "cores": cores, "kind": "port",
-            "sample": f"{done} slice(s) of the same workload, one at a time (N=1), 1 warm-up, {dt:.1f} s of CPU work"}
+            "sample": f"{done} slice(s) of the same workload ({what}), one at a time (N=1), 1 warm-up, "
+                      f"{dt:.1f} s of CPU work"}
 
 
 def main():
@@ -121,7 +135,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="slices per GPU")
     ap.add_argument("--size", type=int, default=320)
     ap.add_argument("--cascades", type=int, default=12)
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer")
+    ap.add_argument("--mode", choices=["infer", "train"], default="train",
+                    help="train (default): the full optimisation step incl. the gradient all-reduce; infer: forward only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -187,6 +202,21 @@ def main():
     ops.TIMER = None
     dt = sdist.max_over_ranks(dt, dist, dev)
 
+    infer = None
+    if args.mode == "train":
+        # the forward-only (serving) rate of the same model, timed right after, reported alongside
+        net.eval()
+        for _ in range(2):
+            one_step(net, img_full, img_aux)
+        torch.cuda.synchronize()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(net, img_full, img_aux)
+        torch.cuda.synchronize()
+        barrier()
+        dti = sdist.max_over_ranks(time.perf_counter() - t1, dist, dev)
+        infer = {"value": n * world * args.steps / dti, "unit": "slices/s", "ms_per_step": 1e3 * dti / args.steps}
     if rank == 0:
         total_slices = n * world * args.steps
         out = {
@@ -199,6 +229,8 @@ def main():
                        "parallelism": f"dp{world} (independent slice shards, no data-path collective)",
                        "scalar_backend": sdist.BACKEND},
         }
+        if infer is not None:
+            out["inference"] = infer
         if timer is not None:
             tot = timer.totals()
             dom = max(tot, key=lambda k: tot[k]["ms"])
@@ -217,7 +249,7 @@ def main():
                               "share_of_step": d["ms"] / (1e3 * dt)}
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cascades, h, w)
+            out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -115,5 +115,10 @@ class GradBucket:
         """Average the gradients over all ranks (sum, then divide by the world size)."""
         if dist is None:
             return
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        if self.flat.is_cuda and BACKEND == "gloo":      # RCCL unavailable: stage through the host
+            host = self.flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            self.flat.copy_(host)
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.div_(dist.get_world_size())

@@ -46,7 +46,7 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
-TIMED_KERNELS = ("conv3x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
+TIMED_KERNELS = ("conv3x3", "wgrad3x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
 
 
 def _timed(name, work, unit, fn):
@@ -447,9 +447,11 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert dy.c == cout and dx.c == cin
     wp = packed_weight_dgrad(weight)
-    lib().call("san_conv2d_fwd", _p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope),
-               _p(wp), _p(None), _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), _p(None), _p(None),
-               dy.n, dy.h, dy.w, ks, _stream())
+    args = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
+            _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), _p(None), _p(None), dy.n, dy.h, dy.w, ks, _stream())
+    # the data gradient runs on the forward conv kernel: same roofline class
+    _timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
+           lambda: lib().call("san_conv2d_fwd", *args))
 
 
 def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
@@ -458,9 +460,10 @@ def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, ar
     assert x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
     P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout)
     partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
-    lib().call("san_conv2d_wgrad", _p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope),
-               _p(dy.buf), dy.ctot, dy.coff, cout, _p(_chk(dw, name="dw")), int(accumulate), _p(partial),
-               x.n, x.h, x.w, ks, _stream())
+    args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff, cout,
+            _p(_chk(dw, name="dw")), int(accumulate), _p(partial), x.n, x.h, x.w, ks, _stream())
+    _timed("wgrad3x3" if ks == 3 else "wgrad1x1", 2.0 * x.n * x.h * x.w * cout * cin * ks * ks, "FLOP",
+           lambda: lib().call("san_conv2d_wgrad", *args))
 
 
 def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA) -> None:
