@@ -139,13 +139,13 @@ int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin,
  * with packed_dgrad = san_conv_pack_weights_dgrad(w_forward) (flipped taps, swapped channel
  * axes; buffer of san_conv_packed_floats(cin, cout, ks) floats).
  * Weight gradient: dw [cout, cin, ks, ks] (+)= sum_{n,y,x} dy[n,co,y,x] * T(x)[n,ci,y+ky-p,x+kx-p];
- * partial: fp32 [san_conv_wgrad_partitions(n,h,w,cin,cout) * cout*cin*ks*ks] scratch.
+ * partial: fp32 [san_conv_wgrad_partitions(n,h,w,cin,cout,ks) * cout*cin*ks*ks] scratch.
  * san_act_bwd: gradient through the lazy (scale, shift, LeakyReLU) read of a raw tensor y:
  *   yh = sc*y + sh, u = g * (yh >= 0 ? 1 : slope);
  *   mode 0: dy = sc*u;  mode 1 (InstanceNorm): dy = sc*(u - mean(u) - yh*mean(u*yh)) per plane;
  *   part: fp32 [n, c, san_bwd_stat_tiles(hw), 2] scratch (mode 1). */
 int san_conv_pack_weights_dgrad(const float* w, float* packed, int cout, int cin, int ks, void* stream);
-int san_conv_wgrad_partitions(int n, int h, int w, int cin, int cout);
+int san_conv_wgrad_partitions(int n, int h, int w, int cin, int cout, int ks);
 int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin,
                      const float* in_scale, const float* in_shift, float in_slope,
                      const float* dy, int dy_ctot, int dy_coff, int cout,

@@ -9,6 +9,9 @@
 //   * InstanceNorm + LeakyReLU backward through the lazy-normalisation representation:
 //     bwd_stats (two plane reductions) + act_bwd (element-wise), see the formulas at the kernels.
 #include "san_common.h"
+#include <cstdint>
+#include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -16,9 +19,19 @@ constexpr int kThreads = 256;
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ wgrad
-constexpr int kCOB = 8;      // output channels per workgroup (2 quads, every wave)
-constexpr int kCIB = 16;     // input channels per workgroup (1 quad per wave)
-constexpr int kTW = 64, kTH = 4;   // pixel tile per iteration
+// dW[co][ci][tap] = sum over pixels of dy[co][p] * act(x)[ci][p + tap]: a GEMM whose reduction axis
+// is the PIXEL axis (819,200 long at 320x320 x 8) and whose output is tiny (18 x 18 x 9 at level 0).
+// One workgroup = 4 waves; wave w owns input-channel quad w of the block's (up to) 16 input channels
+// and ALL X output-channel quads of the block, i.e. X*TAPS accumulator quads, so each staged input
+// element feeds X MFMAs and each dy element feeds TAPS MFMAs.  A pixel tile of th x tw pixels
+// (th*tw <= 256, geometry chosen per layer on the host so that narrow images fill the 16-pixel
+// groups) is staged through LDS with the lazy activation applied; per group of 16 linearised
+// pixels a wave reads X + TAPS operands and issues X*TAPS 4x4x1 MFMAs (block b = pixel b).
+constexpr int kCIB = 16;       // input channels per workgroup (one quad per wave)
+__device__ __forceinline__ int san_cdiv_dev(int a, int b) { return (a + b - 1) / b; }
+constexpr int kVT = 512;       // threads of the pipelined kernel: 8 waves, 2 per SIMD
+constexpr int kDCS = 264;      // LDS channel stride of the dy tile (== 8 mod 32: the four channels x eight pixels
+                               // of a 32-lane ds_read_b32 group land on 32 different banks)
 
 struct WgradArgs {
     const float* x;          // forward input (raw) + its lazy affine
@@ -30,48 +43,60 @@ struct WgradArgs {
     int x_ctot, x_coff, cin;
     int dy_ctot, dy_coff, cout;
     int N, H, W;
+    int tw, th, aw, a_count, npx, groups;    // tile geometry: th x tw pixels, halo row pitch aw, 16-pixel groups
     int tiles_x, tiles_y, P;
+    int cib_q;               // input-channel quads per workgroup (<= 4; balanced over the z blocks)
+    unsigned long long* ts;  // DEBUG
 };
 
-template <int KS>
+struct WgradPlan {
+    int vec;                 // 16-byte staged, pipelined kernel (W % 4 == 0) or the generic scalar one
+    int tw, th, aw, a_count, npx, groups, tiles_x, tiles_y;
+    int X, co_blocks, cib_q, ci_blocks, P;
+};
+
+template <int KS, int X>
 __global__ void __launch_bounds__(kThreads) conv_wgrad_kernel(const WgradArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int TAPS = KS * KS;
-    constexpr int AW = kTW + 2 * PAD, AH = kTH + 2 * PAD;
-    constexpr int AP = AW + 1, DP = kTW + 1;         // LDS pitches
-    constexpr int ASLOTS = (AH * AW + kThreads - 1) / kThreads;   // 2 (3x3) or 1 (1x1) staged elements per channel
-    __shared__ float aT[kCIB][AH][AP];
-    __shared__ float dT[kCOB][kTH][DP];
+    constexpr int ACS = KS == 3 ? 456 : 264;         // LDS channel stride of the input tile (== 8 mod 32)
+    constexpr int ASLOTS = KS == 3 ? 2 : 1;          // staged input elements per thread per channel
+    constexpr int CO = 4 * X;
+    __shared__ float aT[kCIB * ACS];
+    __shared__ float dT[CO * kDCS];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int b = lane >> 2, q = lane & 3;
-    const int co0 = blockIdx.y * kCOB;
-    const int ci0 = blockIdx.z * kCIB;
+    const int co0 = blockIdx.y * CO;
+    const int ci0 = blockIdx.z * a.cib_q * 4;
+    const int nstage = min(4 * a.cib_q, kCIB);       // channels this block stages (multiple of 4)
+    const bool wave_on = wave < a.cib_q && ci0 + 4 * wave < a.cin;
     const int H = a.H, W = a.W;
     const size_t HW = (size_t)H * W;
 
-    f4 acc[2][TAPS];
+    f4 acc[X][TAPS];
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < X; ++c)
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) acc[c][t] = f4{0.f, 0.f, 0.f, 0.f};
 
-    // per-thread staging slots (tile-relative, computed once): input halo tile and dy tile
+    // per-thread staging slots (tile-relative, computed once): element e of the dense halo tile
     int ar[ASLOTS], ac[ASLOTS];
     bool a_in[ASLOTS];
 #pragma unroll
     for (int s = 0; s < ASLOTS; ++s) {
         const int e = tid + s * kThreads;
-        a_in[s] = e < AH * AW;
-        ar[s] = a_in[s] ? e / AW : 0;
-        ac[s] = a_in[s] ? e - ar[s] * AW : 0;
+        a_in[s] = e < a.a_count;
+        ar[s] = a_in[s] ? e / a.aw : 0;
+        ac[s] = a_in[s] ? e - ar[s] * a.aw : 0;
     }
-    const int dr = tid / kTW, dc = tid - dr * kTW;     // 256 threads == kTH * kTW dy elements per channel
+    const bool d_in = tid < a.npx;
+    const int dr = d_in ? tid / a.tw : 0, dc = d_in ? tid - dr * a.tw : 0;
 
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int total_tiles = tiles_per_img * a.N;
-    float sa[kCIB][ASLOTS], sd[kCOB];
+    float sa[kCIB][ASLOTS], sd[CO];
     bool a_ok[ASLOTS];
     bool d_ok = false;
     int tn = 0;
@@ -80,7 +105,7 @@ __global__ void __launch_bounds__(kThreads) conv_wgrad_kernel(const WgradArgs a)
         const int n = tile / tiles_per_img;
         const int tr = tile - n * tiles_per_img;
         const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
-        const int x0 = tx * kTW, y0 = ty * kTH;
+        const int x0 = tx * a.tw, y0 = ty * a.th;
         tn = n;
         int aoff[ASLOTS];
 #pragma unroll
@@ -90,89 +115,400 @@ __global__ void __launch_bounds__(kThreads) conv_wgrad_kernel(const WgradArgs a)
             aoff[s] = a_ok[s] ? gy * W + gx : 0;
         }
 #pragma unroll
-        for (int c = 0; c < kCIB; ++c) {
-            const int ci = min(ci0 + c, a.cin - 1);
-            const float* src = a.x + (size_t)(n * a.x_ctot + a.x_coff + ci) * HW;
+        for (int c = 0; c < kCIB; ++c)
+            if (c < nstage) {
+                const int ci = min(ci0 + c, a.cin - 1);
+                const float* src = a.x + (size_t)(n * a.x_ctot + a.x_coff + ci) * HW;
 #pragma unroll
-            for (int s = 0; s < ASLOTS; ++s) sa[c][s] = src[aoff[s]];
-        }
+                for (int s = 0; s < ASLOTS; ++s) sa[c][s] = src[aoff[s]];
+            }
         const int gy = y0 + dr, gx = x0 + dc;
-        d_ok = gy < H && gx < W;
+        d_ok = d_in && gy < H && gx < W;
         const int doff = d_ok ? gy * W + gx : 0;
 #pragma unroll
-        for (int c = 0; c < kCOB; ++c) {
+        for (int c = 0; c < CO; ++c) {
             const int co = min(co0 + c, a.cout - 1);
             sd[c] = a.dy[(size_t)(n * a.dy_ctot + a.dy_coff + co) * HW + doff];
         }
     };
 
+    const float* ab = aT + (4 * wave + q) * ACS;
+    const float* db = dT + q * kDCS + b;
     if ((int)blockIdx.x < total_tiles) prefetch(blockIdx.x);
     for (int tile = blockIdx.x; tile < total_tiles; tile += a.P) {
         __syncthreads();
         // ---- registers -> LDS with the lazy activation; zero outside the image / channel range
 #pragma unroll
-        for (int c = 0; c < kCIB; ++c) {
-            const bool ch_ok = (ci0 + c) < a.cin;
-            float sc = 1.f, sh = 0.f;
-            if (a.in_scale) {
-                sc = a.in_scale[tn * a.x_ctot + a.x_coff + min(ci0 + c, a.cin - 1)];
-                sh = a.in_shift[tn * a.x_ctot + a.x_coff + min(ci0 + c, a.cin - 1)];
+        for (int c = 0; c < kCIB; ++c)
+            if (c < nstage) {
+                const bool ch_ok = (ci0 + c) < a.cin;
+                float sc = 1.f, sh = 0.f;
+                if (a.in_scale) {
+                    sc = a.in_scale[tn * a.x_ctot + a.x_coff + min(ci0 + c, a.cin - 1)];
+                    sh = a.in_shift[tn * a.x_ctot + a.x_coff + min(ci0 + c, a.cin - 1)];
+                }
+#pragma unroll
+                for (int s = 0; s < ASLOTS; ++s)
+                    if (a_in[s])
+                        aT[c * ACS + tid + s * kThreads] = (ch_ok && a_ok[s]) ? san_act(sa[c][s], sc, sh, a.in_slope) : 0.f;
             }
 #pragma unroll
-            for (int s = 0; s < ASLOTS; ++s)
-                if (a_in[s]) aT[c][ar[s]][ac[s]] = (ch_ok && a_ok[s]) ? san_act(sa[c][s], sc, sh, a.in_slope) : 0.f;
-        }
-#pragma unroll
-        for (int c = 0; c < kCOB; ++c) dT[c][dr][dc] = (d_ok && (co0 + c) < a.cout) ? sd[c] : 0.f;
+        for (int c = 0; c < CO; ++c) dT[c * kDCS + tid] = (d_ok && (co0 + c) < a.cout) ? sd[c] : 0.f;
         __syncthreads();
         if (tile + a.P < total_tiles) prefetch(tile + a.P);     // next tile's loads fly during the MFMAs
-        // ---- 16 pixel groups (4 rows x 4 x-groups of 16): block b of the MFMA = pixel b of the group
-#pragma unroll 1
-        for (int r = 0; r < kTH; ++r)
-#pragma unroll 1
-            for (int xg = 0; xg < kTW / 16; ++xg) {
-                const int px = xg * 16 + b;
-                const float a0 = dT[q][r][px], a1 = dT[4 + q][r][px];
+        if (wave_on) {
+            // ---- groups of 16 linearised tile pixels: block b of the MFMA = pixel 16 g + b.  Operands of
+            // group g+1 are read from LDS before the X*TAPS MFMAs of group g are issued.
+            float dcur[X], bcur[TAPS];
+            // lane's pixel of group g: LDS offset off = y*aw + x of the halo tile, advanced incrementally
+            const int p0 = min(b, a.npx - 1);
+            int px = p0 % a.tw;
+            int off = (p0 / a.tw) * a.aw + px;
+            const int off_last = (a.th - 1) * a.aw + a.tw - 1;     // pad pixels of the last group: dy is 0 there
+            auto load_group = [&](int g, int o, float (&dq)[X], float (&bq)[TAPS]) {
+                const float* ap = ab + o;
+#pragma unroll
+                for (int c = 0; c < X; ++c) dq[c] = db[4 * c * kDCS + 16 * g];
 #pragma unroll
                 for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
-                    for (int kx = 0; kx < KS; ++kx) {
-                        const float bv = aT[4 * wave + q][r + ky][px + kx];
-                        acc[0][ky * KS + kx] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, bv, acc[0][ky * KS + kx], 0, 0, 0);
-                        acc[1][ky * KS + kx] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, bv, acc[1][ky * KS + kx], 0, 0, 0);
+                    for (int kx = 0; kx < KS; ++kx) bq[ky * KS + kx] = ap[ky * a.aw + kx];
+            };
+            float dalt[X], balt[TAPS];
+            constexpr int NLD = X + TAPS;
+            constexpr int MPL = (X * TAPS) / NLD > 0 ? (X * TAPS) / NLD : 1;
+            const int wrap = a.aw - a.tw;
+            auto advance = [&]() {
+                px += 16;
+                off += 16;
+                if (a.tw >= 16) {
+                    const bool w = px >= a.tw;
+                    px -= w ? a.tw : 0;
+                    off += w ? wrap : 0;
+                } else {
+                    while (px >= a.tw) {
+                        px -= a.tw;
+                        off += wrap;
                     }
-            }
-    }
-    // ---- sum the 16 blocks: lanes 4b + j, b = 0..15, hold partial D[i][j]
+                }
+            };
+            // one half step: LDS reads of group g+1 interleaved under the X*TAPS MFMAs of group g
+            auto half = [&](int g, float (&dq)[X], float (&bq)[TAPS], float (&dn)[X], float (&bn)[TAPS]) {
+                advance();
+                load_group(min(g + 1, a.groups - 1), min(off, off_last), dn, bn);
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int c = 0; c < X; ++c)
+                        acc[c][t] = __builtin_amdgcn_mfma_f32_4x4x1f32(dq[c], bq[t], acc[c][t], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NLD; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MPL, 0);
+                }
+            };
+            load_group(0, off, dcur, bcur);
+#pragma unroll 1
+            for (int g = 0; g < a.groups; g += 2) {
+                half(g, dcur, bcur, dalt, balt);
+                if (g + 1 < a.groups) half(g + 1, dalt, balt, dcur, bcur);
+            }
+        }
+    }
+    if (!wave_on) return;
+    // ---- sum the 16 blocks: lanes 4b + j, b = 0..15, hold partial D[i][j].  Rotations by 4 and 8 lanes
+    // inside each row of 16 (DPP), then the four rows through the crossbar.
+    const int ci = ci0 + 4 * wave + q;          // lane (b = 0, j = q) owns column ci
+#pragma unroll
+    for (int c = 0; c < X; ++c)
 #pragma unroll
         for (int t = 0; t < TAPS; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v = acc[c][t][i];
-                v += __shfl_xor(v, 4, 64);
-                v += __shfl_xor(v, 8, 64);
+                v += san_dpp_get<0x124, 0xf>(v);    // row_ror:4
+                v += san_dpp_get<0x128, 0xf>(v);    // row_ror:8
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
                 acc[c][t][i] = v;
             }
-    if (b == 0) {
-        const int ci = ci0 + 4 * wave + q;          // lane (0, j = q)
-        if (ci < a.cin) {
+    if (b == 0 && ci < a.cin) {
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < X; ++c)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int co = co0 + 4 * c + i;
-                    if (co < a.cout) {
-                        float* o = a.partial + (((size_t)blockIdx.x * a.cout + co) * a.cin + ci) * TAPS;
+            for (int i = 0; i < 4; ++i) {
+                const int co = co0 + 4 * c + i;
+                if (co < a.cout) {
+                    float* o = a.partial + (((size_t)blockIdx.x * a.cout + co) * a.cin + ci) * TAPS;
 #pragma unroll
-                        for (int t = 0; t < TAPS; ++t) o[t] = acc[c][t][i];
-                    }
+                    for (int t = 0; t < TAPS; ++t) o[t] = acc[c][t][i];
                 }
-        }
+            }
     }
+}
+
+// Same arithmetic for the layers that matter (W % 4 == 0: every VarNet / alignment layer), built
+// around one measured fact: a wave issues MFMA, VALU, LDS and memory instructions strictly one
+// after the other (scratch/probe/mfma_mix.hip: 8.7 cycles per 4x4x1 MFMA alone, 17.5 with 14 LDS
+// reads + 30 VALU per 45 MFMAs), so the staging work only overlaps the matrix work when ANOTHER
+// wave on the same SIMD supplies it.  Hence 8 waves = 2 per SIMD: wave w owns input-channel quad
+// w & 3 and output-channel part w >> 2 (X quads), so the two waves of a SIMD share the input
+// operand rows and split the output channels.  Staging uses 16-byte accesses and is software
+// pipelined: LDS is double buffered; while the MFMAs of tile t run out of buffer t&1, staging
+// chunk k runs next to pixel group 2k: it writes the register-held float4 of tile t+1
+// (activation applied) into the other buffer and issues the global load of tile t+2 into the
+// same registers.  One barrier per tile; global latency has a whole tile of matrix work to hide
+// under.  The halo tile starts 4 columns left of the pixel tile so every row is 16-byte aligned.
+template <int KS, int X>
+__global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) {
+    constexpr int PAD = KS / 2;
+    constexpr int XO = KS == 3 ? 4 : 0;              // halo columns left of the tile (aligned)
+    constexpr int TAPS = KS * KS;
+    constexpr int ACS = KS == 3 ? 456 : 264;
+    constexpr int NA = KS == 3 ? 4 : 2;              // float4 slots per thread, input tile (16 ch x <= 114 / 64)
+    constexpr int ND = X;                            // float4 slots per thread, dy tile (8X ch x <= 64)
+    constexpr int CO = 8 * X;                        // output channels per workgroup (two parts of X quads)
+    constexpr int BUF = kCIB * ACS + CO * kDCS;      // floats per LDS buffer
+    constexpr int MAXG = 16;
+    static_assert(NA + ND <= MAXG, "one staging chunk per pixel group");
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ciq = wave & 3, cop = wave >> 2;       // waves w and w+4 share a SIMD: same input quad, other co part
+    const int lane = tid & 63;
+    const int b = lane >> 2, q = lane & 3;
+    const int co0 = blockIdx.y * CO;
+    const int ci0 = blockIdx.z * a.cib_q * 4;
+    const int nstage = min(4 * a.cib_q, kCIB);
+    // this wave's share of the block's output-channel quads: the two parts split them evenly
+    const int qblk = min(2 * X, san_cdiv_dev(a.cout, 4) - 2 * X * (int)blockIdx.y);
+    const int qfirst = cop ? (qblk + 1) / 2 : 0;
+    const bool ci_on = ciq < a.cib_q && ci0 + 4 * ciq < a.cin;
+    const int nq = ci_on ? (cop ? qblk - qfirst : (qblk + 1) / 2) : 0;     // 0: this wave only stages
+    const int H = a.H, W = a.W;
+    const int HW = H * W;
+    int tsi = 0;
+    const bool tson = a.ts && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
+#define TS() do { if (tson && tsi < 250) a.ts[tsi++] = __builtin_amdgcn_s_memtime(); } while (0)
+    TS();
+
+    for (int i = tid; i < 2 * BUF + 4 * kVT; i += kVT) lds[i] = 0.f;     // pad pixels stay finite
+
+    // ---- tile-invariant staging slots.  Every slot loads and stores unconditionally (branch-free
+    // chunks keep the staging code inside the MFMA basic blocks): slots past the staged range
+    // store into a per-thread trash line, channels past cin / cout store zeros in place.
+    const int aw4 = a.aw >> 2, nv4 = a.a_count >> 2, tw4 = a.tw >> 2, nd4 = a.npx >> 2;
+    int a_lds[NA], a_rel[NA], a_rc[NA], a_ch[NA];
+    bool a_valid[NA];
+#pragma unroll
+    for (int s = 0; s < NA; ++s) {
+        const int e = tid + s * kVT;
+        const int c = e / nv4;
+        const int v = e - c * nv4;
+        const int row = v / aw4, col = 4 * (v - row * aw4);
+        a_valid[s] = c < nstage && ci0 + c < a.cin;
+        a_ch[s] = min(ci0 + c, a.cin - 1) - ci0;
+        a_lds[s] = c < kCIB ? c * ACS + 4 * v : 2 * BUF + 4 * tid;
+        a_rel[s] = a_ch[s] * HW + row * W + col;
+        a_rc[s] = row | (col << 16);
+    }
+    int d_lds[ND], d_rel[ND], d_rc[ND];
+    bool d_valid[ND];
+#pragma unroll
+    for (int s = 0; s < ND; ++s) {
+        const int e = tid + s * kVT;
+        const int c = e / nd4;
+        const int v = e - c * nd4;
+        const int row = v / tw4, col = 4 * (v - row * tw4);
+        d_valid[s] = c < CO && co0 + c < a.cout;
+        d_lds[s] = c < CO ? kCIB * ACS + c * kDCS + 4 * v : 2 * BUF + 4 * tid;
+        d_rel[s] = (min(co0 + c, a.cout - 1) - co0) * HW + row * W + col;
+        d_rc[s] = row | (col << 16);
+    }
+
+    // ---- this workgroup's contiguous run of tiles
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int total_tiles = tiles_per_img * a.N;
+    const int t0 = (int)(((long long)blockIdx.x * total_tiles) / a.P);
+    const int t1 = (int)(((long long)(blockIdx.x + 1) * total_tiles) / a.P);
+
+    f4 sa[NA], sd[ND];
+    float ssc[NA], ssh[NA];
+    bool a_ok[NA], d_ok[ND];
+    const bool has_aff = a.in_scale != nullptr;
+    const float* scp = has_aff ? a.in_scale : a.x;
+    const float* shp = has_aff ? a.in_shift : a.x;
+    // tile coordinates of the tile being loaded (wave-uniform)
+    int ln = 0, ly0 = 0, lx0 = 0;
+    auto set_tile = [&](int tile) {
+        const int n = tile / tiles_per_img;
+        const int tr = tile - n * tiles_per_img;
+        const int ty = tr / a.tiles_x, tx = tr - ty * a.tiles_x;
+        ln = n;
+        ly0 = ty * a.th;
+        lx0 = tx * a.tw;
+    };
+    auto load_a = [&](int s) {
+        const int row = a_rc[s] & 0xffff, col = a_rc[s] >> 16;
+        const int gy = ly0 - PAD + row, gx = lx0 - XO + col;
+        a_ok[s] = a_valid[s] & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+        const float* base = a.x + (size_t)(ln * a.x_ctot + a.x_coff + ci0) * HW;
+        const int off = a_ok[s] ? a_rel[s] + (ly0 - PAD) * W + lx0 - XO : 0;
+        sa[s] = *reinterpret_cast<const f4*>(base + off);
+        const int k = has_aff ? ln * a.x_ctot + a.x_coff + ci0 + a_ch[s] : 0;
+        const float lsc = scp[k], lsh = shp[k];
+        // out-of-image / out-of-range elements become act(0*x + 0) = 0: no select at store time
+        ssc[s] = a_ok[s] ? (has_aff ? lsc : 1.f) : 0.f;
+        ssh[s] = a_ok[s] ? (has_aff ? lsh : 0.f) : 0.f;
+    };
+    auto load_d = [&](int s) {
+        const int row = d_rc[s] & 0xffff, col = d_rc[s] >> 16;
+        const int gy = ly0 + row, gx = lx0 + col;
+        d_ok[s] = d_valid[s] & (gy < H) & (gx < W);
+        const float* base = a.dy + (size_t)(ln * a.dy_ctot + a.dy_coff + co0) * HW;
+        const int off = d_ok[s] ? d_rel[s] + ly0 * W + lx0 : 0;
+        sd[s] = *reinterpret_cast<const f4*>(base + off);
+    };
+    auto write_a = [&](int s, float* buf0, int bufoff) {
+        f4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = fmaf(sa[s][i], ssc[s], ssh[s]);
+            r[i] = fmaxf(v, v * a.in_slope);            // LeakyReLU for 0 <= slope <= 1 (host-checked)
+        }
+        *reinterpret_cast<f4*>(buf0 + (a_lds[s] < 2 * BUF ? a_lds[s] + bufoff : a_lds[s])) = r;
+    };
+    auto write_d = [&](int s, float* buf0, int bufoff) {
+        const f4 r = d_ok[s] ? sd[s] : f4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f4*>(buf0 + (d_lds[s] < 2 * BUF ? d_lds[s] + bufoff : d_lds[s])) = r;
+    };
+    // staging chunk g: NA input slots first, then ND dy slots; store the held tile, fetch the next
+    auto chunk = [&](int g, int bufoff) {
+        if (g < NA) {
+            write_a(g, lds, bufoff);
+            load_a(g);
+        } else if (g < NA + ND) {
+            write_d(g - NA, lds, bufoff);
+            load_d(g - NA);
+        }
+    };
+
+    // ---- prologue: tile t0 -> buffer 0, tile t0+1 -> registers
+    set_tile(t0);
+#pragma unroll
+    for (int s = 0; s < NA; ++s) load_a(s);
+#pragma unroll
+    for (int s = 0; s < ND; ++s) load_d(s);
+    __syncthreads();                                   // zero fill done before the first writes
+    set_tile(min(t0 + 1, t1 - 1));
+#pragma unroll
+    for (int g = 0; g < NA + ND; ++g) chunk(g, 0);
+    __syncthreads();
+    TS();
+
+    // ---- main loop.  The pixel tile is 16 x 16: group g = tile row g, MFMA block b = column b, so
+    // consecutive groups slide the 3-row input window down by one row: only the new row (KS
+    // operands) and the XE dy operands are read from LDS per group, all at immediate offsets; the
+    // 16 groups are one straight-line block.  XE = the wave's own number of output-channel quads
+    // (0..X, wave-uniform): a wave never issues MFMAs for quads it does not own, because they
+    // would come straight out of its SIMD partner's matrix-pipe time.
+    constexpr int AW = 16 + 2 * XO;
+    auto run = [&](auto xe_tag) {
+        constexpr int XE = decltype(xe_tag)::value;
+        constexpr int XR = XE > 0 ? XE : 1;
+        f4 acc[XR][TAPS];
+#pragma unroll
+        for (int c = 0; c < XR; ++c)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) acc[c][t] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int tile = t0; tile < t1; ++tile) {
+            const float* cur = lds + ((tile - t0) & 1) * BUF;
+            const int nxt = (((tile - t0) & 1) ^ 1) * BUF;       // the held tile (tile+1) goes to the other buffer
+            set_tile(min(tile + 2, t1 - 1));                     // past the run: a redundant reload, never consumed
+            if constexpr (XE == 0) {
+#pragma unroll
+                for (int k = 0; k < NA + ND; ++k) chunk(k, nxt);
+            } else {
+                const float* ab = cur + (4 * ciq + q) * ACS + b + XO - PAD;
+                const float* db = cur + kCIB * ACS + (4 * qfirst + q) * kDCS + b;
+                float bw[KS][KS];              // input window row r lives in bw[r % KS]
+                float dq[2][XE];
+#pragma unroll
+                for (int ky = 0; ky < KS - 1; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) bw[ky][kx] = ab[ky * AW + kx];
+#pragma unroll
+                for (int c = 0; c < XE; ++c) dq[0][c] = db[4 * c * kDCS];
+#pragma unroll
+                for (int g = 0; g < MAXG; ++g) {
+                    if (g < a.th) {                     // tile rows (wave-uniform)
+                        // operands of this group's last window row, and the next group's dy
+#pragma unroll
+                        for (int kx = 0; kx < KS; ++kx) bw[(g + KS - 1) % KS][kx] = ab[(g + KS - 1) * AW + kx];
+                        if (g + 1 < MAXG) {
+#pragma unroll
+                            for (int c = 0; c < XE; ++c) dq[(g + 1) & 1][c] = db[4 * c * kDCS + 16 * (g + 1)];
+                        }
+#pragma unroll
+                        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                                for (int c = 0; c < XE; ++c)
+                                    acc[c][ky * KS + kx] = __builtin_amdgcn_mfma_f32_4x4x1f32(
+                                        dq[g & 1][c], bw[(g + ky) % KS][kx], acc[c][ky * KS + kx], 0, 0, 0);
+                    }
+                    if (g < NA + ND) chunk(g, nxt);
+                }
+            }
+            TS();
+            __syncthreads();
+            TS();
+        }
+        if constexpr (XE > 0) {
+            // sum the 16 blocks: lanes 4b + j hold D_b[i][j]; rotations inside each row of 16, then the four rows
+            const int ci = ci0 + 4 * ciq + q;
+#pragma unroll
+            for (int c = 0; c < XE; ++c)
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v = acc[c][t][i];
+                        v += san_dpp_get<0x124, 0xf>(v);    // row_ror:4
+                        v += san_dpp_get<0x128, 0xf>(v);    // row_ror:8
+                        v += __shfl_xor(v, 16, 64);
+                        v += __shfl_xor(v, 32, 64);
+                        acc[c][t][i] = v;
+                    }
+            if (b == 0 && ci < a.cin) {
+#pragma unroll
+                for (int c = 0; c < XE; ++c)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = co0 + 4 * (qfirst + c) + i;
+                        if (co < a.cout) {
+                            float* o = a.partial + (((size_t)blockIdx.x * a.cout + co) * a.cin + ci) * TAPS;
+#pragma unroll
+                            for (int t = 0; t < TAPS; ++t) o[t] = acc[c][t][i];
+                        }
+                    }
+            }
+        }
+    };
+    if (nq <= 0) {
+        run(std::integral_constant<int, 0>{});
+    } else if (nq == 1) {
+        run(std::integral_constant<int, 1>{});
+    } else if (nq == 2) {
+        if constexpr (X >= 2) run(std::integral_constant<int, 2>{});
+    } else if (nq == 3) {
+        if constexpr (X >= 3) run(std::integral_constant<int, 3>{});
+    } else {
+        if constexpr (X >= 4) run(std::integral_constant<int, 4>{});
+    }
+    TS();
+#undef TS
 }
 
 // dW[i] (+)= sum_p partial[p][i], fixed order
@@ -185,14 +521,65 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __
     }
 }
 
-int wgrad_partitions(int n, int h, int w, int cin, int cout) {
-    const int tiles = san_cdiv(w, kTW) * san_cdiv(h, kTH) * n;
-    const int blocks = san_cdiv(cout, kCOB) * san_cdiv(cin, kCIB);
-    int P = san_cdiv(1024, blocks);
+// Tile geometry, channel blocking and pixel partitions of one weight-gradient launch.
+WgradPlan wgrad_plan(int n, int h, int w, int cin, int cout, int ks, bool allow_vec) {
+    WgradPlan p{};
+    const int pad = ks / 2;
+    const int amax = ks == 3 ? 456 : 256;
+    p.vec = allow_vec && (w % 4 == 0);
+    const int xpad = p.vec ? (ks == 3 ? 4 : 0) : pad;      // the vector kernel's halo is 4 columns wide (alignment)
+    if (p.vec) {                                           // 16 columns x up to 16 rows, rows balanced over the image
+        p.tw = 16;
+        p.th = san_cdiv(h, san_cdiv(h, 16));
+    }
+    // pixel tile: minimise  tiles * (groups + staging cost in group units)
+    long best = -1;
+    for (int k = 1; k <= w && !p.vec; ++k) {
+        const int tw = san_cdiv(w, k);
+        if (tw > 256) continue;
+        for (int th = 1; th <= h && th * tw <= 256; ++th) {
+            if ((th + 2 * pad) * (tw + 2 * xpad) > amax) break;
+            const int groups = san_cdiv(th * tw, 16);
+            const long cost = (long)san_cdiv(w, tw) * san_cdiv(h, th) * (groups + 4);
+            if (best < 0 || cost < best) {
+                best = cost;
+                p.tw = tw;
+                p.th = th;
+            }
+        }
+    }
+    p.aw = p.tw + 2 * xpad;
+    p.a_count = (p.th + 2 * pad) * p.aw;
+    p.npx = p.th * p.tw;
+    p.groups = san_cdiv(p.npx, 16);
+    p.tiles_x = san_cdiv(w, p.tw);
+    p.tiles_y = san_cdiv(h, p.th);
+    // output-channel quads per wave: fewest (blocks * (X + fixed per-group cost)).  The pipelined
+    // kernel covers 2X quads per workgroup (two co parts) under a 256-register budget: X <= 4.
+    const int qco = san_cdiv(cout, 4);
+    static const int xs_scalar[4] = {2, 3, 5, 6}, xs_vec[4] = {1, 2, 3, 4};
+    const int* xs = p.vec ? xs_vec : xs_scalar;
+    const int nx = p.vec && ks == 3 ? 3 : 4;         // 3x3: X = 4 would spill (36 accumulator quads + staging)
+    const int span = p.vec ? 2 : 1;
+    float bx = 0.f;
+    for (int i = 0; i < nx; ++i) {
+        const float c = san_cdiv(qco, span * xs[i]) * (xs[i] + (p.vec ? 0.75f : 1.5f));
+        if (p.X == 0 || c < bx) {
+            bx = c;
+            p.X = xs[i];
+        }
+    }
+    p.co_blocks = san_cdiv(qco, span * p.X);
+    const int qci = san_cdiv(cin, 4);
+    p.ci_blocks = san_cdiv(qci, 4);
+    p.cib_q = san_cdiv(qci, p.ci_blocks);
+    const int tiles = p.tiles_x * p.tiles_y * n;
+    int P = p.vec ? 256 / (p.co_blocks * p.ci_blocks) : san_cdiv(768, p.co_blocks * p.ci_blocks);   // vec: 1 WG per CU (LDS)
     if (P > tiles) P = tiles;
     if (P > 256) P = 256;
     if (P < 1) P = 1;
-    return P;
+    p.P = P;
+    return p;
 }
 
 // ------------------------------------------------- norm + activation backward
@@ -497,11 +884,33 @@ gradient_loss_bwd_kernel(const float* __restrict__ off, float* __restrict__ g, i
     }
 }
 
+template <int KS, int X>
+static int wgrad_vec_launch(dim3 grid, hipStream_t s, const WgradArgs& a) {
+    constexpr int ACS = KS == 3 ? 456 : 264;
+    constexpr size_t bytes = (2 * (size_t)(kCIB * ACS + 8 * X * kDCS) + 4 * kVT) * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_vec_kernel<KS, X>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+        {
+            san_set_error("cannot reserve %d bytes of LDS for the weight-gradient kernel", (int)bytes);
+            return SAN_E_UNSUPPORTED;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_vec_kernel<KS, X>), grid, dim3(kVT), bytes, s, a);
+    return SAN_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int san_conv_wgrad_partitions(int n, int h, int w, int cin, int cout) { return wgrad_partitions(n, h, w, cin, cout); }
+int san_conv_wgrad_partitions(int n, int h, int w, int cin, int cout, int ks) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || (ks != 1 && ks != 3)) return 0;
+    const int pv = wgrad_plan(n, h, w, cin, cout, ks, true).P, ps = wgrad_plan(n, h, w, cin, cout, ks, false).P;
+    return pv > ps ? pv : ps;
+}
 
 int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
                      float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
@@ -511,6 +920,9 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const floa
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && dy_coff >= 0 && dy_coff + cout <= dy_ctot, "bad channel view");
     SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
+    const bool aligned = (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
+    const bool lrelu01 = in_slope >= 0.f && in_slope <= 1.f;          // the pipelined kernel evaluates LeakyReLU as max(v, slope*v)
+    const WgradPlan p = wgrad_plan(n, h, w, cin, cout, ks, aligned && lrelu01 && !getenv("SAN_WGRAD_SCALAR"));
     WgradArgs a{};
     a.x = x;
     a.in_scale = in_scale;
@@ -527,20 +939,62 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const floa
     a.N = n;
     a.H = h;
     a.W = w;
-    a.tiles_x = san_cdiv(w, kTW);
-    a.tiles_y = san_cdiv(h, kTH);
-    a.P = wgrad_partitions(n, h, w, cin, cout);
-    dim3 grid(a.P, san_cdiv(cout, kCOB), san_cdiv(cin, kCIB));
+    a.tw = p.tw;
+    a.th = p.th;
+    a.aw = p.aw;
+    a.a_count = p.a_count;
+    a.npx = p.npx;
+    a.groups = p.groups;
+    a.tiles_x = p.tiles_x;
+    a.tiles_y = p.tiles_y;
+    a.P = p.P;
+    a.cib_q = p.cib_q;
+    if (const char* e = getenv("SAN_DBG_TS")) a.ts = (unsigned long long*)strtoull(e, nullptr, 10);
+    dim3 grid(p.P, p.co_blocks, p.ci_blocks);
     hipStream_t s = (hipStream_t)stream;
-    if (ks == 3)
-        hipLaunchKernelGGL((conv_wgrad_kernel<3>), grid, dim3(kThreads), 0, s, a);
-    else
-        hipLaunchKernelGGL((conv_wgrad_kernel<1>), grid, dim3(kThreads), 0, s, a);
+#define SAN_WGRAD_LAUNCH(KS, X) hipLaunchKernelGGL((conv_wgrad_kernel<KS, X>), grid, dim3(kThreads), 0, s, a)
+    if (p.vec) {
+#define SAN_WGRAD_VEC(KS, X)                                          \
+    do {                                                              \
+        const int rc = wgrad_vec_launch<KS, X>(grid, s, a);           \
+        if (rc != SAN_OK) return rc;                                  \
+    } while (0)
+        if (ks == 3) {
+            switch (p.X) {
+                case 1: SAN_WGRAD_VEC(3, 1); break;
+                case 2: SAN_WGRAD_VEC(3, 2); break;
+                default: SAN_WGRAD_VEC(3, 3); break;
+            }
+        } else {
+            switch (p.X) {
+                case 1: SAN_WGRAD_VEC(1, 1); break;
+                case 2: SAN_WGRAD_VEC(1, 2); break;
+                case 3: SAN_WGRAD_VEC(1, 3); break;
+                default: SAN_WGRAD_VEC(1, 4); break;
+            }
+        }
+#undef SAN_WGRAD_VEC
+    } else if (ks == 3) {
+        switch (p.X) {
+            case 2: SAN_WGRAD_LAUNCH(3, 2); break;
+            case 3: SAN_WGRAD_LAUNCH(3, 3); break;
+            case 5: SAN_WGRAD_LAUNCH(3, 5); break;
+            default: SAN_WGRAD_LAUNCH(3, 6); break;
+        }
+    } else {
+        switch (p.X) {
+            case 2: SAN_WGRAD_LAUNCH(1, 2); break;
+            case 3: SAN_WGRAD_LAUNCH(1, 3); break;
+            case 5: SAN_WGRAD_LAUNCH(1, 5); break;
+            default: SAN_WGRAD_LAUNCH(1, 6); break;
+        }
+    }
+#undef SAN_WGRAD_LAUNCH
     SAN_LAUNCH_CHECK();
     const int count = cout * cin * ks * ks;
     int blocks = san_cdiv(count, 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, count, a.P, accumulate);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, count, p.P, accumulate);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -458,7 +458,7 @@ def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, ar
     """dw [cout, cin, ks, ks] (+)= correlation of dy with the lazily activated forward input x."""
     cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
     assert x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
-    P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout)
+    P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout, ks)
     partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff, cout,
             _p(_chk(dw, name="dw")), int(accumulate), _p(partial), x.n, x.h, x.w, ks, _stream())
