@@ -449,6 +449,10 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
 #pragma unroll
                             for (int c = 0; c < XE; ++c) dq[(g + 1) & 1][c] = db[4 * c * kDCS + 16 * (g + 1)];
                         }
+                        // Solid MFMA block: switching between matrix and vector issue costs ~4 extra cycles per
+                        // switch on gfx950 (scratch/probe/mfma_il.hip: 45 MFMA + 45 VALU runs at 113 TF blocked,
+                        // 82 TF interleaved 1:1), so the staging VALU work below must not be woven in.
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int ky = 0; ky < KS; ++ky)
 #pragma unroll
@@ -457,6 +461,7 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
                                 for (int c = 0; c < XE; ++c)
                                     acc[c][ky * KS + kx] = __builtin_amdgcn_mfma_f32_4x4x1f32(
                                         dq[g & 1][c], bw[(g + ky) % KS][kx], acc[c][ky * KS + kx], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                     if (g < NA + ND) chunk(g, nxt);
                 }

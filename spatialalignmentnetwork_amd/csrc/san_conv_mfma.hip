@@ -125,8 +125,24 @@ MGeom mfma_geom(int N, int H, int W, int cout, int ks) {
     g.TH = g.GH * g.G * g.WY;
     g.tiles_x = san_cdiv(W, g.TW);
     g.tiles_y = san_cdiv(H, g.TH);
+    // LDS row pitch: the 32 lanes of a ds_read_b32 group sit in 32/GW lane rows that are G tile rows
+    // apart; pick the smallest pitch whose lane rows fall on disjoint banks
     g.pitch = g.TW + 2 * pad;
-    if ((g.pitch & 1) == 0) g.pitch += 1;      // odd pitch: rows of a 2-/4-row pixel group fall on different banks
+    if (g.GW < 32) {
+        int best_p = g.pitch, best_c = 1 << 30;
+        for (int p = g.TW + 2 * pad; p < g.TW + 2 * pad + 32; ++p) {
+            int cnt[32] = {0}, worst = 0;
+            for (int l = 0; l < 32 && l < g.GW * g.GH; ++l) {
+                const int b = ((l / g.GW) * g.G * p + l % g.GW) & 31;
+                if (++cnt[b] > worst) worst = cnt[b];
+            }
+            if (worst < best_c) {
+                best_c = worst;
+                best_p = p;
+            }
+        }
+        g.pitch = best_p;
+    }
     g.rows_t = g.TH + 2 * pad;
     return g;
 }
@@ -216,9 +232,8 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
 #pragma unroll
         for (int c = 0; c < CQ; ++c) acc[g][c] = f4{0.f, 0.f, 0.f, 0.f};
 
-    const int row0 = wy * (M.GH * G) + lrow;       // this lane's row inside the tile for group 0
+    const int row0 = wy * (M.GH * G) + lrow * G;   // this lane's G pixels are rows row0 .. row0 + G - 1 of the tile
     const int in_base = row0 * pitch + lcol;
-    const int gstep = M.GH * pitch;                // LDS stride between pixel groups
     const float* wl = lds_w + wc * w_chunk + (lane & 3) * CQP;
     const int aff = n * a.x_ctot + a.x_coff;
 
@@ -247,47 +262,58 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
         __syncthreads();
         if (c0 + kCK < a.cin) prefetch(c0 + kCK);
         if (g_ok) {
-            // Software pipeline over (channel, tap) steps: the LDS reads of step s+1 (CQP weights
-            // + G activations per lane) are issued BEFORE the CQ*G MFMAs of step s, and
-            // sched_barrier keeps hipcc from sinking them back next to their first use, so LDS
-            // latency hides under ~160 cycles of matrix work instead of being exposed per tap.
-            float wcur[CQP], bcur[G];
-            auto load_step = [&](int ci, int tap, float (&wq)[CQP], float (&bq)[G]) {
+            // A lane's G pixels are vertically adjacent (row0 + g), so for one input channel the G
+            // 3x3 windows overlap: (G + KS - 1) x KS activations per lane serve all G*TAPS products
+            // (18 LDS reads instead of 36 at G = 4), all at immediate offsets.  Per tap the CQ weight
+            // quads arrive as CQP/4 16-byte reads.  Both are fetched one step ahead of the CQ*G MFMAs
+            // that consume them; the MFMAs of a tap form one solid block (switching between matrix
+            // and vector/LDS issue costs cycles on gfx950, scratch/probe/mfma_il.hip).
+            constexpr int WR = G + KS - 1;
+            float win[2][WR][KS];
+            float wq[2][CQP];
+            auto load_win = [&](int ci, float (&w)[WR][KS]) {
+                const float* tin = lds_in + ci * tile_stride + in_base;
+#pragma unroll
+                for (int r = 0; r < WR; ++r)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) w[r][kx] = tin[r * pitch + kx];
+            };
+            auto load_w = [&](int ci, int tap, float (&q)[CQP]) {
                 const float* tw = wl + (ci * TAPS + tap) * WROW;
 #pragma unroll
                 for (int c4 = 0; c4 < CQP; c4 += 4) {
                     const f4 t4 = *reinterpret_cast<const f4*>(tw + c4);
-                    wq[c4] = t4[0];
-                    wq[c4 + 1] = t4[1];
-                    wq[c4 + 2] = t4[2];
-                    wq[c4 + 3] = t4[3];
+                    q[c4] = t4[0];
+                    q[c4 + 1] = t4[1];
+                    q[c4 + 2] = t4[2];
+                    q[c4 + 3] = t4[3];
                 }
-                const float* tin = lds_in + ci * tile_stride + in_base + (tap / KS) * pitch + (tap % KS);
-#pragma unroll
-                for (int g = 0; g < G; ++g) bq[g] = tin[g * gstep];
             };
-            load_step(0, 0, wcur, bcur);
-#pragma unroll 1
-            for (int ci = 0; ci < ckk; ++ci) {
+            load_win(0, win[0]);
+            load_w(0, 0, wq[0]);
 #pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
-                    float wnext[CQP], bnext[G];
-                    if (tap + 1 < TAPS) {
-                        load_step(ci, tap + 1, wnext, bnext);
-                    } else {
-                        load_step(min(ci + 1, kCK - 1), 0, wnext, bnext);   // clamped: the extra prefetch of the last step is unused
+            for (int ci = 0; ci < kCK; ++ci) {
+                if (ci < ckk) {
+#pragma unroll
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int step = ci * TAPS + tap;
+                        if (tap + 1 < TAPS) {
+                            load_w(ci, tap + 1, wq[(step + 1) & 1]);
+                        } else {
+                            load_w(min(ci + 1, kCK - 1), 0, wq[(step + 1) & 1]);   // clamped: unused after the last channel
+                        }
+                        if (tap == 0) load_win(min(ci + 1, kCK - 1), win[(ci + 1) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int g = 0; g < G; ++g)
+#pragma unroll
+                            for (int c = 0; c < CQ; ++c)
+                                acc[g][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[step & 1][c], win[ci & 1][g + tap / KS][tap % KS],
+                                                                               acc[g][c], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int g = 0; g < G; ++g)
-#pragma unroll
-                        for (int c = 0; c < CQ; ++c)
-                            acc[g][c] = __builtin_amdgcn_mfma_f32_4x4x1f32(wcur[c], bcur[g], acc[g][c], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int c = 0; c < CQP; ++c) wcur[c] = wnext[c];
-#pragma unroll
-                    for (int g = 0; g < G; ++g) bcur[g] = bnext[g];
                 }
             }
         }
@@ -299,7 +325,7 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
     int oyg[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        oyg[g] = y0 + row0 + g * M.GH;
+        oyg[g] = y0 + row0 + g;
         valid[g] = lane_ok && g_ok && oyg[g] < H && ox < W;
     }
     if (a.bias) {
