@@ -292,6 +292,14 @@ int san_smooth_pool_fwd(const float* x, const float* kern, float* y, int planes,
  * [n, 2, h, w] (model.py:21-28 on the permuted view). */
 int san_gradient_loss_fwd(const float* offset, float* loss, int n, int h, int w, float* ws, void* stream);
 
+/* One AdamW step over flat fp32 buffers (replaces torch.optim.AdamW(lr, weight_decay) over every
+ * parameter tensor, model.py:72-87; decoupled weight decay, no amsgrad):
+ *   g' = grad_scale*g;  p *= 1 - lr*wd;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps).   step counts from 1.
+ * All four buffers: count floats, 16-byte aligned. */
+int san_adamw_step(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

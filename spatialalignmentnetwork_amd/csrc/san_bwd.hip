@@ -46,7 +46,6 @@ struct WgradArgs {
     int tw, th, aw, a_count, npx, groups;    // tile geometry: th x tw pixels, halo row pitch aw, 16-pixel groups
     int tiles_x, tiles_y, P;
     int cib_q;               // input-channel quads per workgroup (<= 4; balanced over the z blocks)
-    unsigned long long* ts;  // DEBUG
 };
 
 struct WgradPlan {
@@ -287,10 +286,6 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
     const int nq = ci_on ? (cop ? qblk - qfirst : (qblk + 1) / 2) : 0;     // 0: this wave only stages
     const int H = a.H, W = a.W;
     const int HW = H * W;
-    int tsi = 0;
-    const bool tson = a.ts && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0;
-#define TS() do { if (tson && tsi < 250) a.ts[tsi++] = __builtin_amdgcn_s_memtime(); } while (0)
-    TS();
 
     for (int i = tid; i < 2 * BUF + 4 * kVT; i += kVT) lds[i] = 0.f;     // pad pixels stay finite
 
@@ -404,7 +399,6 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
 #pragma unroll
     for (int g = 0; g < NA + ND; ++g) chunk(g, 0);
     __syncthreads();
-    TS();
 
     // ---- main loop.  The pixel tile is 16 x 16: group g = tile row g, MFMA block b = column b, so
     // consecutive groups slide the 3-row input window down by one row: only the new row (KS
@@ -466,9 +460,7 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
                     if (g < NA + ND) chunk(g, nxt);
                 }
             }
-            TS();
             __syncthreads();
-            TS();
         }
         if constexpr (XE > 0) {
             // sum the 16 blocks: lanes 4b + j hold D_b[i][j]; rotations inside each row of 16, then the four rows
@@ -512,8 +504,6 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
     } else {
         if constexpr (X >= 4) run(std::integral_constant<int, 4>{});
     }
-    TS();
-#undef TS
 }
 
 // dW[i] (+)= sum_p partial[p][i], fixed order
@@ -954,7 +944,6 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const floa
     a.tiles_y = p.tiles_y;
     a.P = p.P;
     a.cib_q = p.cib_q;
-    if (const char* e = getenv("SAN_DBG_TS")) a.ts = (unsigned long long*)strtoull(e, nullptr, 10);
     dim3 grid(p.P, p.co_blocks, p.ci_blocks);
     hipStream_t s = (hipStream_t)stream;
 #define SAN_WGRAD_LAUNCH(KS, X) hipLaunchKernelGGL((conv_wgrad_kernel<KS, X>), grid, dim3(kThreads), 0, s, a)

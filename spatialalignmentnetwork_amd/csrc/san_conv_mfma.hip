@@ -206,8 +206,19 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
 
     float stage[kCK][kSlots];
     f4 wstage[WS];
+    float psc[kCK], psh[kCK];          // the chunk's lazy affine, fetched with the tile (not at first use)
+    const int aff = n * a.x_ctot + a.x_coff;
     auto prefetch = [&](int c0) {
         const int cin_last = a.cin - 1;
+#pragma unroll
+        for (int ci = 0; ci < kCK; ++ci) {
+            psc[ci] = 1.f;
+            psh[ci] = 0.f;
+            if (a.in_scale) {
+                psc[ci] = a.in_scale[aff + min(c0 + ci, cin_last)];
+                psh[ci] = a.in_shift[aff + min(c0 + ci, cin_last)];
+            }
+        }
 #pragma unroll
         for (int ci = 0; ci < kCK; ++ci) {
             const float* src = x + (size_t)(n * a.x_ctot + a.x_coff + min(c0 + ci, cin_last)) * HW;
@@ -235,7 +246,6 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
     const int row0 = wy * (M.GH * G) + lrow * G;   // this lane's G pixels are rows row0 .. row0 + G - 1 of the tile
     const int in_base = row0 * pitch + lcol;
     const float* wl = lds_w + wc * w_chunk + (lane & 3) * CQP;
-    const int aff = n * a.x_ctot + a.x_coff;
 
     prefetch(0);
     for (int c0 = 0; c0 < a.cin; c0 += kCK) {
@@ -243,11 +253,7 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
         __syncthreads();
 #pragma unroll
         for (int ci = 0; ci < kCK; ++ci) {
-            float sc = 1.f, sh = 0.f;
-            if (a.in_scale) {
-                sc = a.in_scale[aff + min(c0 + ci, a.cin - 1)];
-                sh = a.in_shift[aff + min(c0 + ci, a.cin - 1)];
-            }
+            const float sc = psc[ci], sh = psh[ci];
 #pragma unroll
             for (int s = 0; s < kSlots; ++s) {
                 const float v = inb[s] ? san_act(stage[ci][s], sc, sh, a.in_slope) : 0.f;
@@ -407,21 +413,34 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
         }
         return;
     }
+    // Output affine of every channel first, THEN the stores: on gfx9 loads and stores share vmcnt, so a
+    // load between two stores makes each store wait for the previous one to complete.
+    float osv[CQ][4], obv[CQ][4];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            osv[c][i] = 1.f;
+            obv[c][i] = 0.f;
+            if (a.out_scale) {
+                const int co = min(grp * CW + 4 * c + i, a.cout - 1);
+                osv[c][i] = a.out_scale[n * a.cout + co];
+                obv[c][i] = a.out_shift[n * a.cout + co];
+            }
+        }
+    int ooff[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) ooff[g] = oyg[g] * W + ox;
 #pragma unroll
     for (int c = 0; c < CQ; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = grp * CW + 4 * c + i;
             if (co < a.cout) {
-                float os = 1.f, ob = 0.f;
-                if (a.out_scale) {
-                    os = a.out_scale[n * a.cout + co];
-                    ob = a.out_shift[n * a.cout + co];
-                }
-                float* dst = y + (size_t)(n * a.y_ctot + a.y_coff + co) * HW + ox;
+                float* dst = y + (size_t)(n * a.y_ctot + a.y_coff + co) * HW;
 #pragma unroll
                 for (int g = 0; g < G; ++g)
-                    if (oyg[g] < H) dst[(size_t)oyg[g] * W] = fmaf(acc[g][c][i], os, ob);
+                    if (oyg[g] < H) dst[ooff[g]] = fmaf(acc[g][c][i], osv[c][i], obv[c][i]);
             }
         }
 }

@@ -444,7 +444,7 @@ __device__ __forceinline__ void bfly5(float2 (&v)[5], float sgn) {
 // out[t][r]: final outputs of radix-5 butterfly t (element j + 64 r of its line).
 template <int MAP>
 __device__ __forceinline__ void fft320_core(float2 (&in)[5][4], float2 (&out)[4][5], float2* lds,
-                                            const float2* __restrict__ twg, float sgn, int lane) {
+                                            const float2* twg, float sgn, int lane) {
     int lineA[5], jA[5];
 #pragma unroll
     for (int t = 0; t < 5; ++t) Map320<MAP>::r4(lane, t, lineA[t], jA[t]);
@@ -524,7 +524,10 @@ __device__ __forceinline__ void fft320_core(float2 (&in)[5][4], float2 (&out)[4]
 // rows: grid (H/4, outer); plane = outer*inner + l
 __global__ void __launch_bounds__(64) fft320_rows_kernel(const FftArgs a) {
     __shared__ float2 lds[kL320 * kP320];
+    __shared__ float2 tws[kN320];          // LDS-staged twiddles: passes B, C, D read them with LDS latency
     const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) tws[lane + 64 * r] = a.tw[lane + 64 * r];
     const int W = kN320, H = a.H;
     const int h0 = blockIdx.x * kL320;
     const int outer = blockIdx.y;
@@ -570,7 +573,7 @@ __global__ void __launch_bounds__(64) fft320_rows_kernel(const FftArgs a) {
                 for (int r = 0; r < 5; ++r)
                     sv[t][r] = (h0 + t < H) ? a.sens[base + (size_t)t * W + lane + 64 * r] : make_float2(0.f, 0.f);
         }
-        fft320_core<0>(in, out, lds, a.tw, a.sgn, lane);
+        fft320_core<0>(in, out, lds, tws, a.sgn, lane);
         // ---- outputs: row t, element lane + 64 r
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -618,7 +621,10 @@ __global__ void __launch_bounds__(64) fft320_rows_kernel(const FftArgs a) {
 // columns: grid (W/4, planes); transform along H == 320
 __global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
     __shared__ float2 lds[kL320 * kP320];
+    __shared__ float2 tws[kN320];
     const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) tws[lane + 64 * r] = a.tw[lane + 64 * r];
     const int W = a.W;
     const int w0 = blockIdx.x * kL320;
     const int plane = blockIdx.y;
@@ -657,7 +663,7 @@ __global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
             }
         }
     }
-    fft320_core<1>(in, out, lds, a.tw, a.sgn, lane);
+    fft320_core<1>(in, out, lds, tws, a.sgn, lane);
     if (!ok) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {

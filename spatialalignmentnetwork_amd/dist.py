@@ -99,20 +99,22 @@ class GradBucket:
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
-        dev = self.params[0].device if self.params else "cpu"
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = []
         off = 0
-        for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
-            off += n
+        for p in self.params:                      # every tensor starts on a 16-byte boundary
+            self.offsets.append(off)
+            off += (p.numel() + 3) & ~3
+        self.total = off
+        dev = self.params[0].device if self.params else "cpu"
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
 
     def zero(self):
         self.flat.zero_()
 
-    def allreduce_mean(self, dist) -> None:
-        """Average the gradients over all ranks (sum, then divide by the world size)."""
+    def allreduce_sum(self, dist) -> None:
+        """Sum the gradients over all ranks in place (the optimiser kernel applies the 1/world factor)."""
         if dist is None:
             return
         if self.flat.is_cuda and BACKEND == "gloo":      # RCCL unavailable: stage through the host
@@ -121,4 +123,35 @@ class GradBucket:
             self.flat.copy_(host)
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+    def allreduce_mean(self, dist) -> None:
+        """Average the gradients over all ranks (sum, then divide by the world size)."""
+        if dist is None:
+            return
+        self.allreduce_sum(dist)
         self.flat.div_(dist.get_world_size())
+
+
+class ParamBucket(GradBucket):
+    """GradBucket plus flat parameter and AdamW moment buffers: every ``p.data`` becomes a view into
+    ``flat_p`` (same Parameter objects, same state_dict keys and shapes), so one fused kernel
+    (san_adamw_step) updates a whole network."""
+
+    def __init__(self, params):
+        super().__init__(params)
+        self.flat_p = torch.zeros_like(self.flat)
+        for p, o in zip(self.params, self.offsets):
+            view = self.flat_p[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.steps = 0
+
+    def owns(self, params) -> bool:
+        """True while every parameter still lives in this bucket (``module.to()`` re-allocates them)."""
+        lo = self.flat_p.data_ptr()
+        hi = lo + self.flat_p.numel() * 4
+        ps = [p for p in params if p.requires_grad]
+        return len(ps) == len(self.params) and all(
+            a is b and lo <= a.data_ptr() < hi and a.grad is not None for a, b in zip(ps, self.params))

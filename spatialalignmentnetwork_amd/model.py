@@ -19,6 +19,7 @@ from . import ops
 from .basemodel import BaseModel, Config  # noqa: F401
 from .cross import SpatialTransformer
 from .masks import masks
+from .optim import FusedAdamW
 from .signal_utils import rss
 from .ssimloss import ssimloss
 from .varnet import VarNet
@@ -37,7 +38,7 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
 class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_buckets"}
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -50,8 +51,8 @@ class CSModel(BaseModel):
         self.net_R = VarNet(num_cascades=get("num_cascades", 8), sens_chans=get("sens_chans", 8),
                             sens_pools=get("sens_pools", 4), chans=get("chans", 18), pools=get("pools", 4),
                             use_ref=True)
-        self.optim_T = torch.optim.AdamW(self.net_T.parameters(), lr=cfg.lr, weight_decay=0)
-        self.optim_R = torch.optim.AdamW(self.net_R.parameters(), lr=cfg.lr, weight_decay=0)
+        self.optim_T = FusedAdamW(self.net_T.parameters(), lr=cfg.lr, weight_decay=0)
+        self.optim_R = FusedAdamW(self.net_R.parameters(), lr=cfg.lr, weight_decay=0)
         self.use_amp = bool(get("use_amp", False))
         self.device = torch.device("cpu")
 
@@ -129,27 +130,22 @@ class CSModel(BaseModel):
             self.loss_all = 0
         self.forwardR()
         opts = [self.optim_R] + ([self.optim_T] if train_T else [])
-        buckets = self._grad_buckets()
-        for name in (["R"] + (["T"] if train_T else [])):
-            buckets[name].zero()
+        for o in opts:
+            o.zero_grad()                       # one memset of the flat gradient buffer per network
         self.backward(train_T)
         dist = _active_dist()
-        if dist is not None:                    # data parallel: gradients averaged over ranks (RCCL on GPUs)
-            for name in (["R"] + (["T"] if train_T else [])):
-                buckets[name].allreduce_mean(dist)
+        scale = 1.0
+        if dist is not None:                    # data parallel: one in-place RCCL all-reduce per network;
+            for o in opts:                      # the 1/world factor rides in the optimiser kernel
+                o.bucket().allreduce_sum(dist)
+            scale = 1.0 / dist.get_world_size()
         for o in opts:
-            o.step()
+            o.step(grad_scale=scale)
         del self.loss_all
 
     def _grad_buckets(self):
-        """Flat per-network gradient buffers (built once; p.grad are views, see dist.GradBucket)."""
-        b = self.__dict__.get("_buckets")
-        dev = next(self.net_R.parameters()).device
-        if b is None or b["R"].flat.device != dev:
-            from .dist import GradBucket
-            b = {"R": GradBucket(self.net_R.parameters()), "T": GradBucket(self.net_T.parameters())}
-            self._buckets = b
-        return b
+        """Flat per-network buffers (p.data / p.grad are views, see dist.ParamBucket)."""
+        return {"R": self.optim_R.bucket(), "T": self.optim_T.bucket()}
 
     def test(self):
         """model.py:265-286 without the GAN branch; returns -PSNR."""

@@ -246,12 +246,31 @@ def cabs(x: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 # conv / norm stack
 # ---------------------------------------------------------------------------
+# In-place parameter updates by san_adamw_step do not touch tensor._version: the packing caches
+# below also key on this counter, which the fused optimiser bumps after every step.
+WEIGHT_EPOCH = [0]
+
+
+def bump_weight_epoch() -> None:
+    WEIGHT_EPOCH[0] += 1
+
+
+def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float,
+               beta2: float, eps: float, weight_decay: float, step: int, grad_scale: float = 1.0) -> None:
+    """One fused AdamW step over flat fp32 buffers (see san_adamw_step)."""
+    for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, name=name)
+    assert p.numel() == g.numel() == m.numel() == v.numel()
+    lib().call("san_adamw_step", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+               int(step), grad_scale, _stream())
+
+
 def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     """Repacked copy of a conv weight for the scalar-operand kernels, cached on
     (storage, version) so an optimizer step invalidates it."""
     # the cache lives ON the tensor object (so it dies with it: a data_ptr-keyed table would
     # hand a freed layer's packing to whichever new weight the allocator puts at that address)
-    tagv = (w._version, w.data_ptr(), transposed)
+    tagv = (w._version, w.data_ptr(), transposed, WEIGHT_EPOCH[0])
     hit = getattr(w, "_san_packed", None)
     if hit is not None and hit[0] == tagv:
         return hit[1]
@@ -430,7 +449,7 @@ def smooth_pool(x: torch.Tensor, kern: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 def packed_weight_dgrad(w: torch.Tensor) -> torch.Tensor:
     """Flipped / channel-swapped packing of a Conv2d weight: conv2d(dy, this) = dL/dx."""
-    tagv = (w._version, w.data_ptr(), "dgrad")
+    tagv = (w._version, w.data_ptr(), "dgrad", WEIGHT_EPOCH[0])
     hit = getattr(w, "_san_packed_dgrad", None)
     if hit is not None and hit[0] == tagv:
         return hit[1]

@@ -81,3 +81,24 @@ def test_grad_bucket_allreduce_mean_world2():
     mp.spawn(_grad_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     for r in range(world):
         assert out[r] == [1.5 * (i + 1) for i in range(4)]   # mean of (1, 2) * (i + 1) on every rank
+
+
+def test_param_bucket_views_cpu():
+    """ParamBucket: parameters and gradients become views of flat buffers (16-byte aligned starts), values and
+    Parameter identity preserved; owns() notices re-allocated parameters."""
+    import torch
+    from spatialalignmentnetwork_amd.dist import ParamBucket
+    lin = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Conv2d(5, 2, 1))
+    before = {k: v.clone() for k, v in lin.state_dict().items()}
+    params = list(lin.parameters())
+    b = ParamBucket(params)
+    assert all(o % 4 == 0 for o in b.offsets) and b.total >= sum(p.numel() for p in params)
+    for k, v in lin.state_dict().items():
+        assert torch.equal(v, before[k])
+    for p, o in zip(params, b.offsets):
+        assert p.data_ptr() == b.flat_p.data_ptr() + 4 * o and p.grad.data_ptr() == b.flat.data_ptr() + 4 * o
+    b.flat_p.mul_(2.0)                                   # one flat op updates every parameter
+    assert torch.equal(lin[0].weight.detach(), 2 * before["0.weight"])
+    assert b.owns(lin.parameters())
+    lin.double().float()                                 # re-allocates the parameter storage
+    assert not b.owns(lin.parameters())

@@ -324,6 +324,31 @@ def test_conv_dgrad_wgrad_vs_autograd(S, cin, cout, h, w, ks):
     assert rel_err(dw.cpu(), 2 * w64.grad.float()) < 1e-5
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w,ks,slope,affine,coff", [
+    (3, 72, 72, 20, 20, 3, 0.2, True, 0),      # several input / output channel blocks, balanced 10-row tiles
+    (1, 40, 100, 48, 16, 3, 0.0, True, 4),     # ReLU, channel views with an offset, one tile column
+    (2, 8, 16, 36, 52, 3, 1.0, False, 0),      # no lazy affine (materialised input), partial tiles in x and y
+    (2, 18, 18, 24, 24, 3, -0.5, True, 0),     # slope outside [0, 1]: generic kernel
+    (2, 288, 40, 8, 12, 1, 0.01, True, 2),     # 1x1, many input blocks
+])
+def test_conv_wgrad_paths(S, n, cin, cout, h, w, ks, slope, affine, coff):
+    """Weight gradient through the pipelined kernel's channel blocking / tile geometry variants and the
+    generic fallback, against float64 autograd.  Tolerance 1e-5 relative (fp32 sums of up to 2e4 terms)."""
+    x = philox("wp.x", (n, cin + coff, h, w))
+    dy = philox("wp.dy", (n, cout + coff, h, w))
+    sc, sh = philox("wp.sc", (n, cin + coff), lo=0.5, hi=1.5), philox("wp.sh", (n, cin + coff))
+    xs = x[:, coff:]
+    if affine:
+        xs = xs * sc[:, coff:, None, None] + sh[:, coff:, None, None]
+    xa = torch.nn.functional.leaky_relu(xs, slope).double() if slope != 1.0 else xs.double()
+    w64 = torch.zeros((cout, cin, ks, ks), dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xa, w64, None, padding=ks // 2).backward(dy[:, coff:].double())
+    dw = torch.empty((cout, cin, ks, ks), device=DEV)
+    act = S.ops.Act(g(x), coff, cin, g(sc) if affine else None, g(sh) if affine else None, slope)
+    S.ops.conv2d_wgrad(act, S.ops.Act(g(dy), coff, cout, None, None, 1.0), dw)
+    assert rel_err(dw.cpu(), w64.grad.float()) < 1e-5
+
+
 def test_instance_norm_act_backward(S):
     n, c, h, w = 2, 5, 24, 40
     y = philox("ib.y", (n, c, h, w)) * 2 + 0.3
@@ -513,3 +538,28 @@ def test_full_rec_step_gradients_vs_golden(S, tag, shape):
         if k.startswith("bn_after.T."):
             got = dict(net.net_T.named_buffers())[k[len("bn_after.T."):]]
             assert torch.allclose(got.cpu(), as_t(gold[k]), rtol=2e-4, atol=2e-6), k
+
+
+def test_fused_adamw_matches_torch(S):
+    """san_adamw_step over flat buffers == torch.optim.AdamW on the same tensors (4 steps, weight decay on and
+    off, a 1/world gradient scale).  Tolerance 2e-6 relative: same fp32 formula, different operation order."""
+    from spatialalignmentnetwork_amd.optim import FusedAdamW
+    shapes = [(18, 3, 3, 3), (18,), (7, 5), (1,), (36, 18, 3, 3)]
+    for wd, scale in ((0.0, 1.0), (0.01, 0.5)):
+        ref = [torch.nn.Parameter(philox(f"ad.p{i}", sh).clone()) for i, sh in enumerate(shapes)]
+        mine = [torch.nn.Parameter(g(r.detach().clone())) for r in ref]
+        o_ref = torch.optim.AdamW(ref, lr=1e-2, weight_decay=wd)
+        o_mine = FusedAdamW(mine, lr=1e-2, weight_decay=wd)
+        for step in range(4):
+            o_mine.zero_grad()
+            for i, (r, m) in enumerate(zip(ref, mine)):
+                gr = philox(f"ad.g{step}.{i}", tuple(r.shape))
+                r.grad = gr.clone() * scale
+                m.grad.copy_(g(gr))                       # p.grad is a view into the flat buffer
+            o_ref.step()
+            o_mine.step(grad_scale=scale)
+        for r, m in zip(ref, mine):
+            assert rel_err(m.detach().cpu(), r.detach()) < 2e-6
+        # parameters are views of one flat buffer and survive as the same Parameter objects
+        b = o_mine.bucket()
+        assert all(b.flat_p.data_ptr() <= m.data_ptr() < b.flat_p.data_ptr() + 4 * b.total for m in mine)
