@@ -45,13 +45,15 @@ struct WgradArgs {
     int N, H, W;
     int tw, th, aw, a_count, npx, groups;    // tile geometry: th x tw pixels, halo row pitch aw, 16-pixel groups
     int tiles_x, tiles_y, P;
-    int cib_q;               // input-channel quads per workgroup (<= 4; balanced over the z blocks)
+    int cib_q;               // generic kernel: input-channel quads per workgroup (<= 4; balanced over the z blocks)
+    int P_rem;               // pipelined kernel: pixel partitions of the remainder input-channel block (<= P)
+    int co_blocks, n_full;   // pipelined kernel: 1-D grid = co_blocks * (n_full * P + P_rem) workgroups
 };
 
 struct WgradPlan {
     int vec;                 // 16-byte staged, pipelined kernel (W % 4 == 0) or the generic scalar one
     int tw, th, aw, a_count, npx, groups, tiles_x, tiles_y;
-    int X, co_blocks, cib_q, ci_blocks, P;
+    int X, co_blocks, cib_q, ci_blocks, P, P_rem;
 };
 
 template <int KS, int X>
@@ -273,17 +275,46 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
     extern __shared__ float lds[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ciq = wave & 3, cop = wave >> 2;       // waves w and w+4 share a SIMD: same input quad, other co part
     const int lane = tid & 63;
     const int b = lane >> 2, q = lane & 3;
-    const int co0 = blockIdx.y * CO;
-    const int ci0 = blockIdx.z * a.cib_q * 4;
-    const int nstage = min(4 * a.cib_q, kCIB);
-    // this wave's share of the block's output-channel quads: the two parts split them evenly
-    const int qblk = min(2 * X, san_cdiv_dev(a.cout, 4) - 2 * X * (int)blockIdx.y);
-    const int qfirst = cop ? (qblk + 1) / 2 : 0;
-    const bool ci_on = ciq < a.cib_q && ci0 + 4 * ciq < a.cin;
-    const int nq = ci_on ? (cop ? qblk - qfirst : (qblk + 1) / 2) : 0;     // 0: this wave only stages
+    // Input-channel blocks are 4 quads (16 channels) plus one remainder block.  A block with nci
+    // quads gives every quad 8 / ncip waves (ncip = nci rounded up to 1, 2 or 4), which split the
+    // block's output-channel quads between them: a remainder block of one quad (cin = 18, 36)
+    // still runs MFMAs on all four SIMDs instead of one.  Waves w and w + 4 share a SIMD.
+    // The remainder block is cheaper per tile, so it gets fewer pixel partitions (P_rem <= P); the
+    // grid is 1-D with exactly co_blocks * (n_full * P + P_rem) workgroups (never more than the
+    // 256 CUs: a second dispatch round costs 20-50 % here).
+    int px, by, bz, Pb;
+    {
+        const int id = blockIdx.x, full_ids = a.n_full * a.co_blocks * a.P;
+        if (id < full_ids) {
+            bz = id / (a.co_blocks * a.P);
+            const int r = id - bz * (a.co_blocks * a.P);
+            by = r / a.P;
+            px = r - by * a.P;
+            Pb = a.P;
+        } else {
+            const int r = id - full_ids;
+            bz = a.n_full;
+            by = r / a.P_rem;
+            px = r - by * a.P_rem;
+            Pb = a.P_rem;
+        }
+    }
+    const int co0 = by * CO;
+    const int ci0 = bz * kCIB;
+    const int nci = min(4, san_cdiv_dev(a.cin, 4) - 4 * bz);
+    const int ncip = nci > 2 ? 4 : nci;
+    const int ncp = 8 / ncip;
+    const int ciq = wave & (ncip - 1);
+    // co part of this wave; the second half of the parts is taken in reverse so that the two waves of
+    // a SIMD (w, w + 4) get part sizes that add up evenly
+    const int cop_raw = wave / ncip;
+    const int cop = (ncp >= 4 && cop_raw >= ncp / 2) ? ncp - 1 - (cop_raw - ncp / 2) : cop_raw;
+    const int nstage = 4 * nci;
+    const int qblk = min(2 * X, san_cdiv_dev(a.cout, 4) - 2 * X * by);
+    const int qfirst = (cop * qblk) / ncp;
+    const int nq = ciq < nci ? ((cop + 1) * qblk) / ncp - qfirst : 0;       // 0: this wave only stages
     const int H = a.H, W = a.W;
     const int HW = H * W;
 
@@ -324,8 +355,8 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
     // ---- this workgroup's contiguous run of tiles
     const int tiles_per_img = a.tiles_x * a.tiles_y;
     const int total_tiles = tiles_per_img * a.N;
-    const int t0 = (int)(((long long)blockIdx.x * total_tiles) / a.P);
-    const int t1 = (int)(((long long)(blockIdx.x + 1) * total_tiles) / a.P);
+    const int t0 = (int)(((long long)px * total_tiles) / Pb);
+    const int t1 = (int)(((long long)(px + 1) * total_tiles) / Pb);
 
     f4 sa[NA], sd[ND];
     float ssc[NA], ssh[NA];
@@ -485,7 +516,7 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
                     for (int i = 0; i < 4; ++i) {
                         const int co = co0 + 4 * (qfirst + c) + i;
                         if (co < a.cout) {
-                            float* o = a.partial + (((size_t)blockIdx.x * a.cout + co) * a.cin + ci) * TAPS;
+                            float* o = a.partial + (((size_t)px * a.cout + co) * a.cin + ci) * TAPS;
 #pragma unroll
                             for (int t = 0; t < TAPS; ++t) o[t] = acc[c][t][i];
                         }
@@ -508,10 +539,12 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
 
 // dW[i] (+)= sum_p partial[p][i], fixed order
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int count, int P,
-                                    int accumulate) {
+                                    int accumulate, int cin_taps, int split, int P_rem) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        // input-channel columns >= split belong to the remainder block, which wrote P_rem partitions
+        const int Pi = (i % cin_taps) >= split ? P_rem : P;
         float s = 0.f;
-        for (int p = 0; p < P; ++p) s += partial[(size_t)p * count + i];
+        for (int p = 0; p < Pi; ++p) s += partial[(size_t)p * count + i];
         dw[i] = accumulate ? dw[i] + s : s;
     }
 }
@@ -569,11 +602,35 @@ WgradPlan wgrad_plan(int n, int h, int w, int cin, int cout, int ks, bool allow_
     p.ci_blocks = san_cdiv(qci, 4);
     p.cib_q = san_cdiv(qci, p.ci_blocks);
     const int tiles = p.tiles_x * p.tiles_y * n;
-    int P = p.vec ? 256 / (p.co_blocks * p.ci_blocks) : san_cdiv(768, p.co_blocks * p.ci_blocks);   // vec: 1 WG per CU (LDS)
+    int P;
+    p.P_rem = 0;
+    if (p.vec) {
+        // One workgroup per CU (LDS).  Full input-channel blocks keep a SIMD busy for qblk quads per pixel
+        // group, the remainder block (qci % 4 quads) for fewer (see the kernel): split the 256 workgroup
+        // slots between them in proportion to that work (+1.5 quads of per-tile staging overhead).
+        const int qblk = qco < span * p.X ? qco : span * p.X;
+        const int rem = qci % 4;
+        const int n_full = qci / 4;
+        const float w_full = qblk + 1.5f;
+        const float w_rem = (rem == 0 ? 0.f : rem == 1 ? (qblk + 3) / 4 : rem == 2 ? (qblk + 1) / 2 : qblk) + (rem ? 1.5f : 0.f);
+        const float slots = 256.f / p.co_blocks;
+        const float unit = slots / (n_full * w_full + w_rem);
+        P = n_full ? (int)(unit * w_full) : (int)(unit * w_rem);
+        if (P < 1) P = 1;
+        if (rem) {
+            int pr = n_full ? (int)(slots - (float)n_full * P) : P;
+            if (pr < 1) pr = 1;
+            if (pr > P) pr = P;
+            p.P_rem = pr;
+        }
+    } else {
+        P = san_cdiv(768, p.co_blocks * p.ci_blocks);
+    }
     if (P > tiles) P = tiles;
     if (P > 256) P = 256;
     if (P < 1) P = 1;
     p.P = P;
+    if (p.P_rem > p.P || p.P_rem < 1) p.P_rem = p.P;
     return p;
 }
 
@@ -917,7 +974,7 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const floa
     SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
     const bool aligned = (((uintptr_t)x | (uintptr_t)dy) & 15) == 0;
     const bool lrelu01 = in_slope >= 0.f && in_slope <= 1.f;          // the pipelined kernel evaluates LeakyReLU as max(v, slope*v)
-    const WgradPlan p = wgrad_plan(n, h, w, cin, cout, ks, aligned && lrelu01 && !getenv("SAN_WGRAD_SCALAR"));
+    const WgradPlan p = wgrad_plan(n, h, w, cin, cout, ks, aligned && lrelu01);
     WgradArgs a{};
     a.x = x;
     a.in_scale = in_scale;
@@ -943,8 +1000,15 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const floa
     a.tiles_x = p.tiles_x;
     a.tiles_y = p.tiles_y;
     a.P = p.P;
+    a.P_rem = p.P_rem;
+    a.co_blocks = p.co_blocks;
+    a.n_full = san_cdiv(cin, 4) / 4;
     a.cib_q = p.cib_q;
     dim3 grid(p.P, p.co_blocks, p.ci_blocks);
+    if (p.vec) {
+        const int has_rem = (san_cdiv(cin, 4) % 4) != 0;
+        grid = dim3(p.co_blocks * (a.n_full * p.P + (has_rem ? p.P_rem : 0)), 1, 1);
+    }
     hipStream_t s = (hipStream_t)stream;
 #define SAN_WGRAD_LAUNCH(KS, X) hipLaunchKernelGGL((conv_wgrad_kernel<KS, X>), grid, dim3(kThreads), 0, s, a)
     if (p.vec) {
@@ -988,7 +1052,10 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const floa
     const int count = cout * cin * ks * ks;
     int blocks = san_cdiv(count, 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, count, p.P, accumulate);
+    const int taps = ks * ks;
+    const int split = p.vec ? a.n_full * kCIB * taps : cin * taps;          // first column of the remainder block
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, count, p.P, accumulate, cin * taps,
+                       split, p.vec ? p.P_rem : p.P);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
