@@ -292,6 +292,14 @@ int san_smooth_pool_fwd(const float* x, const float* kern, float* y, int planes,
  * [n, 2, h, w] (model.py:21-28 on the permuted view). */
 int san_gradient_loss_fwd(const float* offset, float* loss, int n, int h, int w, float* ws, void* stream);
 
+/* Batched weight packing for training, where every weight changes every step: san_conv_pack_job
+ * fills one HOST table entry (8 x int64) for a weight/packed-buffer pair -- mode 0: Conv2d forward
+ * (san_conv_pack_weights_fwd), 1: ConvTranspose2d 2x2 (san_conv_pack_weights transposed), 2: Conv2d
+ * data gradient (san_conv_pack_weights_dgrad); packed buffer sizes as for those calls -- and
+ * san_conv_pack_batch runs a device copy of the table [njobs][8] in ONE launch. */
+int san_conv_pack_job(long long* job8, const float* w, float* packed, int cout, int cin, int ks, int mode);
+int san_conv_pack_batch(const long long* jobs_dev, int njobs, void* stream);
+
 /* One AdamW step over flat fp32 buffers (replaces torch.optim.AdamW(lr, weight_decay) over every
  * parameter tensor, model.py:72-87; decoupled weight decay, no amsgrad):
  *   g' = grad_scale*g;  p *= 1 - lr*wd;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;

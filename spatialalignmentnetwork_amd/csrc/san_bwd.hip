@@ -537,15 +537,35 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
     }
 }
 
-// dW[i] (+)= sum_p partial[p][i], fixed order
-__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int count, int P,
-                                    int accumulate, int cin_taps, int split, int P_rem) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
-        // input-channel columns >= split belong to the remainder block, which wrote P_rem partitions
-        const int Pi = (i % cin_taps) >= split ? P_rem : P;
+// dW[i] (+)= sum_p partial[p][i] in a fixed order (deterministic): four lanes share one output
+// element, lane k adds partitions p = k, k+4, ... with four independent loads in flight, and the
+// four partial sums are combined in the order ((0+1)+(2+3)).  (A single thread walking up to 256
+// partitions one dependent load at a time made this step cost as much as a small convolution.)
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int count, int P, int accumulate,
+                    int cin_taps, int split, int P_rem) {
+    const int k = threadIdx.x & 3;
+    for (int i = blockIdx.x * 64 + (threadIdx.x >> 2); i < ((count + 63) & ~63); i += gridDim.x * 64) {
         float s = 0.f;
-        for (int p = 0; p < Pi; ++p) s += partial[(size_t)p * count + i];
-        dw[i] = accumulate ? dw[i] + s : s;
+        if (i < count) {
+            // input-channel columns >= split belong to the remainder block, which wrote P_rem partitions
+            const int Pi = (i % cin_taps) >= split ? P_rem : P;
+            const float* src = partial + i;
+            int p = k;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            for (; p + 12 < Pi; p += 16) {
+                s0 += src[(size_t)p * count];
+                s1 += src[(size_t)(p + 4) * count];
+                s2 += src[(size_t)(p + 8) * count];
+                s3 += src[(size_t)(p + 12) * count];
+            }
+            for (; p < Pi; p += 4) s0 += src[(size_t)p * count];
+            s = (s0 + s1) + (s2 + s3);
+        }
+        // lanes 4e .. 4e+3 hold the four strided sums of element e
+        const float a = s + san_dpp_get<0xB1, 0xf>(s);      // quad_perm [1,0,3,2]: (0+1), (2+3)
+        const float t = a + san_dpp_get<0x4E, 0xf>(a);      // quad_perm [2,3,0,1]: ((0+1)+(2+3))
+        if (k == 0 && i < count) dw[i] = accumulate ? dw[i] + t : t;
     }
 }
 
@@ -1050,8 +1070,8 @@ int san_conv2d_wgrad(const float* x, int x_ctot, int x_coff, int cin, const floa
 #undef SAN_WGRAD_LAUNCH
     SAN_LAUNCH_CHECK();
     const int count = cout * cin * ks * ks;
-    int blocks = san_cdiv(count, 256);
-    if (blocks > 1024) blocks = 1024;
+    int blocks = san_cdiv(count, 64);
+    if (blocks > 2048) blocks = 2048;
     const int taps = ks * ks;
     const int split = p.vec ? a.n_full * kCIB * taps : cin * taps;          // first column of the remainder block
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, partial, dw, count, p.P, accumulate, cin * taps,

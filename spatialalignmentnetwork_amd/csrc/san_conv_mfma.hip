@@ -473,6 +473,36 @@ __global__ void pack_mfma_kernel(const float* __restrict__ w, float* __restrict_
     }
 }
 
+// One pack job per blockIdx.y; the job table lives in device memory: 8 x int64 per job =
+// {w, packed, cout, cin, taps, cw, cqp, groups | transposed << 32} (built by san_conv_pack_job).
+__global__ void pack_mfma_batch_kernel(const long long* __restrict__ jobs) {
+    const long long* j = jobs + 8 * (size_t)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(j[0]);
+    float* packed = reinterpret_cast<float*>(j[1]);
+    const int cout = (int)j[2], cin = (int)j[3], taps = (int)j[4], cw = (int)j[5], cqp = (int)j[6];
+    const int groups = (int)(j[7] & 0xffffffffll), transposed = (int)(j[7] >> 32);
+    const int wrow = 4 * cqp;
+    const size_t total = (size_t)groups * cin * taps * wrow;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total + (size_t)kCK * taps * wrow;
+         i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < total) {
+            const int cq = (int)(i % cqp);
+            const int jj = (int)((i / cqp) % 4);
+            const int t = (int)((i / wrow) % taps);
+            const int ci = (int)((i / ((size_t)wrow * taps)) % cin);
+            const int g = (int)(i / ((size_t)wrow * taps * cin));
+            const int co = g * cw + 4 * cq + jj;
+            if (4 * cq < cw && co < cout) {
+                if (transposed == 1) v = w[(size_t)ci * cout + co];
+                else if (transposed == 2) v = w[((size_t)ci * cout + co) * taps + (taps - 1 - t)];
+                else v = w[((size_t)co * cin + ci) * taps + t];
+            }
+        }
+        packed[i] = v;
+    }
+}
+
 template <int CQ, int KS, int G>
 void launch_ws(const float* x, const float* wp, float* y, const MArgs& a, dim3 grid, size_t lds, int ws, hipStream_t s) {
     if (KS == 1 || ws <= 1) {
@@ -564,6 +594,45 @@ int san_conv_pack_weights_dgrad(const float* w, float* packed, int cout, int cin
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pack_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, packed, cin, cout, ks * ks,
                        cw, cqp, groups, 2);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_conv_pack_job(long long* job8, const float* w, float* packed, int cout, int cin, int ks, int mode) {
+    // mode 0: Conv2d forward [cout,cin,ks,ks]; 1: ConvTranspose2d 2x2 [cin,cout,2,2] (ks = 2);
+    // 2: Conv2d data gradient (w is the forward weight; the packed result has cout' = cin, cin' = cout)
+    SAN_CHECK_ARG(job8 && w && packed, "null pointer");
+    SAN_CHECK_ARG(cout > 0 && cin > 0, "bad dims");
+    int pc = cout, pcin = cin, taps = ks * ks;
+    if (mode == 1) {
+        SAN_CHECK_ARG(ks == 2, "transposed packing is for ConvTranspose2d 2x2 only");
+        pc = 4 * cout;
+        taps = 1;
+    } else {
+        SAN_CHECK_ARG(ks == 1 || ks == 3, "ks must be 1 or 3");
+        SAN_CHECK_ARG(mode == 0 || mode == 2, "mode must be 0, 1 or 2");
+        if (mode == 2) {
+            pc = cin;
+            pcin = cout;
+        }
+    }
+    const int cw = pick_cw(pc);
+    const int cqp = ((cw / 4) + 3) & ~3;
+    const int groups = san_cdiv(pc, cw);
+    job8[0] = (long long)(uintptr_t)w;
+    job8[1] = (long long)(uintptr_t)packed;
+    job8[2] = pc;
+    job8[3] = pcin;
+    job8[4] = taps;
+    job8[5] = cw;
+    job8[6] = cqp;
+    job8[7] = (long long)groups | ((long long)mode << 32);
+    return SAN_OK;
+}
+
+int san_conv_pack_batch(const long long* jobs_dev, int njobs, void* stream) {
+    SAN_CHECK_ARG(jobs_dev && njobs > 0, "empty job table");
+    hipLaunchKernelGGL(pack_mfma_batch_kernel, dim3(16, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -7,6 +7,7 @@ ATen compute kernel is launched on the hot path.
 from __future__ import annotations
 
 import ctypes
+import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -265,28 +266,94 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
                int(step), grad_scale, _stream())
 
 
+class _PackRegistry:
+    """Packed copies of conv weights (the layouts the MFMA kernels read).  Inference packs a weight
+    once; in training every weight changes every step, so ALL registered (weight, mode) pairs are
+    re-packed by one batched launch (san_conv_pack_batch) the first time any of them is requested
+    after an optimiser step, instead of ~650 tiny launches per step.  mode 0: Conv2d forward,
+    1: ConvTranspose2d 2x2, 2: Conv2d data gradient."""
+
+    def __init__(self):
+        self.jobs = {}          # (id(w), mode) -> job dict
+        self.table = None       # device int64 [njobs, 8]
+        self.order = []
+        self.epoch = -1
+
+    def _prune(self):
+        dead = [k for k, j in self.jobs.items() if j["wref"]() is None]
+        for k in dead:
+            del self.jobs[k]
+        if dead:
+            self.table = None
+
+    def _register(self, w: torch.Tensor, mode: int):
+        _chk(w, name="weight")
+        if mode == 1:
+            cin, cout, ks = w.shape[0], w.shape[1], w.shape[2]
+            nfl = lib().query("san_conv_packed_floats", cout, cin, ks)
+        elif mode == 2:
+            cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+            nfl = lib().query("san_conv_packed_floats", cin, cout, ks)
+        else:
+            cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
+            nfl = lib().query("san_conv_packed_floats", cout, cin, ks)
+        if len(self.jobs) >= 4096:
+            self._prune()
+        job = {"wref": weakref.ref(w), "ptr": w.data_ptr(), "mode": mode, "dims": (cout, cin, ks), "version": -1,
+               "packed": torch.empty(nfl, device=w.device, dtype=torch.float32), "device": w.device}
+        self.jobs[(id(w), mode)] = job
+        self.table = None
+        return job
+
+    def _run(self, device):
+        """Re-pack every live job on `device` in one launch."""
+        if self.table is not None and any(j["wref"]() is None for j in self.order):
+            self.table = None                   # a registered weight was freed: never read through its old pointer
+        if self.table is None or self.table.device != device:
+            self._prune()
+            self.order = [j for j in self.jobs.values() if j["device"] == device]
+            host = torch.zeros((len(self.order), 8), dtype=torch.int64)
+            row = (ctypes.c_longlong * 8)()
+            for i, j in enumerate(self.order):
+                cout, cin, ks = j["dims"]
+                lib().call("san_conv_pack_job", ctypes.c_void_p(ctypes.addressof(row)), ctypes.c_void_p(j["ptr"]),
+                           _p(j["packed"]), cout, cin, ks, j["mode"])
+                host[i] = torch.tensor(list(row), dtype=torch.int64)
+            self.table = host.to(device)
+        if self.order:
+            lib().call("san_conv_pack_batch", _p(self.table), len(self.order), _stream())
+        for j in self.order:
+            w = j["wref"]()
+            j["version"] = w._version if w is not None else -1
+        self.epoch = WEIGHT_EPOCH[0]
+
+    def _pack_one(self, job, w):
+        cout, cin, ks = job["dims"]
+        if job["mode"] == 1:
+            lib().call("san_conv_pack_weights", _p(w.detach()), _p(job["packed"]), cout, cin, ks, 1, _stream())
+        elif job["mode"] == 2:
+            lib().call("san_conv_pack_weights_dgrad", _p(w.detach()), _p(job["packed"]), cout, cin, ks, _stream())
+        else:
+            lib().call("san_conv_pack_weights_fwd", _p(w.detach()), _p(job["packed"]), cout, cin, ks, _stream())
+        job["version"] = w._version
+
+    def get(self, w: torch.Tensor, mode: int) -> torch.Tensor:
+        job = self.jobs.get((id(w), mode))
+        if job is None or job["wref"]() is not w or job["ptr"] != w.data_ptr():
+            job = self._register(w, mode)
+        if self.epoch != WEIGHT_EPOCH[0]:
+            self._run(w.device)                 # an optimiser step happened: everything is stale, one launch
+        if job["version"] != w._version:
+            self._pack_one(job, w)              # new weight, or modified in place by torch (load_state_dict, tests)
+        return job["packed"]
+
+
+PACKS = _PackRegistry()
+
+
 def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
-    """Repacked copy of a conv weight for the scalar-operand kernels, cached on
-    (storage, version) so an optimizer step invalidates it."""
-    # the cache lives ON the tensor object (so it dies with it: a data_ptr-keyed table would
-    # hand a freed layer's packing to whichever new weight the allocator puts at that address)
-    tagv = (w._version, w.data_ptr(), transposed, WEIGHT_EPOCH[0])
-    hit = getattr(w, "_san_packed", None)
-    if hit is not None and hit[0] == tagv:
-        return hit[1]
-    _chk(w, name="weight")
-    if transposed:
-        cin, cout, ks = w.shape[0], w.shape[1], w.shape[2]
-    else:
-        cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-    nfl = lib().query("san_conv_packed_floats", cout, cin, ks)
-    packed = torch.empty(nfl, device=w.device, dtype=torch.float32)
-    if transposed:
-        lib().call("san_conv_pack_weights", _p(w.detach()), _p(packed), cout, cin, ks, 1, _stream())
-    else:
-        lib().call("san_conv_pack_weights_fwd", _p(w.detach()), _p(packed), cout, cin, ks, _stream())
-    w._san_packed = (tagv, packed)
-    return packed
+    """Packed copy of a Conv2d (or, transposed, ConvTranspose2d 2x2) weight for the MFMA kernels."""
+    return PACKS.get(w, 1 if transposed else 0)
 
 
 def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: bool = False,
@@ -449,16 +516,7 @@ def smooth_pool(x: torch.Tensor, kern: torch.Tensor) -> torch.Tensor:
 # ---------------------------------------------------------------------------
 def packed_weight_dgrad(w: torch.Tensor) -> torch.Tensor:
     """Flipped / channel-swapped packing of a Conv2d weight: conv2d(dy, this) = dL/dx."""
-    tagv = (w._version, w.data_ptr(), "dgrad", WEIGHT_EPOCH[0])
-    hit = getattr(w, "_san_packed_dgrad", None)
-    if hit is not None and hit[0] == tagv:
-        return hit[1]
-    _chk(w, name="weight")
-    cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
-    packed = torch.empty(lib().query("san_conv_packed_floats", cin, cout, ks), device=w.device, dtype=torch.float32)
-    lib().call("san_conv_pack_weights_dgrad", _p(w.detach()), _p(packed), cout, cin, ks, _stream())
-    w._san_packed_dgrad = (tagv, packed)
-    return packed
+    return PACKS.get(w, 2)
 
 
 def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
