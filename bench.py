@@ -234,6 +234,15 @@ def main():
         if timer is not None:
             tot = timer.totals()
             dom = max(tot, key=lambda k: tot[k]["ms"])
+            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected in two
+            # separate rocprofv3 runs of this workload and corrected as profiles/r01_pmc_traffic.json states);
+            # bench.py itself cannot run the profiler, so this is the profile's figure, not a live one
+            pmc = {}
+            try:
+                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                                  "r01_pmc_traffic.json")))["kernels"]
+            except (OSError, KeyError, ValueError):
+                pass
             for key, field in ((dom, "roofline"), ("fft_dc", "roofline_fft_dc")):
                 if key not in tot:
                     continue
@@ -244,7 +253,11 @@ def main():
                 else:
                     ach, peak, unit, bound = d["work"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
                 out[field] = {"kernel": key, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                              "frac": ach / peak, "traffic": None, "launches": d["launches"],
+                              "frac": ach / peak,
+                              "traffic": (pmc.get(key) or {}).get("hbm_bytes_per_launch") if args.mode == "train" and
+                              (n, h, args.cascades) == (8, 320, 12) else None,
+                              "traffic_source": "profiles/r01_pmc_traffic.json" if key in pmc else None,
+                              "launches": d["launches"],
                               "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                               "share_of_step": d["ms"] / (1e3 * dt)}
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
