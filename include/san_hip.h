@@ -86,6 +86,20 @@ int san_sens_expand_dc(const float* r_planar, const float* sens, const float* k,
                        const float* mask, const float* dc_w, float* k_out, int n, int c, int h, int w,
                        void* ws, size_t ws_bytes, void* stream);
 
+/* The same two calls with the cascade boundary fused: san_sens_expand_dc_next additionally writes
+ * next_cols [n,c,h,w] complex = the (unnormalised) inverse column transform of k_out, i.e. the
+ * first pass of the NEXT cascade's sens_reduce (varnet.py:511 right after :530), computed while
+ * k_out is still in registers; san_sens_reduce_from_cols consumes it and runs only the row pass.
+ * Results are identical to san_sens_expand_dc followed by san_sens_reduce. */
+int san_sens_expand_dc_next(const float* r_planar, const float* sens, const float* k, const float* k0,
+                            const float* mask, const float* dc_w, float* k_out, float* next_cols,
+                            int n, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
+int san_sens_reduce_from_cols(const float* k_cols, const float* sens, float* out_planar, int out_ctot,
+                              int n, int c, int h, int w, void* ws, size_t ws_bytes, void* stream);
+/* san_ifft2_rss (varnet.py:486) on the same precomputed column transform. */
+int san_ifft2_rss_from_cols(const float* k_cols, float* out, int n, int c, int h, int w,
+                            void* ws, size_t ws_bytes, void* stream);
+
 /* out[n,0] = sqrt(sum_c |ifft2(k[n,c])|^2)   (real [n,1,h,w]).
  * Replaces rss(ifft2(kspace_pred)) (varnet.py:486). */
 int san_ifft2_rss(const float* k, float* out, int n, int c, int h, int w,

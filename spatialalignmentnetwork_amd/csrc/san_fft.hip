@@ -29,7 +29,7 @@ constexpr int kMaxRad = 12;
 
 enum RowPro { RP_NONE = 0, RP_PLANAR_MUL_SENS = 1 };
 enum RowEpi { RE_STORE = 0, RE_STORE_PLANAR = 1, RE_CONJ_SENS_SUM_PLANAR = 2, RE_RSS = 3 };
-enum ColEpi { CE_STORE = 0, CE_DC = 1 };
+enum ColEpi { CE_STORE = 0, CE_DC = 1, CE_DC_NEXT = 2 };   // _NEXT: also the next cascade's inverse column pass
 
 struct FftArgs {
     const float2* in;
@@ -40,6 +40,7 @@ struct FftArgs {
     const float2* k0;        // CE_DC
     const float* mask;       // CE_DC: [W]
     const float* dcw;        // CE_DC: 1 float
+    float2* out2;            // CE_DC_NEXT: inverse column transform of the DC result (the next sens_reduce's first pass)
     float* out_real;         // planar / rss output
     const float* cm_in;      // optional column mask on load  [W]
     const float* cm_out;     // optional column mask on store [W]
@@ -521,7 +522,11 @@ __device__ __forceinline__ void fft320_core(float2 (&in)[5][4], float2 (&out)[4]
     }
 }
 
-// rows: grid (H/4, outer); plane = outer*inner + l
+// rows: grid (H/4, outer); plane = outer*inner + l.  PRO / EPI are compile-time so the load and
+// store sections are straight-line code: every global load of a wave is issued before the first
+// one is consumed (rows past H are clamped and zeroed by a select, not skipped by a branch --
+// a branchy prologue made the planar-x-S variant 8 us slower than the plain one).
+template <int PRO, int EPI>
 __global__ void __launch_bounds__(64) fft320_rows_kernel(const FftArgs a) {
     __shared__ float2 lds[kL320 * kP320];
     __shared__ float2 tws[kN320];          // LDS-staged twiddles: passes B, C, D read them with LDS latency
@@ -539,58 +544,68 @@ __global__ void __launch_bounds__(64) fft320_rows_kernel(const FftArgs a) {
 
     for (int l = 0; l < a.inner; ++l) {
         const int plane = outer * a.inner + l;
-        const size_t base = ((size_t)plane * H + h0) * W;
+        const size_t pbase = (size_t)plane * H * W;
         float2 in[5][4], out[4][5];
         if (l > 0) __syncthreads();
         // ---- pass-A inputs straight from global: butterfly b = lane + 64 t -> row b/80, j = b%80
+        float2 sin[5][4];
+        float pre[5][4], pim[5][4];
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            int line, j;
+            Map320<0>::r4(lane, t, line, j);
+            const int row = min(h0 + line, H - 1);
+            const int e = row * W + j;                        // in-plane offset (H * W < 2^31)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (PRO == RP_NONE) {
+                    in[t][r] = a.in[pbase + e + 80 * r];
+                } else {                                      // planar r [n,2,H,W] times S[n,c]
+                    const int n = plane / a.C;
+                    const float* rp = a.in_planar + (size_t)n * 2 * H * W;
+                    pre[t][r] = rp[e + 80 * r];
+                    pim[t][r] = rp[e + 80 * r + H * W];
+                    sin[t][r] = a.sens[pbase + e + 80 * r];
+                }
+            }
+        }
+        // epilogue operands are requested BEFORE the transform so their latency hides under it
+        float2 sv[4][5];
+        if (EPI == RE_CONJ_SENS_SUM_PLANAR) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 5; ++r) sv[t][r] = a.sens[pbase + (size_t)min(h0 + t, H - 1) * W + lane + 64 * r];
+        }
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
             int line, j;
             Map320<0>::r4(lane, t, line, j);
             const bool ok = (h0 + line) < H;
-            const size_t e = base + (size_t)line * W + j;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float2 v = make_float2(0.f, 0.f);
-                if (ok) {
-                    if (a.pro == RP_NONE) {
-                        v = a.in[e + 80 * r];
-                    } else {   // planar r [n,2,H,W] times S[n,c]
-                        const int n = plane / a.C;
-                        const size_t re = ((size_t)n * 2 * H + h0 + line) * W + j + 80 * r;
-                        v = cmul(make_float2(a.in_planar[re], a.in_planar[re + (size_t)H * W]), a.sens[e + 80 * r]);
-                    }
-                }
-                in[t][r] = v;
+                if (PRO != RP_NONE) in[t][r] = cmul(make_float2(pre[t][r], pim[t][r]), sin[t][r]);
+                if (!ok) in[t][r] = make_float2(0.f, 0.f);
             }
-        }
-        // epilogue operands are requested BEFORE the transform so their latency hides under it
-        float2 sv[4][5];
-        if (a.epi == RE_CONJ_SENS_SUM_PLANAR) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 5; ++r)
-                    sv[t][r] = (h0 + t < H) ? a.sens[base + (size_t)t * W + lane + 64 * r] : make_float2(0.f, 0.f);
         }
         fft320_core<0>(in, out, lds, tws, a.sgn, lane);
         // ---- outputs: row t, element lane + 64 r
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (h0 + t >= H) continue;
-            const size_t e = base + (size_t)t * W + lane;
+            const size_t e = pbase + (size_t)(h0 + t) * W + lane;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const float2 v = out[t][r];
-                if (a.epi == RE_STORE) {
+                if (EPI == RE_STORE) {
                     float s = a.scale;
                     if (a.cm_out) s *= a.cm_out[lane + 64 * r];
                     a.out[e + 64 * r] = make_float2(v.x * s, v.y * s);
-                } else if (a.epi == RE_STORE_PLANAR) {
+                } else if (EPI == RE_STORE_PLANAR) {
                     const size_t pe = ((size_t)plane * a.out_ctot * H + h0 + t) * W + lane + 64 * r;
                     a.out_real[pe] = v.x * a.scale;
                     a.out_real[pe + (size_t)H * W] = v.y * a.scale;
-                } else if (a.epi == RE_CONJ_SENS_SUM_PLANAR) {
+                } else if (EPI == RE_CONJ_SENS_SUM_PLANAR) {
                     const float2 s = sv[t][r];
                     acc[t][r].x += v.x * s.x + v.y * s.y;
                     acc[t][r].y += v.y * s.x - v.x * s.y;
@@ -600,13 +615,13 @@ __global__ void __launch_bounds__(64) fft320_rows_kernel(const FftArgs a) {
             }
         }
     }
-    if (a.epi == RE_CONJ_SENS_SUM_PLANAR || a.epi == RE_RSS) {
+    if (EPI == RE_CONJ_SENS_SUM_PLANAR || EPI == RE_RSS) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (h0 + t >= H) continue;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                if (a.epi == RE_RSS) {
+                if (EPI == RE_RSS) {
                     a.out_real[((size_t)outer * H + h0 + t) * W + lane + 64 * r] = sqrtf(acc[t][r].x) * a.scale;
                 } else {
                     const size_t pe = ((size_t)outer * a.out_ctot * H + h0 + t) * W + lane + 64 * r;
@@ -619,6 +634,7 @@ __global__ void __launch_bounds__(64) fft320_rows_kernel(const FftArgs a) {
 }
 
 // columns: grid (W/4, planes); transform along H == 320
+template <int EPI>
 __global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
     __shared__ float2 lds[kL320 * kP320];
     __shared__ float2 tws[kN320];
@@ -628,61 +644,94 @@ __global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
     const int W = a.W;
     const int w0 = blockIdx.x * kL320;
     const int plane = blockIdx.y;
-    const size_t base = (size_t)plane * kN320 * W + w0;
     const int c = lane & 3;
     const bool ok = (w0 + c) < W;
+    const size_t base = (size_t)plane * kN320 * W + min(w0 + c, W - 1);      // clamped column: loads are unconditional
     float2 in[5][4], out[4][5];
-    float cm = 1.f;
-    if (a.cm_in && ok) cm = a.cm_in[w0 + c];
+    float cm = ok ? 1.f : 0.f;
+    if (a.cm_in) cm *= a.cm_in[min(w0 + c, W - 1)];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
         int line, j;
         Map320<1>::r4(lane, t, line, j);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float2 v = make_float2(0.f, 0.f);
-            if (ok) v = a.in[base + (size_t)(j + 80 * r) * W + c];
-            in[t][r] = make_float2(v.x * cm, v.y * cm);
-        }
+        for (int r = 0; r < 4; ++r) in[t][r] = a.in[base + (size_t)(j + 80 * r) * W];
     }
     // soft-DC operands are requested BEFORE the transform so their latency hides under it
     float2 kv[4][5], k0v[4][5];
     float dcw = 0.f, m = 0.f;
-    if (a.epi == CE_DC) {
+    if (EPI != CE_STORE) {
         dcw = a.dcw[0];
-        m = ok ? a.mask[w0 + c] : 0.f;
+        m = a.mask[min(w0 + c, W - 1)];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             int line, j;
             Map320<1>::r5(lane, t, line, j);
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                const size_t idx = base + (size_t)(j + 64 * r) * W + c;
-                kv[t][r] = ok ? a.k[idx] : make_float2(0.f, 0.f);
-                k0v[t][r] = ok ? a.k0[idx] : make_float2(0.f, 0.f);
+                const size_t idx = base + (size_t)(j + 64 * r) * W;
+                kv[t][r] = a.k[idx];
+                k0v[t][r] = a.k0[idx];
             }
         }
     }
+#pragma unroll
+    for (int t = 0; t < 5; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) in[t][r] = make_float2(in[t][r].x * cm, in[t][r].y * cm);
     fft320_core<1>(in, out, lds, tws, a.sgn, lane);
-    if (!ok) return;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         int line, j;
         Map320<1>::r5(lane, t, line, j);
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
-            const size_t idx = base + (size_t)(j + 64 * r) * W + c;
+            const size_t idx = base + (size_t)(j + 64 * r) * W;
             float2 R = out[t][r];
             R.x *= a.scale;
             R.y *= a.scale;
-            if (a.epi == CE_STORE) {
-                a.out[idx] = R;
+            if (EPI == CE_STORE) {
+                if (ok) a.out[idx] = R;
             } else {
                 const float2 kk = kv[t][r];
                 const float2 k0 = k0v[t][r];
                 const float2 dc = make_float2((kk.x - k0.x) * m * dcw, (kk.y - k0.y) * m * dcw);
-                a.out[idx] = make_float2((kk.x - dc.x) - R.x, (kk.y - dc.y) - R.y);
+                R = make_float2((kk.x - dc.x) - R.x, (kk.y - dc.y) - R.y);
+                if (ok) a.out[idx] = R;
+                out[t][r] = ok ? R : make_float2(0.f, 0.f);
             }
+        }
+    }
+    if (EPI == CE_DC_NEXT) {
+        // The next cascade starts with the inverse column transform of exactly these columns
+        // (sens_reduce, varnet.py:511): run it here while k' is still in registers instead of
+        // re-reading it from HBM in a separate launch.  One LDS exchange converts the radix-5
+        // output layout (element j + 64 r) into the pass-A input layout (element j + 80 r).
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int line, j;
+            Map320<1>::r5(lane, t, line, j);
+#pragma unroll
+            for (int r = 0; r < 5; ++r) lds[line * kP320 + j + 64 * r] = out[t][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            int line, j;
+            Map320<1>::r4(lane, t, line, j);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) in[t][r] = lds[line * kP320 + j + 80 * r];
+        }
+        __syncthreads();
+        fft320_core<1>(in, out, lds, tws, -a.sgn, lane);
+        if (!ok) return;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int line, j;
+            Map320<1>::r5(lane, t, line, j);
+#pragma unroll
+            for (int r = 0; r < 5; ++r) a.out2[base + (size_t)(j + 64 * r) * W] = out[t][r];
         }
     }
 }
@@ -805,7 +854,24 @@ size_t lds_bytes(const FftArgs& a) { return sizeof(float2) * ((size_t)a.len + 2 
 
 int launch_rows(FftArgs& a, int outer, hipStream_t s) {
     if (a.len == kN320 && a.W == kN320) {
-        hipLaunchKernelGGL(fft320_rows_kernel, dim3(san_cdiv(a.H, kL320), outer), dim3(64), 0, s, a);
+        const dim3 grid(san_cdiv(a.H, kL320), outer);
+#define SAN_ROWS320(P, E) hipLaunchKernelGGL((fft320_rows_kernel<P, E>), grid, dim3(64), 0, s, a)
+        if (a.pro == RP_NONE) {
+            switch (a.epi) {
+                case RE_STORE: SAN_ROWS320(RP_NONE, RE_STORE); break;
+                case RE_STORE_PLANAR: SAN_ROWS320(RP_NONE, RE_STORE_PLANAR); break;
+                case RE_CONJ_SENS_SUM_PLANAR: SAN_ROWS320(RP_NONE, RE_CONJ_SENS_SUM_PLANAR); break;
+                default: SAN_ROWS320(RP_NONE, RE_RSS); break;
+            }
+        } else {
+            switch (a.epi) {
+                case RE_STORE: SAN_ROWS320(RP_PLANAR_MUL_SENS, RE_STORE); break;
+                case RE_STORE_PLANAR: SAN_ROWS320(RP_PLANAR_MUL_SENS, RE_STORE_PLANAR); break;
+                case RE_CONJ_SENS_SUM_PLANAR: SAN_ROWS320(RP_PLANAR_MUL_SENS, RE_CONJ_SENS_SUM_PLANAR); break;
+                default: SAN_ROWS320(RP_PLANAR_MUL_SENS, RE_RSS); break;
+            }
+        }
+#undef SAN_ROWS320
         SAN_LAUNCH_CHECK();
         return SAN_OK;
     }
@@ -831,7 +897,13 @@ int launch_rows(FftArgs& a, int outer, hipStream_t s) {
 
 int launch_cols(FftArgs& a, int planes, hipStream_t s) {
     if (a.len == kN320 && a.H == kN320) {
-        hipLaunchKernelGGL(fft320_cols_kernel, dim3(san_cdiv(a.W, kL320), planes), dim3(64), 0, s, a);
+        const dim3 grid(san_cdiv(a.W, kL320), planes);
+        if (a.epi == CE_DC_NEXT)
+            hipLaunchKernelGGL((fft320_cols_kernel<CE_DC_NEXT>), grid, dim3(64), 0, s, a);
+        else if (a.epi == CE_DC)
+            hipLaunchKernelGGL((fft320_cols_kernel<CE_DC>), grid, dim3(64), 0, s, a);
+        else
+            hipLaunchKernelGGL((fft320_cols_kernel<CE_STORE>), grid, dim3(64), 0, s, a);
         SAN_LAUNCH_CHECK();
         return SAN_OK;
     }
@@ -949,8 +1021,9 @@ int san_fft2(const float* in, float* out, int planes, int h, int w, int inverse,
     return launch_rows(a, planes, s);
 }
 
-int san_sens_reduce(const float* k, const float* sens, float* out_planar, int out_ctot, int n, int c, int h, int w,
-                    void* ws, size_t ws_bytes, void* stream) {
+// cols_done != 0: `k` already holds the inverse column transform (written by san_sens_expand_dc_next)
+static int sens_reduce_impl(const float* k, const float* sens, float* out_planar, int out_ctot, int n, int c, int h, int w,
+                            void* ws, size_t ws_bytes, int cols_done, void* stream) {
     int r = common_checks(k, out_planar, n * c, h, w, ws, ws_bytes);
     if (r) return r;
     SAN_CHECK_ARG(sens != nullptr, "sens is null");
@@ -959,16 +1032,18 @@ int san_sens_reduce(const float* k, const float* sens, float* out_planar, int ou
     if ((r = get_plan(h, &ph))) return r;
     if ((r = get_plan(w, &pw))) return r;
     hipStream_t s = (hipStream_t)stream;
-    FftArgs cargs = base_args(c, h, w);
-    fill_pass(cargs, ph);
-    cargs.in = (const float2*)k;
-    cargs.out = (float2*)ws;
-    cargs.sgn = -1.f;
-    cargs.epi = CE_STORE;
-    if ((r = launch_cols(cargs, n * c, s))) return r;
+    if (!cols_done) {
+        FftArgs cargs = base_args(c, h, w);
+        fill_pass(cargs, ph);
+        cargs.in = (const float2*)k;
+        cargs.out = (float2*)ws;
+        cargs.sgn = -1.f;
+        cargs.epi = CE_STORE;
+        if ((r = launch_cols(cargs, n * c, s))) return r;
+    }
     FftArgs a = base_args(c, h, w);
     fill_pass(a, pw);
-    a.in = (const float2*)ws;
+    a.in = cols_done ? (const float2*)k : (const float2*)ws;
     a.sens = (const float2*)sens;
     a.out_real = out_planar;
     a.out_ctot = out_ctot;
@@ -980,9 +1055,19 @@ int san_sens_reduce(const float* k, const float* sens, float* out_planar, int ou
     return launch_rows(a, n, s);
 }
 
-int san_sens_expand_dc(const float* r_planar, const float* sens, const float* k, const float* k0,
-                       const float* mask, const float* dc_w, float* k_out, int n, int c, int h, int w, void* ws,
-                       size_t ws_bytes, void* stream) {
+int san_sens_reduce(const float* k, const float* sens, float* out_planar, int out_ctot, int n, int c, int h, int w,
+                    void* ws, size_t ws_bytes, void* stream) {
+    return sens_reduce_impl(k, sens, out_planar, out_ctot, n, c, h, w, ws, ws_bytes, 0, stream);
+}
+
+int san_sens_reduce_from_cols(const float* k_cols, const float* sens, float* out_planar, int out_ctot, int n, int c,
+                              int h, int w, void* ws, size_t ws_bytes, void* stream) {
+    return sens_reduce_impl(k_cols, sens, out_planar, out_ctot, n, c, h, w, ws, ws_bytes, 1, stream);
+}
+
+static int sens_expand_dc_impl(const float* r_planar, const float* sens, const float* k, const float* k0,
+                               const float* mask, const float* dc_w, float* k_out, float* next_cols, int n, int c, int h,
+                               int w, void* ws, size_t ws_bytes, void* stream) {
     int r = common_checks(r_planar, k_out, n * c, h, w, ws, ws_bytes);
     if (r) return r;
     SAN_CHECK_ARG(sens && k && k0 && mask && dc_w, "null input");
@@ -1009,28 +1094,55 @@ int san_sens_expand_dc(const float* r_planar, const float* sens, const float* k,
     cargs.dcw = dc_w;
     cargs.sgn = 1.f;
     cargs.scale = (float)(1.0 / std::sqrt((double)h * (double)w));
-    cargs.epi = CE_DC;
-    return launch_cols(cargs, n * c, s);
+    const bool fuse = next_cols != nullptr && h == kN320;           // the register-resident column kernel
+    cargs.epi = fuse ? CE_DC_NEXT : CE_DC;
+    cargs.out2 = (float2*)next_cols;
+    if ((r = launch_cols(cargs, n * c, s))) return r;
+    if (next_cols && !fuse) {                                         // other sizes: the same result in a second launch
+        FftArgs nx = base_args(c, h, w);
+        fill_pass(nx, ph);
+        nx.in = (const float2*)k_out;
+        nx.out = (float2*)next_cols;
+        nx.sgn = -1.f;
+        nx.epi = CE_STORE;
+        return launch_cols(nx, n * c, s);
+    }
+    return SAN_OK;
 }
 
-int san_ifft2_rss(const float* k, float* out, int n, int c, int h, int w, void* ws, size_t ws_bytes,
-                  void* stream) {
+int san_sens_expand_dc(const float* r_planar, const float* sens, const float* k, const float* k0,
+                       const float* mask, const float* dc_w, float* k_out, int n, int c, int h, int w, void* ws,
+                       size_t ws_bytes, void* stream) {
+    return sens_expand_dc_impl(r_planar, sens, k, k0, mask, dc_w, k_out, nullptr, n, c, h, w, ws, ws_bytes, stream);
+}
+
+int san_sens_expand_dc_next(const float* r_planar, const float* sens, const float* k, const float* k0,
+                            const float* mask, const float* dc_w, float* k_out, float* next_cols, int n, int c, int h,
+                            int w, void* ws, size_t ws_bytes, void* stream) {
+    SAN_CHECK_ARG(next_cols != nullptr, "next_cols is null");
+    return sens_expand_dc_impl(r_planar, sens, k, k0, mask, dc_w, k_out, next_cols, n, c, h, w, ws, ws_bytes, stream);
+}
+
+static int ifft2_rss_impl(const float* k, float* out, int n, int c, int h, int w, void* ws, size_t ws_bytes,
+                          int cols_done, void* stream) {
     int r = common_checks(k, out, n * c, h, w, ws, ws_bytes);
     if (r) return r;
     Plan ph, pw;
     if ((r = get_plan(h, &ph))) return r;
     if ((r = get_plan(w, &pw))) return r;
     hipStream_t s = (hipStream_t)stream;
-    FftArgs cargs = base_args(c, h, w);
-    fill_pass(cargs, ph);
-    cargs.in = (const float2*)k;
-    cargs.out = (float2*)ws;
-    cargs.sgn = -1.f;
-    cargs.epi = CE_STORE;
-    if ((r = launch_cols(cargs, n * c, s))) return r;
+    if (!cols_done) {
+        FftArgs cargs = base_args(c, h, w);
+        fill_pass(cargs, ph);
+        cargs.in = (const float2*)k;
+        cargs.out = (float2*)ws;
+        cargs.sgn = -1.f;
+        cargs.epi = CE_STORE;
+        if ((r = launch_cols(cargs, n * c, s))) return r;
+    }
     FftArgs a = base_args(c, h, w);
     fill_pass(a, pw);
-    a.in = (const float2*)ws;
+    a.in = cols_done ? (const float2*)k : (const float2*)ws;
     a.out_real = out;
     a.sgn = -1.f;
     a.scale = (float)(1.0 / std::sqrt((double)h * (double)w));
@@ -1038,6 +1150,16 @@ int san_ifft2_rss(const float* k, float* out, int n, int c, int h, int w, void* 
     a.pro = RP_NONE;
     a.epi = RE_RSS;
     return launch_rows(a, n, s);
+}
+
+int san_ifft2_rss(const float* k, float* out, int n, int c, int h, int w, void* ws, size_t ws_bytes,
+                  void* stream) {
+    return ifft2_rss_impl(k, out, n, c, h, w, ws, ws_bytes, 0, stream);
+}
+
+int san_ifft2_rss_from_cols(const float* k_cols, float* out, int n, int c, int h, int w, void* ws, size_t ws_bytes,
+                            void* stream) {
+    return ifft2_rss_impl(k_cols, out, n, c, h, w, ws, ws_bytes, 1, stream);
 }
 
 }  // extern "C"

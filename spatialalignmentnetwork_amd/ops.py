@@ -183,38 +183,49 @@ def ifft2c_planar(x: torch.Tensor, colmask_in: Optional[torch.Tensor], out: torc
     return out
 
 
-def sens_reduce(k: torch.Tensor, sens: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """sum_c ifft2(k)*conj(sens) -> channels 0,1 of real ``out`` [N, ctot, H, W]."""
+def sens_reduce(k: torch.Tensor, sens: torch.Tensor, out: torch.Tensor, cols: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum_c ifft2(k)*conj(sens) -> channels 0,1 of real ``out`` [N, ctot, H, W].  ``cols``: the inverse
+    column transform of k if the previous sens_expand_dc already produced it (then only the row pass runs)."""
     n, c, h, w = k.shape
     _chk(out, name="out")
     ws = fft_workspace(n * c, h, w, k.device)
-    args = (_p(_creal(k, "k")), _p(_creal(sens, "sens")), _p(out), int(out.shape[1]), n, c, h, w, _p(ws), ws.numel() * 4,
+    src = k if cols is None else cols
+    args = (_p(_creal(src, "k")), _p(_creal(sens, "sens")), _p(out), int(out.shape[1]), n, c, h, w, _p(ws), ws.numel() * 4,
             _stream())
+    fn = "san_sens_reduce" if cols is None else "san_sens_reduce_from_cols"
     # algorithmic bytes: read k and S (C planes each), write m (1 plane); E = H*W*8
-    _timed("fft_dc", float((2 * c + 1) * n * h * w * 8), "B", lambda: lib().call("san_sens_reduce", *args))
+    _timed("fft_dc", float((2 * c + 1) * n * h * w * 8), "B", lambda: lib().call(fn, *args))
     return out
 
 
 def sens_expand_dc(r_planar: torch.Tensor, sens: torch.Tensor, k: torch.Tensor, k0: torch.Tensor,
-                   mask: torch.Tensor, dc_w: torch.Tensor, k_out: torch.Tensor) -> torch.Tensor:
+                   mask: torch.Tensor, dc_w: torch.Tensor, k_out: torch.Tensor,
+                   next_cols: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """k_out = k - dc_w*mask*(k - k0) - fft2(r*S).  ``next_cols`` (complex, like k_out): also receives the
+    inverse column transform of k_out, the first pass of the next cascade's sens_reduce / of ifft2_rss."""
     n, c, h, w = k.shape
     _chk(r_planar, name="r_planar")
     assert r_planar.shape == (n, 2, h, w)
     ws = fft_workspace(n * c, h, w, k.device)
-    args = (_p(r_planar), _p(_creal(sens, "sens")), _p(_creal(k, "k")), _p(_creal(k0, "k0")),
-            _p(_chk(mask, name="mask")), _p(_chk(dc_w, name="dc_w")), _p(_creal(k_out, "k_out")), n, c, h, w,
-            _p(ws), ws.numel() * 4, _stream())
+    head = (_p(r_planar), _p(_creal(sens, "sens")), _p(_creal(k, "k")), _p(_creal(k0, "k0")),
+            _p(_chk(mask, name="mask")), _p(_chk(dc_w, name="dc_w")), _p(_creal(k_out, "k_out")))
+    tail = (n, c, h, w, _p(ws), ws.numel() * 4, _stream())
+    if next_cols is None:
+        fn, args = "san_sens_expand_dc", head + tail
+    else:
+        fn, args = "san_sens_expand_dc_next", head + (_p(_creal(next_cols, "next_cols")),) + tail
     # algorithmic bytes: read r (1 plane), S, k, k0 (C planes each), write k' (C planes)
-    _timed("fft_dc", float((4 * c + 1) * n * h * w * 8), "B", lambda: lib().call("san_sens_expand_dc", *args))
+    _timed("fft_dc", float((4 * c + 1) * n * h * w * 8), "B", lambda: lib().call(fn, *args))
     return k_out
 
 
-def ifft2_rss(k: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def ifft2_rss(k: torch.Tensor, out: Optional[torch.Tensor] = None, cols: Optional[torch.Tensor] = None) -> torch.Tensor:
     n, c, h, w = k.shape
     if out is None:
         out = torch.empty((n, 1, h, w), device=k.device, dtype=torch.float32)
     ws = fft_workspace(n * c, h, w, k.device)
-    lib().call("san_ifft2_rss", _p(_creal(k, "k")), _p(_chk(out, name="out")), n, c, h, w, _p(ws), ws.numel() * 4, _stream())
+    src, fn = (k, "san_ifft2_rss") if cols is None else (cols, "san_ifft2_rss_from_cols")
+    lib().call(fn, _p(_creal(src, "k")), _p(_chk(out, name="out")), n, c, h, w, _p(ws), ws.numel() * 4, _stream())
     return out
 
 

@@ -450,12 +450,15 @@ class VarNetBlock(nn.Module):
         return torch.complex(out[:, 0:1], out[:, 1:2])
 
     def run(self, k: torch.Tensor, k0: torch.Tensor, mask_f: torch.Tensor, sens: torch.Tensor, xin: Act,
-            k_out: torch.Tensor, key: str) -> torch.Tensor:
+            k_out: torch.Tensor, key: str, k_cols: Optional[torch.Tensor] = None,
+            next_cols: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """k_cols: inverse column transform of k left behind by the previous cascade (skips this
+        cascade's first FFT pass); next_cols: buffer that receives the same for k_out."""
         n, c, h, w = k.shape
-        ops.sens_reduce(k, sens, xin.buf)
+        ops.sens_reduce(k, sens, xin.buf, cols=k_cols)
         r = ARENA.get(f"{key}.r", (n, 2, h, w), k.device)
         self.model.run(xin, r, key)
-        ops.sens_expand_dc(r, sens, k, k0, mask_f, self.dc_weight.detach(), k_out)
+        ops.sens_expand_dc(r, sens, k, k0, mask_f, self.dc_weight.detach(), k_out, next_cols=next_cols)
         self._tape = (k, k0, mask_f, sens, r, key)
         return k_out
 
@@ -534,9 +537,14 @@ class VarNet(nn.Module):
             if self.use_ref:
                 self.cascades[0].model.set_ref(xin, ref1)
             k_buf = ARENA.get("cas.k", (n, c, h, w), dev, dtype=torch.complex64)
+            # each cascade's DC kernel also leaves the inverse column transform of its result: the next
+            # cascade (and the final ifft2 + rss) start from it -> 3 FFT launches per cascade instead of 4
+            cols = ARENA.get("cas.cols", (n, c, h, w), dev, dtype=torch.complex64)
+            have = None
             for cascade in self.cascades:
-                k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_buf, "cas")
-            return ops.ifft2_rss(k)
+                k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_buf, "cas", k_cols=have, next_cols=cols)
+                have = cols
+            return ops.ifft2_rss(k, cols=have)
         # training: every cascade keeps its own activations and its own k-space buffers
         for j, cascade in enumerate(self.cascades):
             key = f"cas{j}"
@@ -544,8 +552,9 @@ class VarNet(nn.Module):
             if self.use_ref:
                 cascade.model.set_ref(xin, ref1)
             k_out = ARENA.get(f"{key}.kout", (n, c, h, w), dev, dtype=torch.complex64)
-            k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_out, key)
-        out = ops.ifft2_rss(k)
+            cols = ARENA.get("cas.cols", (n, c, h, w), dev, dtype=torch.complex64)
+            k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_out, key, k_cols=cols if j else None, next_cols=cols)
+        out = ops.ifft2_rss(k, cols=cols if len(self.cascades) else None)
         self._train_state = (k, out, ref, ref1)
         return out
 

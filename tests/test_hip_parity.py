@@ -563,3 +563,27 @@ def test_fused_adamw_matches_torch(S):
         # parameters are views of one flat buffer and survive as the same Parameter objects
         b = o_mine.bucket()
         assert all(b.flat_p.data_ptr() <= m.data_ptr() < b.flat_p.data_ptr() + 4 * b.total for m in mine)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 1, 320, 320), (1, 3, 320, 320), (2, 2, 48, 80), (1, 1, 320, 64)])
+def test_fused_cascade_boundary(S, n, c, h, w):
+    """san_sens_expand_dc_next + san_sens_reduce_from_cols / san_ifft2_rss_from_cols == the unfused calls (the
+    320-row case runs the fused register-resident kernel, the others the two-launch fallback).  1e-6 relative."""
+    ops = S.ops
+    k = torch.complex(philox("fc.kr", (n, c, h, w)), philox("fc.ki", (n, c, h, w)))
+    k0 = torch.complex(philox("fc.k0r", (n, c, h, w)), philox("fc.k0i", (n, c, h, w)))
+    sens = torch.complex(philox("fc.sr", (n, c, h, w)), philox("fc.si", (n, c, h, w)))
+    r = philox("fc.r", (n, 2, h, w))
+    mask = (philox("fc.m", (w,)) > 0).float()
+    dcw = torch.tensor([0.7])
+    kd, k0d, sd, rd, md, dd = g(k), g(k0), g(sens), g(r), g(mask), g(dcw)
+    ref_k = ops.sens_expand_dc(rd, sd, kd, k0d, md, dd, torch.empty_like(kd))
+    ref_m = ops.sens_reduce(ref_k, sd, torch.empty((n, 2, h, w), device=DEV))
+    ref_rss = ops.ifft2_rss(ref_k)
+    cols = torch.empty_like(kd)
+    got_k = ops.sens_expand_dc(rd, sd, kd, k0d, md, dd, torch.empty_like(kd), next_cols=cols)
+    got_m = ops.sens_reduce(got_k, sd, torch.empty((n, 2, h, w), device=DEV), cols=cols)
+    got_rss = ops.ifft2_rss(got_k, cols=cols)
+    assert torch.equal(torch.view_as_real(got_k), torch.view_as_real(ref_k))
+    assert rel_err(got_m.cpu(), ref_m.cpu()) < 1e-6
+    assert rel_err(got_rss.cpu(), ref_rss.cpu()) < 1e-6
