@@ -642,7 +642,13 @@ __global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
 #pragma unroll
     for (int r = 0; r < 5; ++r) tws[lane + 64 * r] = a.tw[lane + 64 * r];
     const int W = a.W;
-    const int w0 = blockIdx.x * kL320;
+    // XCD-aware column order: workgroups are dealt round-robin to the 8 XCDs (id % 8), and four
+    // adjacent column quads share every 128-byte line of a row; give XCD x the contiguous quads
+    // [x*nq/8, (x+1)*nq/8) so each line is filled once into ONE L2 instead of into four.
+    const int nq = gridDim.x;
+    int cq = blockIdx.x;
+    if ((nq & 7) == 0) cq = (cq & 7) * (nq >> 3) + (cq >> 3);
+    const int w0 = cq * kL320;
     const int plane = blockIdx.y;
     const int c = lane & 3;
     const bool ok = (w0 + c) < W;
