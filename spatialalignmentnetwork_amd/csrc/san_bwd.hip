@@ -286,18 +286,25 @@ __global__ void __launch_bounds__(kVT) conv_wgrad_vec_kernel(const WgradArgs a) 
     // 256 CUs: a second dispatch round costs 20-50 % here).
     int px, by, bz, Pb;
     {
-        const int id = blockIdx.x, full_ids = a.n_full * a.co_blocks * a.P;
-        if (id < full_ids) {
-            bz = id / (a.co_blocks * a.P);
-            const int r = id - bz * (a.co_blocks * a.P);
-            by = r / a.P;
-            px = r - by * a.P;
+        // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs (id % 8).  Give each XCD a
+        // contiguous run of the logical order below, in which the channel block varies fastest, so the
+        // workgroups that share a pixel partition's x tiles (same input block) and dy tiles (same output
+        // block) run on the same XCD and hit in its L2 instead of each refilling it from the fabric.
+        const int total = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        const int L = xcd * (total >> 3) + min(xcd, total & 7) + slot;
+        const int nblk = a.n_full * a.co_blocks, full_ids = nblk * a.P;
+        if (L < full_ids) {
+            px = L / nblk;
+            const int blk = L - px * nblk;
+            bz = blk / a.co_blocks;
+            by = blk - bz * a.co_blocks;
             Pb = a.P;
         } else {
-            const int r = id - full_ids;
+            const int r = L - full_ids;
             bz = a.n_full;
-            by = r / a.P_rem;
-            px = r - by * a.P_rem;
+            px = r / a.co_blocks;
+            by = r - px * a.co_blocks;
             Pb = a.P_rem;
         }
     }

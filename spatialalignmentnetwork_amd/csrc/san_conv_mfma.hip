@@ -166,11 +166,25 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
     const bool lane_ok = lane < M.GW * M.GH;
     const int lrow = lane_ok ? lane / M.GW : 0;
     const int lcol = lane_ok ? lane - lrow * M.GW : 0;
-    const int ty = blockIdx.x / M.tiles_x;
-    const int tx = blockIdx.x - ty * M.tiles_x;
+    // XCD-aware order: the 1-D grid's ids are dealt round-robin to the 8 XCDs (id % 8); each XCD gets a
+    // contiguous run of the logical order (n, tile row-major, channel group fastest), so the channel
+    // groups that read the same input tile, and neighbouring tiles that share halo rows / columns,
+    // are served by ONE L2 instead of refilling up to eight of them from the fabric.
+    const int ngrp = (M.groups + M.WC - 1) / M.WC;
+    const int ntile = M.tiles_x * M.tiles_y;
+    int lin;
+    {
+        const int total = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        lin = xcd * (total >> 3) + min(xcd, total & 7) + slot;
+    }
+    const int bgrp = lin % ngrp;
+    const int btile = (lin / ngrp) % ntile;
+    const int ty = btile / M.tiles_x;
+    const int tx = btile - ty * M.tiles_x;
     const int x0 = tx * M.TW, y0 = ty * M.TH;
-    const int n = blockIdx.z;
-    const int grp0 = blockIdx.y * M.WC;           // first output-channel group of this workgroup
+    const int n = lin / (ngrp * ntile);
+    const int grp0 = bgrp * M.WC;                 // first output-channel group of this workgroup
     const int grp = grp0 + wc;                    // wave-uniform
     const bool g_ok = grp < M.groups;
     const int H = a.H, W = a.W;
@@ -351,7 +365,7 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
         // with every value shifted by a pilot sample c (one valid output of the same channel), so
         //   mean = c + S1/n,  M2 = S2 - S1^2/n   with S1 = sum(x-c), S2 = sum((x-c)^2)
         // has no catastrophic cancellation; wave totals by DPP butterflies (wave_total), partials
-        // merged later by san_norm_finalize (Chan).  Tile index = blockIdx.x * WY + wy.
+        // merged later by san_norm_finalize (Chan).  Tile index = tile * WY + wy.
         const unsigned long long vm = __ballot(valid[0]);
         const int src_lane = vm ? (int)__ffsll((long long)vm) - 1 : 0;
         float cnt = 0.f;
@@ -383,7 +397,7 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
             const int co = grp * CW + lane;
             if (co < a.cout) {
                 const int tiles = M.tiles_x * M.tiles_y * M.WY;
-                float* o = a.part + ((size_t)(n * a.cout + co) * tiles + blockIdx.x * M.WY + wy) * 3;
+                float* o = a.part + ((size_t)(n * a.cout + co) * tiles + btile * M.WY + wy) * 3;
                 o[0] = cnt;
                 o[1] = cnt > 0.f ? my_mean : 0.f;
                 o[2] = cnt > 0.f ? my_m2 : 0.f;
@@ -528,7 +542,7 @@ void launch_g(const float* x, const float* wp, float* y, const MArgs& a, dim3 gr
 template <int KS>
 int launch_mfma(const float* x, const float* wp, float* y, const MArgs& a, hipStream_t s) {
     const MGeom& g = a.g;
-    dim3 grid(g.tiles_x * g.tiles_y, san_cdiv(g.groups, g.WC), a.N);
+    dim3 grid(g.tiles_x * g.tiles_y * san_cdiv(g.groups, g.WC) * a.N, 1, 1);
     const int taps = KS * KS;
     size_t in_fl = ((size_t)kCK * g.rows_t * g.pitch + kThreads + 3) & ~(size_t)3;
     size_t w_fl = (size_t)g.WC * kCK * taps * 4 * g.cqp;
