@@ -285,6 +285,17 @@ int san_warp_fwd(const float* img, const float* offset, float* out, float* grid_
 int san_grid_sample_fwd(const float* img, const float* grid, float* out,
                         int n, int c, int h, int w, int ho, int wo, int padding, void* stream);
 
+/* The same sampler on interleaved complex planes (img, out: [n,c,h,w] float2): real and imaginary
+ * parts sampled with one grid, as augment.py:62-63 does with two grid_sample calls. */
+int san_grid_sample_complex_fwd(const float* img, const float* grid, float* out,
+                                int n, int c, int h, int w, int ho, int wo, int padding, void* stream);
+
+/* Augmentation sampling grid (augment.py:7-48): grid [n,h,w,2] = affine_grid(affine [n,2,3],
+ * align_corners=False) (+ bicubic (A=-0.75, align_corners=False) upsample of ctrl [n,2,cg,cg] when
+ * ctrl != NULL; the reference uses cg = 9 and ctrl = (rand-0.5)*2/50).  Feed it to the samplers
+ * above with padding = 1 (reflection). */
+int san_augment_grid(const float* affine, const float* ctrl, float* grid, int n, int h, int w, int cg, void* stream);
+
 /* loss[0] = 1 - mean SSIM(x, y), 7x7 uniform valid window (ssimloss.py:11-40).
  * ws: fp32 [san_loss_workspace_floats(n, h, w)]. */
 size_t san_loss_workspace_floats(int n, int h, int w);

@@ -368,6 +368,108 @@ def warp_manual(img: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------
+# augmentation (augment.py:7-66) -- random draws are ARGUMENTS here
+# --------------------------------------------------------------------------
+
+
+def rigid_affine(r_s, t_s, dtype=torch.float32) -> torch.Tensor:
+    """[N,2,3] matrices M = T @ R (rotation r about the centre, then translation t on both axes).
+    Reference: augment.py:7-33 (built in float64 numpy, cast to the image dtype)."""
+    import numpy as np
+    mats = []
+    for r, t in zip(r_s, t_s):
+        rot = np.array([[np.cos(r), -np.sin(r), 0.0], [np.sin(r), np.cos(r), 0.0], [0.0, 0.0, 1.0]])
+        tr = np.array([[1.0, 0.0, t], [0.0, 1.0, t], [0.0, 0.0, 1.0]])
+        mats.append((tr @ rot)[:-1])
+    return torch.as_tensor(np.stack(mats, 0), dtype=dtype)
+
+
+def rigid_grid(m: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """affine_grid(M, align_corners=False): grid[n,i,j] = M_n @ (x_j, y_i, 1).  augment.py:35-38."""
+    base = identity_grid(h, w, m.dtype)[0]                               # [h, w, 2]
+    ones = torch.ones(h, w, 1, dtype=m.dtype)
+    hom = torch.cat([base, ones], dim=-1)                                # [h, w, 3]
+    return torch.einsum("nij,hwj->nhwi", m, hom)
+
+
+def _cubic_weights(t: torch.Tensor, a: float = -0.75):
+    """Cubic convolution coefficients for taps at -1, 0, +1, +2 (Keys, A = -0.75: ATen's bicubic)."""
+    def c1(x):   # |x| <= 1
+        return ((a + 2) * x - (a + 3)) * x * x + 1
+    def c2(x):   # 1 < |x| < 2
+        return ((a * x - 5 * a) * x + 8 * a) * x - 4 * a
+    return [c2(t + 1), c1(t), c1(1 - t), c2(2 - t)]
+
+
+def bicubic_upsample(x: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """F.interpolate(x, size=(h, w), mode='bicubic', align_corners=False) from first principles:
+    src = (dst + 0.5) * in/out - 0.5 (not clamped), taps floor(src)-1 .. +2 clamped to the border."""
+    n, c, hi, wi = x.shape
+    def axis(out_len, in_len):
+        src = (torch.arange(out_len, dtype=x.dtype) + 0.5) * (in_len / out_len) - 0.5
+        i0 = torch.floor(src)
+        wts = _cubic_weights(src - i0)
+        idx = [(i0 + k - 1).clamp(0, in_len - 1).long() for k in range(4)]
+        return idx, wts
+    iy, wy = axis(h, hi)
+    ix, wx = axis(w, wi)
+    out = torch.zeros(n, c, h, w, dtype=x.dtype)
+    for a_ in range(4):
+        rows = x[:, :, iy[a_], :]                                       # [n, c, h, wi]
+        for b_ in range(4):
+            out = out + rows[:, :, :, ix[b_]] * (wy[a_][:, None] * wx[b_][None, :])
+    return out
+
+
+def bspline_grid(ctrl: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """ctrl [N,2,9,9] = (rand - 0.5) * 2 / 50 -> NHWC offsets [N,h,w,2].  augment.py:40-48."""
+    return bicubic_upsample(ctrl, h, w).permute(0, 2, 3, 1).contiguous()
+
+
+def sample_reflect(img: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
+    """grid_sample(bilinear, padding_mode='reflection', align_corners=False), real input.  augment.py:60-61.
+    Reflection is about the pixel EDGES (-0.5, size-0.5), then clipped to [0, size-1]."""
+    n, c, h, w = img.shape
+    def unnorm_reflect(g, size):
+        x = ((g + 1) * size - 1) / 2
+        lo, span = -0.5, float(size)
+        x = (x - lo).abs()
+        flips = torch.floor(x / span)
+        extra = x - flips * span
+        x = torch.where(flips.long() % 2 == 0, extra + lo, span - extra + lo)
+        return x.clamp(0, size - 1)
+    ix = unnorm_reflect(grid[..., 0], w)
+    iy = unnorm_reflect(grid[..., 1], h)
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    out = torch.zeros(n, c, grid.shape[1], grid.shape[2], dtype=img.dtype)
+    flat = img.reshape(n, c, h * w)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xx, yy = x0 + dx, y0 + dy
+            wgt = (1 - (ix - xx).abs()) * (1 - (iy - yy).abs())
+            ok = (xx >= 0) & (xx <= w - 1) & (yy >= 0) & (yy <= h - 1)
+            idx = (yy.clamp(0, h - 1) * w + xx.clamp(0, w - 1)).long().reshape(n, 1, -1).expand(n, c, -1)
+            v = torch.gather(flat, 2, idx).reshape(n, c, grid.shape[1], grid.shape[2])
+            out = out + v * (wgt * ok.to(img.dtype))[:, None]
+    return out
+
+
+def augment(img: torch.Tensor, r_s=None, t_s=None, ctrl: Optional[torch.Tensor] = None,
+            grid: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """augment.py:50-66 with the random draws passed in: rigid (r_s, t_s) [+ B-spline ctrl], or a given grid."""
+    real_dtype = img.real.dtype if torch.is_complex(img) else img.dtype
+    if grid is None:
+        grid = rigid_grid(rigid_affine(r_s, t_s, real_dtype), img.shape[2], img.shape[3])
+        if ctrl is not None:
+            grid = grid + bspline_grid(ctrl.to(real_dtype), img.shape[2], img.shape[3])
+    if torch.is_complex(img):
+        out = torch.complex(sample_reflect(img.real.contiguous(), grid), sample_reflect(img.imag.contiguous(), grid))
+    else:
+        out = sample_reflect(img, grid)
+    return out, grid
+
+
+# --------------------------------------------------------------------------
 # losses
 # --------------------------------------------------------------------------
 

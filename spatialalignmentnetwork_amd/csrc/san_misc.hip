@@ -22,8 +22,18 @@ __device__ __forceinline__ float reflect_coord(float x, float lo2, float hi2) {
     return (flips & 1) ? (span - extra + mn) : (extra + mn);
 }
 
-__device__ __forceinline__ float sample_bilinear(const float* __restrict__ img, int H, int W, float gx, float gy,
-                                                 int padding) {
+__device__ __forceinline__ float2 operator*(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+__device__ __forceinline__ float2& operator+=(float2& a, float2 b) {
+    a.x += b.x;
+    a.y += b.y;
+    return a;
+}
+template <typename T> __device__ __forceinline__ T zero_of();
+template <> __device__ __forceinline__ float zero_of<float>() { return 0.f; }
+template <> __device__ __forceinline__ float2 zero_of<float2>() { return make_float2(0.f, 0.f); }
+
+template <typename T>
+__device__ __forceinline__ T sample_bilinear(const T* __restrict__ img, int H, int W, float gx, float gy, int padding) {
     float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
     float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
     if (padding == 1) {
@@ -39,7 +49,7 @@ __device__ __forceinline__ float sample_bilinear(const float* __restrict__ img, 
     const float wx0 = 1.f - wx1, wy0 = 1.f - wy1;
     const bool xin0 = x0 >= 0 && x0 < W, xin1 = x1 >= 0 && x1 < W;
     const bool yin0 = y0 >= 0 && y0 < H, yin1 = y1 >= 0 && y1 < H;
-    float v = 0.f;
+    T v = zero_of<T>();
     if (yin0 && xin0) v += img[y0 * W + x0] * (wx0 * wy0);
     if (yin0 && xin1) v += img[y0 * W + x1] * (wx1 * wy0);
     if (yin1 && xin0) v += img[y1 * W + x0] * (wx0 * wy1);
@@ -75,6 +85,78 @@ grid_sample_kernel(const float* __restrict__ img, const float* __restrict__ grid
         for (int c = 0; c < C; ++c)
             out[((size_t)n * C + c) * HWo + i] =
                 sample_bilinear(img + ((size_t)n * C + c) * H * W, H, W, g.x, g.y, padding);
+    }
+}
+
+// interleaved complex planes (the reference samples real and imaginary parts with the same grid, augment.py:62-63)
+__global__ void __launch_bounds__(kThreads)
+grid_sample_c_kernel(const float2* __restrict__ img, const float* __restrict__ grid, float2* __restrict__ out, int C,
+                     int H, int W, int HO, int WO, int padding) {
+    const int n = blockIdx.y;
+    const int HWo = HO * WO;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < HWo; i += gridDim.x * kThreads) {
+        const float2 g = *reinterpret_cast<const float2*>(grid + ((size_t)n * HWo + i) * 2);
+        for (int c = 0; c < C; ++c)
+            out[((size_t)n * C + c) * HWo + i] =
+                sample_bilinear(img + ((size_t)n * C + c) * H * W, H, W, g.x, g.y, padding);
+    }
+}
+
+// ------------------------------------------------------------- augmentation grid
+// grid[n,i,j] = M_n @ (x_j, y_i, 1) [+ bicubic upsample of the CG x CG control offsets]  (augment.py:7-48).
+// Bicubic = ATen's upsample_bicubic2d, align_corners=False: src = (dst + 0.5) * in/out - 0.5 (not
+// clamped), Keys kernel A = -0.75, taps floor(src)-1 .. +2 clamped to the border.
+__device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x3 = 2.f - t, u = 1.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * u - (A + 3.f)) * u * u + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+__global__ void __launch_bounds__(kThreads)
+augment_grid_kernel(const float* __restrict__ affine, const float* __restrict__ ctrl, float* __restrict__ grid, int H,
+                    int W, int CG) {
+    extern __shared__ float cg[];            // [2][CG][CG] of this sample
+    const int n = blockIdx.y;
+    if (ctrl) {
+        for (int i = threadIdx.x; i < 2 * CG * CG; i += kThreads) cg[i] = ctrl[(size_t)n * 2 * CG * CG + i];
+        __syncthreads();
+    }
+    const float* m = affine + (size_t)n * 6;
+    const float m00 = m[0], m01 = m[1], m02 = m[2], m10 = m[3], m11 = m[4], m12 = m[5];
+    const float sy = (float)CG / (float)H, sx = (float)CG / (float)W;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < H * W; i += gridDim.x * kThreads) {
+        const int yi = i / W, xj = i - yi * W;
+        const float bx = (float)(2 * xj + 1) / (float)W - 1.f;
+        const float by = (float)(2 * yi + 1) / (float)H - 1.f;
+        float gx = m00 * bx + m01 * by + m02;
+        float gy = m10 * bx + m11 * by + m12;
+        if (ctrl) {
+            const float srcy = ((float)yi + 0.5f) * sy - 0.5f, srcx = ((float)xj + 0.5f) * sx - 0.5f;
+            const float fy = floorf(srcy), fx = floorf(srcx);
+            float wy[4], wx[4];
+            cubic_w(srcy - fy, wy);
+            cubic_w(srcx - fx, wx);
+            float ox = 0.f, oy = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int r = min(max((int)fy - 1 + a, 0), CG - 1);
+                float rx = 0.f, ry = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int c = min(max((int)fx - 1 + b, 0), CG - 1);
+                    rx += cg[r * CG + c] * wx[b];
+                    ry += cg[CG * CG + r * CG + c] * wx[b];
+                }
+                ox += rx * wy[a];
+                oy += ry * wy[a];
+            }
+            gx += ox;
+            gy += oy;
+        }
+        *reinterpret_cast<float2*>(grid + ((size_t)n * H * W + i) * 2) = make_float2(gx, gy);
     }
 }
 
@@ -308,6 +390,28 @@ int san_grid_sample_fwd(const float* img, const float* grid, float* out, int n, 
     SAN_CHECK_ARG(padding == 0 || padding == 1, "padding must be 0 (zeros) or 1 (reflection)");
     hipLaunchKernelGGL(grid_sample_kernel, dim3(stream_blocks(ho * wo), n), dim3(kThreads), 0, (hipStream_t)stream, img,
                        grid, out, c, h, w, ho, wo, padding);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_grid_sample_complex_fwd(const float* img, const float* grid, float* out, int n, int c, int h, int w, int ho,
+                                int wo, int padding, void* stream) {
+    SAN_CHECK_ARG(img && grid && out, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "bad dims");
+    SAN_CHECK_ARG(padding == 0 || padding == 1, "padding must be 0 (zeros) or 1 (reflection)");
+    hipLaunchKernelGGL(grid_sample_c_kernel, dim3(stream_blocks(ho * wo), n), dim3(kThreads), 0, (hipStream_t)stream,
+                       (const float2*)img, grid, (float2*)out, c, h, w, ho, wo, padding);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_augment_grid(const float* affine, const float* ctrl, float* grid, int n, int h, int w, int cg, void* stream) {
+    SAN_CHECK_ARG(affine && grid, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0, "bad dims");
+    SAN_CHECK_ARG(ctrl == nullptr || (cg >= 2 && cg <= 64), "control grid size must be in [2, 64]");
+    const size_t lds = ctrl ? (size_t)2 * cg * cg * sizeof(float) : 0;
+    hipLaunchKernelGGL(augment_grid_kernel, dim3(stream_blocks(h * w), n), dim3(kThreads), lds, (hipStream_t)stream,
+                       affine, ctrl, grid, h, w, cg);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -477,6 +477,32 @@ def grid_sample(img: torch.Tensor, grid: torch.Tensor, padding: str = "zeros") -
     return out
 
 
+def grid_sample_complex(img: torch.Tensor, grid: torch.Tensor, padding: str = "zeros") -> torch.Tensor:
+    """grid_sample on a complex64 image: real and imaginary parts with one grid, one launch."""
+    _chk(grid, name="grid")
+    n, c, h, w = img.shape
+    ho, wo = grid.shape[1:3]
+    out = torch.empty((n, c, ho, wo), device=img.device, dtype=torch.complex64)
+    lib().call("san_grid_sample_complex_fwd", _p(_creal(img, "img")), _p(grid), _p(_creal(out, "out")), n, c, h, w, ho, wo,
+               0 if padding == "zeros" else 1, _stream())
+    return out
+
+
+def augment_grid(affine: torch.Tensor, ctrl: Optional[torch.Tensor], h: int, w: int) -> torch.Tensor:
+    """NHWC sampling grid = affine_grid(affine [N,2,3]) + bicubic upsample of ctrl [N,2,cg,cg] (or None)."""
+    _chk(affine, name="affine")
+    n = affine.shape[0]
+    assert tuple(affine.shape) == (n, 2, 3)
+    cg = 0
+    if ctrl is not None:
+        _chk(ctrl, name="ctrl")
+        assert ctrl.shape[0] == n and ctrl.shape[1] == 2 and ctrl.shape[2] == ctrl.shape[3]
+        cg = int(ctrl.shape[2])
+    grid = torch.empty((n, h, w, 2), device=affine.device, dtype=torch.float32)
+    lib().call("san_augment_grid", _p(affine), _p(ctrl), _p(grid), n, h, w, cg, _stream())
+    return grid
+
+
 def _loss_ws(n, h, w, device):
     return GLOBAL_ARENA.get("loss_ws", (lib().query("san_loss_workspace_floats", n, h, w),), device)
 

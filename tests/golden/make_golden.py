@@ -247,8 +247,35 @@ def make_e2e_full():
     save("e2e_full_320.npz", **out)
 
 
+def make_augment():
+    """augment.py:7-66: rigid + B-spline sampling grids and the reflection-padded bilinear resampling.
+    The reference draws its random numbers internally (np.random.uniform twice, torch.rand once); the
+    generators are seeded here and the SAME draws are reproduced below so the fixture carries them."""
+    import augment as R_aug
+    out = {}
+    for tag, shp, cplx_in in (("c24x40", (2, 1, 24, 40), True), ("r33x20", (3, 2, 33, 20), False)):
+        img = cplx("aug." + tag, shp) if cplx_in else philox("aug." + tag, shp)
+        for mode, bs in (("rigid", False), ("bspline", True)):
+            np.random.seed(1234)
+            torch.manual_seed(4321)
+            res, grid = R_aug.augment(img, rigid=True, bspline=bs)
+            np.random.seed(1234)
+            torch.manual_seed(4321)
+            r_s = np.random.uniform(-2 * np.pi * 0.005, 2 * np.pi * 0.005, shp[0])       # augment.py:10,13
+            t_s = np.random.uniform(-0.05, 0.05, shp[0])                                # augment.py:11,14
+            out[f"{tag}.{mode}.r_s"], out[f"{tag}.{mode}.t_s"] = r_s, t_s
+            if bs:
+                out[f"{tag}.{mode}.ctrl"] = ((torch.rand(shp[0], 2, 9, 9) - 0.5) * 2 / 50).numpy()   # augment.py:42-44
+            out[f"{tag}.{mode}.grid"] = npy(grid)
+            out[f"{tag}.{mode}.out"] = npy(res)
+            # re-applying a given grid (augment_PBSpline, train.py:44-52)
+            res2, _ = R_aug.augment(img, rigid=False, bspline=False, grid=grid)
+            assert torch.equal(torch.view_as_real(res2) if cplx_in else res2, torch.view_as_real(res) if cplx_in else res)
+    save("augment.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "small", "full"]
+    which = sys.argv[1:] or ["ops", "small", "full", "augment"]
     with torch.no_grad():
         if "ops" in which:
             make_ops()
@@ -256,3 +283,6 @@ if __name__ == "__main__":
         make_e2e_small()
     if "full" in which:
         make_e2e_full()
+    if "augment" in which:
+        with torch.no_grad():
+            make_augment()

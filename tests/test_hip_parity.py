@@ -587,3 +587,46 @@ def test_fused_cascade_boundary(S, n, c, h, w):
     assert torch.equal(torch.view_as_real(got_k), torch.view_as_real(ref_k))
     assert rel_err(got_m.cpu(), ref_m.cpu()) < 1e-6
     assert rel_err(got_rss.cpu(), ref_rss.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("tag,mode", [("c24x40", "rigid"), ("c24x40", "bspline"), ("r33x20", "rigid"), ("r33x20", "bspline")])
+def test_augment_grid_and_sampling_vs_reference(S, tag, mode):
+    """san_augment_grid + the reflection samplers against the reference's augment() outputs for the same random
+    draws (tests/golden/augment.npz) and against the oracle.  2e-6 abs on the grid, 5e-5 / 1e-5 abs on samples."""
+    gold = load_golden("augment.npz")
+    shp = {"c24x40": (2, 1, 24, 40), "r33x20": (3, 2, 33, 20)}[tag]
+    img = cplx(f"aug.{tag}", shp) if tag.startswith("c") else philox(f"aug.{tag}", shp)
+    from spatialalignmentnetwork_amd import augment as A
+    aff = A.rigid_affine(gold[f"{tag}.{mode}.r_s"], gold[f"{tag}.{mode}.t_s"], DEV)
+    ctrl = g(torch.from_numpy(gold[f"{tag}.{mode}.ctrl"])) if mode == "bspline" else None
+    grid = S.ops.augment_grid(aff, ctrl, shp[2], shp[3])
+    ref_grid = torch.from_numpy(gold[f"{tag}.{mode}.grid"])
+    ref_out = torch.from_numpy(gold[f"{tag}.{mode}.out"])
+    assert (grid.cpu() - ref_grid).abs().max() < 2e-6
+    out = A.sample(g(img), grid)
+    got = torch.view_as_real(out.cpu()) if torch.is_complex(out) else out.cpu()
+    assert (got - ref_out).abs().max() < 5e-5
+    out2, grid2 = A.augment(g(img), rigid=False, bspline=False, grid=g(ref_grid))
+    got2 = torch.view_as_real(out2.cpu()) if torch.is_complex(out2) else out2.cpu()
+    assert (got2 - ref_out).abs().max() < 1e-5
+    # oracle on the same grid
+    o_out, _ = S.O.augment(img, grid=ref_grid)
+    o = torch.view_as_real(o_out) if torch.is_complex(o_out) else o_out
+    assert (got2 - o).abs().max() < 1e-5
+
+
+def test_augment_random_draws_full_size(S):
+    """Full-size property checks: a zero-motion augment is the identity; the drawn grid stays within the
+    reference's ranges (|grid - identity| <= translation + rotation*sqrt(2) + 1.35/50 B-spline overshoot)."""
+    from spatialalignmentnetwork_amd import augment as A
+    n, h, w = 8, 320, 320
+    img = g(cplx("aug.full", (n, 1, h, w)))
+    ident = S.ops.augment_grid(A.rigid_affine([0.0] * n, [0.0] * n, DEV), None, h, w)
+    same = A.sample(img, ident)
+    # identity grid: ix = j up to fp32 rounding of ((2j+1)/W - 1 + 1) * W (about 2e-5 pixel at j ~ 300), times the
+    # neighbour difference of a uniform(-1, 1) image (<= 2)
+    assert (torch.view_as_real(same) - torch.view_as_real(img)).abs().max() < 1e-4
+    out, grid = A.augment(img)
+    assert out.shape == img.shape and out.dtype == img.dtype and torch.isfinite(torch.view_as_real(out)).all()
+    bound = A.TRANSLATION + A.ROTATION * 2 ** 0.5 * 1.01 + 1.35 / A.BSPLINE_SCALE
+    assert (grid - ident).abs().max().item() <= bound

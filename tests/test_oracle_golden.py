@@ -175,3 +175,26 @@ def test_e2e_small_train_and_grads(tag, shape):
         stat = state.batch_mean[pre + "."] if leaf == "running_mean" else state.batch_var_unbiased[pre + "."]
         after = 0.9 * before + 0.1 * stat.detach()
         assert torch.allclose(after, as_t(g[k]), rtol=1e-4, atol=1e-6), name
+
+
+@pytest.mark.parametrize("tag,mode", [("c24x40", "rigid"), ("c24x40", "bspline"), ("r33x20", "rigid"), ("r33x20", "bspline")])
+def test_oracle_augment_vs_reference(tag, mode):
+    """Rigid / B-spline sampling grids and the reflection-padded resampling (augment.py) against the reference's
+    outputs for the same random draws.  Tolerance 2e-6 abs on the grid (values in [-1.1, 1.1]); samples 5e-5 abs
+    through the oracle's own grid (a 1e-7 grid difference times the image slope), 1e-5 through the reference's grid."""
+    gold = load_golden("augment.npz")
+    shp = {"c24x40": (2, 1, 24, 40), "r33x20": (3, 2, 33, 20)}[tag]
+    if tag.startswith("c"):
+        img = cplx(f"aug.{tag}", shp)
+    else:
+        img = philox(f"aug.{tag}", shp)
+    ctrl = torch.from_numpy(gold[f"{tag}.{mode}.ctrl"]) if mode == "bspline" else None
+    out, grid = O.augment(img, gold[f"{tag}.{mode}.r_s"], gold[f"{tag}.{mode}.t_s"], ctrl)
+    ref_grid = torch.from_numpy(gold[f"{tag}.{mode}.grid"])
+    ref_out = torch.from_numpy(gold[f"{tag}.{mode}.out"])
+    assert (grid - ref_grid).abs().max() < 2e-6
+    got = torch.view_as_real(out) if torch.is_complex(out) else out
+    assert (got - ref_out).abs().max() < 5e-5
+    out2, _ = O.augment(img, grid=ref_grid)
+    got2 = torch.view_as_real(out2) if torch.is_complex(out2) else out2
+    assert (got2 - ref_out).abs().max() < 1e-5
