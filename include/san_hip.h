@@ -325,6 +325,11 @@ int san_gradient_loss_fwd(const float* offset, float* loss, int n, int h, int w,
 int san_conv_pack_job(long long* job8, const float* w, float* packed, int cout, int cin, int ks, int mode);
 int san_conv_pack_batch(const long long* jobs_dev, int njobs, void* stream);
 
+/* Validation metrics of an image batch (metrics.py:23-35, 55-69), one launch: out [n][4] doubles =
+ * per image { sum (gt-pred)^2, sum |gt-pred|, sum gt^2, mutual information from a bins x bins joint
+ * histogram over [0,1]^2 }.  mse / mae / nmse / psnr / mi follow on the host from these sums. */
+int san_image_metrics(const float* gt, const float* pred, double* out, int n, int hw, int bins, void* stream);
+
 /* One AdamW step over flat fp32 buffers (replaces torch.optim.AdamW(lr, weight_decay) over every
  * parameter tensor, model.py:72-87; decoupled weight decay, no amsgrad):
  *   g' = grad_scale*g;  p *= 1 - lr*wd;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;

@@ -582,6 +582,40 @@ def recon_align_forward(p_T: Params, p_R: Params, img_full: torch.Tensor, img_au
 # --------------------------------------------------------------------------
 
 
+def metric_mse(gt: torch.Tensor, pred: torch.Tensor) -> float:
+    """metrics.py:23-25."""
+    return ((gt.double() - pred.double()) ** 2).mean().item()
+
+
+def metric_mae(gt: torch.Tensor, pred: torch.Tensor) -> float:
+    """metrics.py:27-29."""
+    return (gt.double() - pred.double()).abs().mean().item()
+
+
+def metric_nmse(gt: torch.Tensor, pred: torch.Tensor) -> float:
+    """metrics.py:31-33."""
+    return (((gt.double() - pred.double()) ** 2).sum() / (gt.double() ** 2).sum()).item()
+
+
+def metric_mi(gt: torch.Tensor, pred: torch.Tensor, bins: int = 64) -> float:
+    """Mutual information from a bins x bins joint histogram over [0, 1]^2 per image, batch mean
+    (metrics.py:55-69; np.histogram2d: samples outside the range are dropped, 1.0 goes to the last bin)."""
+    import numpy as np
+    vals = []
+    for x, y in zip(gt.double().numpy(), pred.double().numpy()):
+        x, y = x.ravel(), y.ravel()
+        keep = (x >= 0) & (x <= 1) & (y >= 0) & (y <= 1)
+        bx = np.minimum(np.floor(x[keep] * bins).astype(np.int64), bins - 1)
+        by = np.minimum(np.floor(y[keep] * bins).astype(np.int64), bins - 1)
+        pxy = np.bincount(bx * bins + by, minlength=bins * bins).reshape(bins, bins).astype(np.float64)
+        pxy = pxy / (pxy.sum() + 1e-10)
+        px, py = pxy.sum(axis=1), pxy.sum(axis=0)
+        pp = px[:, None] * py[None, :]
+        nz = pxy > 0
+        vals.append(float((pxy[nz] * np.log(pxy[nz])).sum() - (pxy[nz] * np.log(pp[nz])).sum()))
+    return float(np.mean(vals))
+
+
 def psnr(gt: torch.Tensor, pred: torch.Tensor, data_range: float = 1.0) -> float:
     """One PSNR over the whole batch.  Reference: metrics.py:35-38."""
     err = ((gt.double() - pred.double()) ** 2).mean().item()

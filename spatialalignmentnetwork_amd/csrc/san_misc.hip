@@ -160,6 +160,76 @@ augment_grid_kernel(const float* __restrict__ affine, const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------- validation metrics
+// One workgroup per image: sum of squared / absolute errors, sum of gt^2 (double) and the bins x bins
+// joint histogram over [0,1]^2 in LDS (integer atomics: deterministic), from which the mutual
+// information sum xlogy(Pxy, Pxy) - xlogy(Pxy, Px*Py) is evaluated in double (metrics.py:23-35,55-69).
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = san_wave_sum_d(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(kThreads)
+image_metrics_kernel(const float* __restrict__ gt, const float* __restrict__ pred, double* __restrict__ out, int hw,
+                     int bins) {
+    extern __shared__ int hist[];                    // [bins*bins] counts, then [2*bins] doubles behind them
+    __shared__ double red[4];
+    const int n = blockIdx.x;
+    const float* g = gt + (size_t)n * hw;
+    const float* p = pred + (size_t)n * hw;
+    const int nb = bins * bins;
+    for (int i = threadIdx.x; i < nb; i += kThreads) hist[i] = 0;
+    __syncthreads();
+    double sse = 0.0, sae = 0.0, sgg = 0.0;
+    for (int i = threadIdx.x; i < hw; i += kThreads) {
+        const float a = g[i], b = p[i];
+        const double d = (double)a - (double)b;
+        sse += d * d;
+        sae += fabs(d);
+        sgg += (double)a * (double)a;
+        if (a >= 0.f && a <= 1.f && b >= 0.f && b <= 1.f) {           // np.histogram2d drops samples outside the range
+            const int ba = min((int)floorf(a * (float)bins), bins - 1); // the right edge belongs to the last bin
+            const int bb = min((int)floorf(b * (float)bins), bins - 1);
+            atomicAdd(&hist[ba * bins + bb], 1);
+        }
+    }
+    sse = block_sum_d(sse, red);
+    sae = block_sum_d(sae, red);
+    sgg = block_sum_d(sgg, red);
+    double* marg = reinterpret_cast<double*>(hist + ((nb + 1) & ~1));  // px[bins], py[bins]
+    double tot = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kThreads) tot += (double)hist[i];
+    tot = block_sum_d(tot, red) + 1e-10;
+    for (int i = threadIdx.x; i < 2 * bins; i += kThreads) {
+        double s = 0.0;
+        if (i < bins) {
+            for (int j = 0; j < bins; ++j) s += (double)hist[i * bins + j];
+        } else {
+            for (int j = 0; j < bins; ++j) s += (double)hist[j * bins + (i - bins)];
+        }
+        marg[i] = s / tot;
+    }
+    __syncthreads();
+    double mi = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kThreads) {
+        const int c = hist[i];
+        if (c > 0) {
+            const double pxy = (double)c / tot;
+            mi += pxy * log(pxy) - pxy * log(marg[i / bins] * marg[bins + i % bins]);
+        }
+    }
+    mi = block_sum_d(mi, red);
+    if (threadIdx.x == 0) {
+        out[4 * n + 0] = sse;
+        out[4 * n + 1] = sae;
+        out[4 * n + 2] = sgg;
+        out[4 * n + 3] = mi;
+    }
+}
+
 // ------------------------------------------------------------- loss windows
 // Tile of 32 x 8 outputs per workgroup; the (32+K-1) x (8+K-1) input windows of
 // both images sit in LDS; each lane slides its K x K window over LDS.
@@ -412,6 +482,16 @@ int san_augment_grid(const float* affine, const float* ctrl, float* grid, int n,
     const size_t lds = ctrl ? (size_t)2 * cg * cg * sizeof(float) : 0;
     hipLaunchKernelGGL(augment_grid_kernel, dim3(stream_blocks(h * w), n), dim3(kThreads), lds, (hipStream_t)stream,
                        affine, ctrl, grid, h, w, cg);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_image_metrics(const float* gt, const float* pred, double* out, int n, int hw, int bins, void* stream) {
+    SAN_CHECK_ARG(gt && pred && out, "null pointer");
+    SAN_CHECK_ARG(n > 0 && hw > 0, "bad dims");
+    SAN_CHECK_ARG(bins >= 2 && bins <= 128, "bins must be in [2, 128]");
+    const size_t lds = (size_t)((bins * bins + 1) & ~1) * sizeof(int) + (size_t)2 * bins * sizeof(double);
+    hipLaunchKernelGGL(image_metrics_kernel, dim3(n), dim3(kThreads), lds, (hipStream_t)stream, gt, pred, out, hw, bins);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

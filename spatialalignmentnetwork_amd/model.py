@@ -18,6 +18,7 @@ import torch
 from . import ops
 from .basemodel import BaseModel, Config  # noqa: F401
 from .cross import SpatialTransformer
+from . import metrics
 from .masks import masks
 from .optim import FusedAdamW
 from .signal_utils import rss
@@ -155,11 +156,12 @@ class CSModel(BaseModel):
             self.forwardT()
             self.loss_all = 0
             self.forwardR()
-            gt, pred = self.img_full_rss.double(), self.img_rec.double()
-            mse = ((gt - pred) ** 2).mean().item()
-            self.metric_MSE = mse
-            self.metric_MAE = (gt - pred).abs().mean().item()
-            self.metric_PSNR = 10.0 * math.log10(1.0 / mse) if mse > 0 else float("inf")   # data_range 1, whole batch
+            m = metrics.all_metrics(self.img_full_rss, self.img_rec)      # model.py:275-279, on the GPU
+            self.metric_MI = metrics.mi(self.img_full_rss, self.img_warped_rss)
+            self.metric_PSNR = m["PSNR"]
+            self.metric_SSIM = metrics.ssim(self.img_full_rss, self.img_rec)
+            self.metric_MAE = m["MAE"]
+            self.metric_MSE = m["MSE"]
         return -self.metric_PSNR
 
     def get_vis(self, content=None):

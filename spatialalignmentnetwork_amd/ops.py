@@ -503,6 +503,17 @@ def augment_grid(affine: torch.Tensor, ctrl: Optional[torch.Tensor], h: int, w: 
     return grid
 
 
+def image_metrics(gt: torch.Tensor, pred: torch.Tensor, bins: int = 64) -> torch.Tensor:
+    """[planes, 4] float64: per image sum sq err, sum abs err, sum gt^2, mutual information."""
+    _chk(gt, name="gt")
+    _chk(pred, name="pred")
+    planes = gt.shape[0] * gt.shape[1]
+    hw = gt.shape[2] * gt.shape[3]
+    out = torch.empty((planes, 4), device=gt.device, dtype=torch.float64)
+    lib().call("san_image_metrics", _p(gt), _p(pred), _p(out), planes, hw, int(bins), _stream())
+    return out
+
+
 def _loss_ws(n, h, w, device):
     return GLOBAL_ARENA.get("loss_ws", (lib().query("san_loss_workspace_floats", n, h, w),), device)
 

@@ -274,8 +274,28 @@ def make_augment():
     save("augment.npz", **out)
 
 
+def make_metrics():
+    """metrics.py:23-35,55-69: mse / mae / nmse / mutual information of image batches in [0, 1] (a few samples
+    outside the histogram range and exactly on its edges included).  psnr / ssim go through skimage, which
+    this image lacks: PSNR is 10 log10(1 / mse) by definition and SSIM is pinned through ssimloss."""
+    import metrics as R_met
+    out = {}
+    for tag, shp in (("a", (3, 1, 40, 32)), ("b", (2, 1, 64, 64))):
+        gt = philox("met.gt." + tag, shp, lo=0.0, hi=1.0)
+        pred = (gt + 0.1 * philox("met.d." + tag, shp)).clamp(-0.05, 1.05)
+        pred[0, 0, 0, :4] = torch.tensor([0.0, 1.0, 1.0 / 64, 63.0 / 64])
+        gt[0, 0, 1, :3] = torch.tensor([1.0, 0.0, 0.5])
+        out[f"{tag}.pred"] = pred.numpy()            # gt is regenerated from the Philox stream + these edits
+        out[f"{tag}.gt"] = gt.numpy()
+        out[f"{tag}.mse"] = np.float64(R_met.mse(gt, pred))
+        out[f"{tag}.mae"] = np.float64(R_met.mae(gt, pred))
+        out[f"{tag}.nmse"] = np.float64(R_met.nmse(gt, pred))
+        out[f"{tag}.mi"] = np.float64(R_met.mi(gt, pred))
+    save("metrics.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "small", "full", "augment"]
+    which = sys.argv[1:] or ["ops", "small", "full", "augment", "metrics"]
     with torch.no_grad():
         if "ops" in which:
             make_ops()
@@ -286,3 +306,5 @@ if __name__ == "__main__":
     if "augment" in which:
         with torch.no_grad():
             make_augment()
+    if "metrics" in which:
+        make_metrics()

@@ -630,3 +630,17 @@ def test_augment_random_draws_full_size(S):
     assert out.shape == img.shape and out.dtype == img.dtype and torch.isfinite(torch.view_as_real(out)).all()
     bound = A.TRANSLATION + A.ROTATION * 2 ** 0.5 * 1.01 + 1.35 / A.BSPLINE_SCALE
     assert (grid - ident).abs().max().item() <= bound
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_metrics_vs_reference(S, tag):
+    """mse / mae / nmse / mi on the GPU against the reference's metrics.py numbers; psnr by its definition;
+    ssim = 1 - ssimloss against the oracle.  1e-6 relative (double sums on device, float32 inputs)."""
+    from spatialalignmentnetwork_amd import metrics as M
+    gold = load_golden("metrics.npz")
+    gt, pred = torch.from_numpy(gold[f"{tag}.gt"]), torch.from_numpy(gold[f"{tag}.pred"])
+    for name, fn in (("mse", M.mse), ("mae", M.mae), ("nmse", M.nmse), ("mi", M.mi)):
+        ref = float(gold[f"{tag}.{name}"])
+        assert abs(fn(g(gt), g(pred)) - ref) <= 1e-6 * max(1.0, abs(ref)), name
+    assert abs(M.psnr(g(gt), g(pred)) - 10 * np.log10(1.0 / float(gold[f"{tag}.mse"]))) < 1e-5
+    assert abs(M.ssim(g(gt), g(pred)) - (1.0 - S.O.ssimloss(gt, pred).item())) < 2e-5

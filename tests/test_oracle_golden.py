@@ -198,3 +198,13 @@ def test_oracle_augment_vs_reference(tag, mode):
     out2, _ = O.augment(img, grid=ref_grid)
     got2 = torch.view_as_real(out2) if torch.is_complex(out2) else out2
     assert (got2 - ref_out).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_metrics_vs_reference(tag):
+    """mse / mae / nmse / mutual information (metrics.py) against the reference's numbers (1e-9 rel: float64)."""
+    gold = load_golden("metrics.npz")
+    gt, pred = torch.from_numpy(gold[f"{tag}.gt"]), torch.from_numpy(gold[f"{tag}.pred"])
+    for name, fn in (("mse", O.metric_mse), ("mae", O.metric_mae), ("nmse", O.metric_nmse), ("mi", O.metric_mi)):
+        ref = float(gold[f"{tag}.{name}"])
+        assert abs(fn(gt, pred) - ref) <= 1e-7 * max(1.0, abs(ref)), name     # the reference sums in float32 numpy
