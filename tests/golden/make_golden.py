@@ -294,8 +294,41 @@ def make_metrics():
     save("metrics.npz", **out)
 
 
+def make_ckpt():
+    """(1) state_dict key / shape lists of the reference's networks at the sizes CSModel hard-codes
+    (model.py:64-71) -> ckpt_keys.json; (2) a small checkpoint DIRECTORY written by the reference's own
+    basemodel.ckpt_save (config JSON + one np.savez blob per network, basemodel.py:43-55) for a small
+    VarNet / SpatialTransformer / mask, to be loaded by the build's BaseModel.load."""
+    import json
+    import shutil
+    import basemodel as R_base
+    keys = {}
+    big_R = R_varnet.VarNet(num_cascades=12, sens_chans=8, sens_pools=4, chans=18, pools=4, use_ref=True)
+    big_T = R_cross.SpatialTransformer(channels=1)
+    keys["net_R"] = [[k, list(v.shape), str(v.dtype)] for k, v in big_R.state_dict().items()]
+    keys["net_T"] = [[k, list(v.shape), str(v.dtype)] for k, v in big_T.state_dict().items()]
+    keys["net_mask"] = [[k, list(v.shape), str(v.dtype)] for k, v in R_masks.EquispacedMask(0.25, 320).state_dict().items()]
+    with open(os.path.join(HERE, "ckpt_keys.json"), "w") as f:
+        json.dump(keys, f)
+    print("wrote ckpt_keys.json:", {k: len(v) for k, v in keys.items()})
+    folder = os.path.join(HERE, "ckpt_ref_small")
+    if os.path.exists(folder):
+        shutil.rmtree(folder)
+    small_R = R_varnet.VarNet(num_cascades=2, sens_chans=2, sens_pools=2, chans=4, pools=2, use_ref=True)
+    small_T = R_cross.SpatialTransformer(channels=1)
+    load_into(small_R, 7)
+    load_into(small_T, 8)
+    mask = R_masks.EquispacedMask(0.25, 32)
+    cfg = R_base.Config(sparsity=0.25, lr=1e-4, shape=32, coils=1, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                        weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False,
+                        num_cascades=2, sens_chans=2, sens_pools=2, chans=4, pools=2)
+    R_base.ckpt_save({"config": cfg, "net_R": small_R.state_dict(), "net_T": small_T.state_dict(),
+                      "net_mask": mask.state_dict()}, folder)
+    print("wrote", folder, sorted(os.listdir(folder)), sum(os.path.getsize(os.path.join(folder, f)) for f in os.listdir(folder)) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "small", "full", "augment", "metrics"]
+    which = sys.argv[1:] or ["ops", "small", "full", "augment", "metrics", "ckpt"]
     with torch.no_grad():
         if "ops" in which:
             make_ops()
@@ -308,3 +341,5 @@ if __name__ == "__main__":
             make_augment()
     if "metrics" in which:
         make_metrics()
+    if "ckpt" in which:
+        make_ckpt()
