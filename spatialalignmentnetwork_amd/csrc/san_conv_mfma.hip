@@ -34,7 +34,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kCK = 4;        // input channels per staged chunk
-constexpr int kSlots = 5;     // staged input elements per thread per channel (<= 1280 per tile)
+constexpr int kSlots = 5;     // most staged input elements per thread per channel (<= 1280 per tile); template SL = 2, 3 or 5
 constexpr int kMaxWSlots = 5; // staged weight float4s per thread per chunk (template WS in {1,2,3,5})
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -149,7 +149,7 @@ MGeom mfma_geom(int N, int H, int W, int cout, int ks) {
 
 extern __shared__ __attribute__((aligned(16))) float mf_lds[];
 
-template <int CQ, int KS, int G, int WS>
+template <int CQ, int KS, int G, int WS, int SL>
 __global__ void __launch_bounds__(kThreads)
 conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, const MArgs a) {
     constexpr int PAD = KS / 2;
@@ -202,10 +202,10 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
     const int trash = kCK * tile_stride + tid;
 
     // ---- staging maps (computed once): input halo tile and the weight chunk
-    int goff[kSlots], loff[kSlots];
-    bool inb[kSlots];
+    int goff[SL], loff[SL];
+    bool inb[SL];
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) {
+    for (int s = 0; s < SL; ++s) {
         const int e = tid + s * kThreads;
         const int r = e / cols_t, col = e - r * cols_t;
         const int gy = y0 - PAD + r, gx = x0 - PAD + col;
@@ -218,7 +218,7 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
     // float4 slot q of this thread covers element (tid + q*256)*4 of the WC concatenated group chunks
     const int w_total4 = M.WC * w_chunk / 4;
 
-    float stage[kCK][kSlots];
+    float stage[kCK][SL];
     f4 wstage[WS];
     float psc[kCK], psh[kCK];          // the chunk's lazy affine, fetched with the tile (not at first use)
     const int aff = n * a.x_ctot + a.x_coff;
@@ -237,7 +237,7 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
         for (int ci = 0; ci < kCK; ++ci) {
             const float* src = x + (size_t)(n * a.x_ctot + a.x_coff + min(c0 + ci, cin_last)) * HW;
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) stage[ci][s] = src[goff[s]];
+            for (int s = 0; s < SL; ++s) stage[ci][s] = src[goff[s]];
         }
 #pragma unroll
         for (int q = 0; q < WS; ++q) {
@@ -269,7 +269,7 @@ conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wp, floa
         for (int ci = 0; ci < kCK; ++ci) {
             const float sc = psc[ci], sh = psh[ci];
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) {
+            for (int s = 0; s < SL; ++s) {
                 const float v = inb[s] ? san_act(stage[ci][s], sc, sh, a.in_slope) : 0.f;
                 lds_in[loff[s] >= 0 ? ci * tile_stride + loff[s] : trash] = v;
             }
@@ -517,25 +517,39 @@ __global__ void pack_mfma_batch_kernel(const long long* __restrict__ jobs) {
     }
 }
 
-template <int CQ, int KS, int G>
+// SL: staged elements per thread per channel.  Small images (40^2, 20^2 tiles) need 2; issuing the other
+// three as masked loads + stores made those layers staging-bound.
+template <int CQ, int KS, int G, int SL>
 void launch_ws(const float* x, const float* wp, float* y, const MArgs& a, dim3 grid, size_t lds, int ws, hipStream_t s) {
     if (KS == 1 || ws <= 1) {
-        hipLaunchKernelGGL((conv_mfma_kernel<CQ, KS, G, 1>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+        hipLaunchKernelGGL((conv_mfma_kernel<CQ, KS, G, 1, SL>), grid, dim3(kThreads), lds, s, x, wp, y, a);
     } else if (KS == 3 && ws == 2) {
-        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 2>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 2, SL>), grid, dim3(kThreads), lds, s, x, wp, y, a);
     } else if (KS == 3 && ws == 3) {
-        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 3>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 3, SL>), grid, dim3(kThreads), lds, s, x, wp, y, a);
     } else {
-        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 5>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+        hipLaunchKernelGGL((conv_mfma_kernel<CQ, 3, G, 5, SL>), grid, dim3(kThreads), lds, s, x, wp, y, a);
     }
+}
+
+template <int CQ, int KS, int G>
+void launch_sl(const float* x, const float* wp, float* y, const MArgs& a, dim3 grid, size_t lds, int ws, hipStream_t s) {
+    const int pad = KS / 2;
+    const int tile_elems = (a.g.TW + 2 * pad) * (a.g.TH + 2 * pad);
+    if (tile_elems <= 2 * kThreads)
+        launch_ws<CQ, KS, G, 2>(x, wp, y, a, grid, lds, ws, s);
+    else if (tile_elems <= 3 * kThreads)
+        launch_ws<CQ, KS, G, 3>(x, wp, y, a, grid, lds, ws, s);
+    else
+        launch_ws<CQ, KS, G, kSlots>(x, wp, y, a, grid, lds, ws, s);
 }
 
 template <int CQ, int KS>
 void launch_g(const float* x, const float* wp, float* y, const MArgs& a, dim3 grid, size_t lds, int ws, hipStream_t s) {
     switch (a.g.G) {
-        case 4: launch_ws<CQ, KS, 4>(x, wp, y, a, grid, lds, ws, s); break;
-        case 2: launch_ws<CQ, KS, 2>(x, wp, y, a, grid, lds, ws, s); break;
-        default: launch_ws<CQ, KS, 1>(x, wp, y, a, grid, lds, ws, s); break;
+        case 4: launch_sl<CQ, KS, 4>(x, wp, y, a, grid, lds, ws, s); break;
+        case 2: launch_sl<CQ, KS, 2>(x, wp, y, a, grid, lds, ws, s); break;
+        default: launch_sl<CQ, KS, 1>(x, wp, y, a, grid, lds, ws, s); break;
     }
 }
 
