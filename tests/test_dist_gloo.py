@@ -102,3 +102,33 @@ def test_param_bucket_views_cpu():
     assert b.owns(lin.parameters())
     lin.double().float()                                 # re-allocates the parameter storage
     assert not b.owns(lin.parameters())
+
+
+def _step_worker(rank, world, port, out):
+    """The data-parallel part of CSModel.update() on CPU: ParamBucket gradients summed over ranks in place, the
+    1/world factor applied by the optimiser (here: a plain SGD stand-in for the fused kernel's grad_scale)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = sdist.init("gloo")
+    torch.manual_seed(0)                                   # identical replicas
+    net = torch.nn.Sequential(torch.nn.Conv2d(2, 3, 3), torch.nn.Conv2d(3, 1, 1))
+    bucket = sdist.ParamBucket(net.parameters())
+    bucket.zero()
+    for i, p in enumerate(net.parameters()):
+        p.grad.add_(float(rank + 1) * (i + 1))
+    bucket.allreduce_sum(d)
+    scale = 1.0 / d.get_world_size()
+    bucket.flat_p.add_(bucket.flat, alpha=-0.1 * scale)    # p -= lr * mean gradient, one flat op
+    out[rank] = (bucket.flat.clone(), bucket.flat_p.clone())
+    d.destroy_process_group()
+
+
+def test_param_bucket_data_parallel_step_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_step_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    g0, p0 = out[0]
+    g1, p1 = out[1]
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)     # replicas stay bit-identical after the exchange
+    assert float(g0[0]) == 3.0                              # sum over ranks of (rank + 1) * 1
