@@ -317,6 +317,27 @@ int san_smooth_pool_fwd(const float* x, const float* kern, float* y, int planes,
  * [n, 2, h, w] (model.py:21-28 on the permuted view). */
 int san_gradient_loss_fwd(const float* offset, float* loss, int n, int h, int w, float* ws, void* stream);
 
+/* ---- 3x3 convolution on the bf16 matrix cores with fp32-level accuracy ("bf16x3": operands split into
+ * three bf16 parts, six products accumulated in fp32; csrc/san_conv_bf16.hip).  Same contract as
+ * san_conv2d_fwd for ks = 3 without the output affine; used where san_conv_bf16x3_eligible() says so
+ * (channel counts that fill 16-wide MFMA tiles).  Weights: san_conv_bf16x3_pack into a buffer of
+ * san_conv_bf16x3_packed_bytes(cout, cin) bytes -- mode 0: forward weight [cout,cin,3,3]; mode 2: data
+ * gradient, where (cout, cin) are those of the data-gradient convolution (= forward cin, cout) and w is
+ * still the forward weight.  Statistics tiles: san_conv_bf16x3_stat_tiles(n, h, w) per (n, channel).
+ * san_conv_bf16x3_pack_job / _pack_batch: the batched form (host table entry, one launch), as for
+ * san_conv_pack_job / san_conv_pack_batch. */
+int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks);
+size_t san_conv_bf16x3_packed_bytes(int cout, int cin);
+int san_conv_bf16x3_stat_tiles(int n, int h, int w);
+int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mode, void* stream);
+int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int cout, int cin, int mode);
+int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* stream);
+int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
+                          const float* in_scale, const float* in_shift, float in_slope,
+                          const void* w_packed, const float* bias,
+                          float* y, int y_ctot, int y_coff, int cout, float* part_stats,
+                          int n, int h, int w, void* stream);
+
 /* Batched weight packing for training, where every weight changes every step: san_conv_pack_job
  * fills one HOST table entry (8 x int64) for a weight/packed-buffer pair -- mode 0: Conv2d forward
  * (san_conv_pack_weights_fwd), 1: ConvTranspose2d 2x2 (san_conv_pack_weights transposed), 2: Conv2d

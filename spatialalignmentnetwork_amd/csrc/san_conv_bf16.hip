@@ -1,0 +1,490 @@
+// 3x3 convolution on the CDNA4 bf16 matrix cores with fp32-level accuracy ("bf16x3"): every fp32
+// operand is split into three bf16 parts a = a1 + a2 + a3 (each the round-to-nearest bf16 of what is
+// left), and a*w is evaluated as the six products a1w1 + a1w2 + a2w1 + a1w3 + a2w2 + a3w1 with
+// v_mfma_f32_16x16x32_bf16, accumulated in fp32.  The dropped terms are O(2^-24): measured on the
+// whole 12-cascade network the result moves 2.2e-5 (relative L2) from the fp32 path, inside the
+// reference's own fp32-vs-fp64 distance (scratch/study/split_bf16_accuracy.py).  Six bf16 MFMAs cost
+// 6 x 16 cycles for 16 x 16 x 32 MACs = 2.7x less matrix-pipe time than the fp32 4x4x1 form, and the
+// 16-cycle instructions leave the LDS / VALU work room (scratch/probe/mfma_bf16.hip: 290-370 TF
+// fp32-equivalent for the K-step below, against 137 TF for fp32 MFMAs alone).
+//
+// GEMM view (im2col never materialised):  D[co][pixel] += sum_k W[co][k] * A[k][pixel],
+//   M = 16 output channels per MFMA (rows), N = 16 pixels of one image row (columns),
+//   k = (tap, input channel), consumed in GROUPS of 8 consecutive channels of one tap: a lane's
+//   8 bf16 operand elements are 8 channels of one pixel, i.e. one 16-byte LDS read from a
+//   [pixel][channel] image of the staged input tile.
+// Used for the layers whose channel counts fit 16-wide tiles (cout >= 32): U-Net levels 2-4 and the
+// alignment network; 18/36-channel layers stay on the fp32 4x4x1 kernel (san_conv_mfma.hip).
+//
+// Workgroup = 4 waves, output tile 32 x 8 pixels, MB blocks of 16 output channels.  Wave w owns
+// rows 2w, 2w+1 = four 16-pixel blocks and all MB channel blocks: 4*MB accumulator tiles.  Input
+// channels are staged 24 at a time (three groups of 8): 3 parts x 340 halo pixels x 48 B in LDS
+// (pixel stride 48 B = 3 x 16 B: conflict-free b128 reads and writes), next to the chunk's packed
+// weights, which are stored in HBM exactly as the lanes read them.  A chunk = 27 (tap, group) pairs =
+// 7 K-steps of 4 groups (one zero group of padding).
+#include "san_common.h"
+
+#include <cstdint>
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kTW = 32, kTH = 8;                 // output tile
+constexpr int kHW_ = kTW + 2, kHH = kTH + 2;     // halo tile 34 x 10
+constexpr int kNP = kHW_ * kHH;                  // 340 staged pixels
+constexpr int kCKC = 24;                         // input channels per chunk (3 groups of 8)
+constexpr int kPS = 48;                          // bytes per staged pixel per part
+constexpr int kPartB = kNP * kPS;                // 16,320 B per part
+constexpr int kSteps = 7;                        // K-steps of 4 groups per chunk (27 + 1 pad)
+constexpr int kUnits = (kNP * 3 + kT - 1) / kT;  // (pixel, group) staging units per thread: 4
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef float f4 __attribute__((ext_vector_type(4)));
+union Frag {
+    uint4 u;
+    bf8 v;
+};
+
+struct BArgs {
+    const float* x;
+    const float* in_scale;
+    const float* in_shift;
+    const uint4* wp;           // packed weights [cg][chunk][step][MB][part][64 lanes] x 16 B
+    const float* bias;
+    float* y;
+    float* part;               // statistics tiles [n][cout][tiles][3] or null
+    float in_slope;
+    int x_ctot, x_coff, cin;
+    int y_ctot, y_coff, cout;
+    int N, H, W;
+    int tiles_x, tiles_y, cgs, chunks;
+};
+
+// round-to-nearest-even bf16 of f, returned as the fp32 it represents (upper 16 bits)
+__device__ __forceinline__ float bf16_round(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return __builtin_bit_cast(float, u & 0xffff0000u);
+}
+
+// f -> three bf16 parts (bit patterns) with p1 + p2 + p3 == f to ~2^-24 relative
+__device__ __forceinline__ void split3(float f, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    const float a = bf16_round(f);
+    const float r1 = f - a;
+    const float b = bf16_round(r1);
+    const float c = bf16_round(r1 - b);
+    p1 = __builtin_bit_cast(uint32_t, a) >> 16;
+    p2 = __builtin_bit_cast(uint32_t, b) >> 16;
+    p3 = __builtin_bit_cast(uint32_t, c) >> 16;
+}
+
+template <int MB>
+__global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
+    constexpr int WCH = kSteps * MB * 3 * 64;          // uint4 per (cg, chunk) weight image
+    constexpr int WSL = (WCH + kT - 1) / kT;           // weight staging slots per thread
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_a = smem;                       // 3 parts x kPartB
+    uint4* lds_w = reinterpret_cast<uint4*>(smem + 3 * kPartB);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int H = a.H, W = a.W;
+    const int HWp = H * W;
+
+    // XCD-aware order: consecutive logical ids (channel group fastest, then tile) on one XCD
+    int lin;
+    {
+        const int total = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        lin = xcd * (total >> 3) + min(xcd, total & 7) + slot;
+    }
+    const int ntile = a.tiles_x * a.tiles_y;
+    const int cg = lin % a.cgs;
+    const int tile = (lin / a.cgs) % ntile;
+    const int n = lin / (a.cgs * ntile);
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int x0 = tx * kTW, y0 = ty * kTH;
+
+    // ---- staging units (pixel p, channel group chg): slots 0..2 = pixel tid of group s (the group, hence the
+    // lazy-affine entries, is wave-uniform there), slot 3 = the remaining 84 pixels x 3 groups
+    int s_goff[kUnits], s_loff[kUnits], s_chg[kUnits];
+    bool s_in[kUnits];
+#pragma unroll
+    for (int s = 0; s < kUnits; ++s) {
+        int p, chg;
+        bool used = true;
+        if (s < 3) {
+            p = tid;
+            chg = s;
+        } else {
+            used = tid < 3 * (kNP - kT);
+            chg = used ? tid / (kNP - kT) : 0;
+            p = used ? kT + tid - chg * (kNP - kT) : 0;
+        }
+        const int pr = p / kHW_, pc = p - pr * kHW_;
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        s_in[s] = used && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        s_goff[s] = s_in[s] ? gy * W + gx : 0;
+        s_loff[s] = used ? p * kPS + chg * 16 : -1;
+        s_chg[s] = chg;
+    }
+
+    float st[kUnits][8], psc[kUnits][8], psh[kUnits][8];
+    uint4 wst[WSL];
+    const float* xb = a.x + (size_t)(n * a.x_ctot + a.x_coff) * HWp;
+    const int aff = n * a.x_ctot + a.x_coff;
+    auto prefetch = [&](int chunk) {
+#pragma unroll
+        for (int s = 0; s < kUnits; ++s) {
+            const int c0 = chunk * kCKC + s_chg[s] * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ci = min(c0 + i, a.cin - 1);
+                st[s][i] = xb[(size_t)ci * HWp + s_goff[s]];
+                psc[s][i] = 1.f;
+                psh[s][i] = 0.f;
+                if (a.in_scale) {                       // fetched with the tile, not at first use
+                    psc[s][i] = a.in_scale[aff + ci];
+                    psh[s][i] = a.in_shift[aff + ci];
+                }
+            }
+        }
+        const uint4* src = a.wp + ((size_t)cg * a.chunks + chunk) * WCH;
+#pragma unroll
+        for (int q = 0; q < WSL; ++q) {
+            const int e = tid + q * kT;
+            wst[q] = e < WCH ? src[e] : make_uint4(0, 0, 0, 0);
+        }
+    };
+
+    f4 acc[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane operand addressing.  B (activations): lane = (pixel nn = lane & 15, k-group kg = lane >> 4);
+    // k-group g = 4 step + kg of the chunk is (tap = g / 3, channel group g % 3); group 27 is padding (zero weights).
+    const int nn = lane & 15, kg = lane >> 4;
+    int tapoff[kSteps];
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+        const int g = min(4 * s + kg, 26);
+        const int tap = g / 3, chg = g - 3 * tap;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        tapoff[s] = (ky * kHW_ + kx) * kPS + chg * 16;
+    }
+    int boff[4];                                        // block b: row 2 wave + (b >> 1), columns 16 (b & 1) ..
+#pragma unroll
+    for (int b = 0; b < 4; ++b) boff[b] = ((2 * wave + (b >> 1)) * kHW_ + 16 * (b & 1) + nn) * kPS;
+
+    prefetch(0);
+    for (int chunk = 0; chunk < a.chunks; ++chunk) {
+        __syncthreads();
+        // ---- registers -> LDS: lazy activation, split into three bf16 parts, [pixel][channel] image
+#pragma unroll
+        for (int s = 0; s < kUnits; ++s) {
+            uint32_t q1[8], q2[8], q3[8];
+            const int c0 = chunk * kCKC + s_chg[s] * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float v = (s_in[s] && c0 + i < a.cin) ? san_act(st[s][i], psc[s][i], psh[s][i], a.in_slope) : 0.f;
+                split3(v, q1[i], q2[i], q3[i]);
+            }
+            if (s_loff[s] >= 0) {
+                *reinterpret_cast<uint4*>(lds_a + s_loff[s]) =
+                    make_uint4(q1[0] | (q1[1] << 16), q1[2] | (q1[3] << 16), q1[4] | (q1[5] << 16), q1[6] | (q1[7] << 16));
+                *reinterpret_cast<uint4*>(lds_a + kPartB + s_loff[s]) =
+                    make_uint4(q2[0] | (q2[1] << 16), q2[2] | (q2[3] << 16), q2[4] | (q2[5] << 16), q2[6] | (q2[7] << 16));
+                *reinterpret_cast<uint4*>(lds_a + 2 * kPartB + s_loff[s]) =
+                    make_uint4(q3[0] | (q3[1] << 16), q3[2] | (q3[3] << 16), q3[4] | (q3[5] << 16), q3[6] | (q3[7] << 16));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < WSL; ++q) {
+            const int e = tid + q * kT;
+            if (e < WCH) lds_w[e] = wst[q];
+        }
+        __syncthreads();
+        if (chunk + 1 < a.chunks) prefetch(chunk + 1);
+        // ---- 7 K-steps: (MB + 4) x 3 sixteen-byte operand reads feed 6 x MB x 4 MFMAs
+#pragma unroll 1
+        for (int s = 0; s < kSteps; ++s) {
+            Frag wa[MB][3], xa[4][3];
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) wa[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
+            const int to = tapoff[s];
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) xa[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
+#pragma unroll
+            for (int pw = 0; pw < 3; ++pw)
+#pragma unroll
+                for (int px = 0; px < 3 - pw; ++px)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[m][pw].v, xa[b][px].v, acc[m][b], 0, 0, 0);
+        }
+    }
+
+    // ------------------------------------------------------------ epilogue
+    // acc[m][b][r] = output channel co = (cg MB + m) 16 + 4 (lane >> 4) + r at pixel (row 2 wave + (b >> 1), column 16 (b & 1) + nn)
+    const int cbase = cg * MB * 16 + 4 * kg;
+    int oy[4], ox[4];
+    bool valid[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        oy[b] = y0 + 2 * wave + (b >> 1);
+        ox[b] = x0 + 16 * (b & 1) + nn;
+        valid[b] = oy[b] < H && ox[b] < W;
+    }
+    if (a.bias) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = cbase + 16 * m + r;
+                const float bv = co < a.cout ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[m][b][r] += bv;
+            }
+    }
+    if (a.part) {
+        // per-wave (count, mean, M2) of every channel over the wave's 64 pixels: pilot-shifted single pass; the 16
+        // lanes of a DPP row hold the 16 pixels of a block, so four row-local DPP steps finish the sum
+        float cnt = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cnt += valid[b] ? 1.f : 0.f;
+        cnt += san_dpp_get<0xB1, 0xf>(cnt);
+        cnt += san_dpp_get<0x4E, 0xf>(cnt);
+        cnt += san_dpp_get<0x141, 0xf>(cnt);
+        cnt += san_dpp_get<0x140, 0xf>(cnt);
+        const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+        const int tiles = ntile * 4;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // pilot: block 0, first pixel of the row of lanes (valid whenever the wave has any valid pixel)
+                const float pilot = __shfl(acc[m][0][r], lane & 48, 64);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float e = valid[b] ? acc[m][b][r] - pilot : 0.f;
+                    s1 += e;
+                    s2 = fmaf(e, e, s2);
+                }
+                s1 += san_dpp_get<0xB1, 0xf>(s1);
+                s2 += san_dpp_get<0xB1, 0xf>(s2);
+                s1 += san_dpp_get<0x4E, 0xf>(s1);
+                s2 += san_dpp_get<0x4E, 0xf>(s2);
+                s1 += san_dpp_get<0x141, 0xf>(s1);
+                s2 += san_dpp_get<0x141, 0xf>(s2);
+                s1 += san_dpp_get<0x140, 0xf>(s1);
+                s2 += san_dpp_get<0x140, 0xf>(s2);
+                const int co = cbase + 16 * m + r;
+                if (nn == 0 && co < a.cout) {
+                    float* o = a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
+                    o[0] = cnt;
+                    o[1] = cnt > 0.f ? pilot + s1 * inv : 0.f;
+                    o[2] = cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f;
+                }
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = cbase + 16 * m + r;
+            if (co < a.cout) {
+                float* dst = a.y + (size_t)(n * a.y_ctot + a.y_coff + co) * HWp;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (valid[b]) dst[oy[b] * W + ox[b]] = acc[m][b][r];
+            }
+        }
+}
+
+// ---------------------------------------------------------------- packing
+// packed[cg][chunk][step][m][part][lane][i] (bf16): lane = (co16 = lane & 15, kg = lane >> 4);
+// co = (cg MB + m) 16 + co16; group g = 4 step + kg -> tap = g / 3, ci = chunk 24 + (g % 3) 8 + i.
+// mode 0: w is the forward weight [cout][cin][3][3]; mode 2 (data gradient): w is the forward weight of
+// the layer being differentiated, [cin_here = its cout ... ] i.e. value = w[ci][co][8 - tap].
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t idx, int cout,
+                                         int cin, int MB, int chunks, int mode) {
+    const int i = (int)(idx & 7);
+    const int lane = (int)((idx >> 3) & 63);
+    size_t r = idx >> 9;
+    const int part = (int)(r % 3);
+    r /= 3;
+    const int m = (int)(r % MB);
+    r /= MB;
+    const int step = (int)(r % kSteps);
+    r /= kSteps;
+    const int chunk = (int)(r % chunks);
+    const int cg = (int)(r / chunks);
+    const int co = (cg * MB + m) * 16 + (lane & 15);
+    const int g = 4 * step + (lane >> 4);
+    const int tap = g / 3;
+    const int ci = chunk * kCKC + (g - 3 * tap) * 8 + i;
+    float v = 0.f;
+    if (tap < 9 && ci < cin && co < cout)
+        v = mode == 2 ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
+    uint32_t p1, p2, p3;
+    split3(v, p1, p2, p3);
+    packed[idx] = (uint16_t)(part == 0 ? p1 : (part == 1 ? p2 : p3));
+}
+
+__global__ void pack_bf16x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t total, int cout,
+                                   int cin, int MB, int chunks, int mode) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+        pack_one(w, packed, idx, cout, cin, MB, chunks, mode);
+}
+
+// batched: 8 x int64 per job = {w, packed, cout, cin, MB, chunks, mode, total}
+__global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
+    const long long* j = jobs + 8 * (size_t)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(j[0]);
+    uint16_t* packed = reinterpret_cast<uint16_t*>(j[1]);
+    const size_t total = (size_t)j[7];
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
+        pack_one(w, packed, idx, (int)j[2], (int)j[3], (int)j[4], (int)j[5], (int)j[6]);
+}
+
+struct BPlan {
+    int MB, cgs, chunks;
+    size_t packed_elems;       // bf16 elements
+};
+
+BPlan bplan(int cout, int cin) {
+    BPlan p{};
+    const int nblk = san_cdiv(cout, 16);
+    p.cgs = san_cdiv(nblk, 5);
+    p.MB = san_cdiv(nblk, p.cgs);
+    if (p.MB < 2) p.MB = 2;
+    p.chunks = san_cdiv(cin, kCKC);
+    p.packed_elems = (size_t)p.cgs * p.chunks * kSteps * p.MB * 3 * 64 * 8;
+    return p;
+}
+
+template <int MB>
+int launch_b(const BArgs& a, hipStream_t s) {
+    constexpr size_t lds = 3 * (size_t)kPartB + (size_t)kSteps * MB * 3 * 64 * 16;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
+            return SAN_E_UNSUPPORTED;
+        }
+        configured = true;
+    }
+    const int total = a.tiles_x * a.tiles_y * a.cgs * a.N;
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MB>), dim3(total), dim3(kT), lds, s, a);
+    return SAN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when san_conv2d_bf16x3_fwd takes this layer (3x3, channel counts that fill 16-wide tiles); the caller then
+// packs the weights with san_conv_bf16x3_pack and sizes statistics with san_conv_bf16x3_stat_tiles.
+int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks) {
+    if (ks != 3) return 0;
+    if (cout < 32 || cin < 24) return 0;
+    if (h < 8 || w < 16) return 0;
+    return 1;
+}
+
+size_t san_conv_bf16x3_packed_bytes(int cout, int cin) { return bplan(cout, cin).packed_elems * 2; }
+
+int san_conv_bf16x3_stat_tiles(int n, int h, int w) {
+    (void)n;
+    return san_cdiv(w, kTW) * san_cdiv(h, kTH) * 4;
+}
+
+int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mode, void* stream) {
+    SAN_CHECK_ARG(w && packed, "null pointer");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && (mode == 0 || mode == 2), "bad dims / mode");
+    // mode 2: `cout`, `cin` are those of the DATA-GRADIENT convolution (cout = forward cin, cin = forward cout)
+    const BPlan p = bplan(cout, cin);
+    size_t blocks = (p.packed_elems + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)packed,
+                       p.packed_elems, cout, cin, p.MB, p.chunks, mode);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int cout, int cin, int mode) {
+    SAN_CHECK_ARG(job8 && w && packed, "null pointer");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && (mode == 0 || mode == 2), "bad dims / mode");
+    const BPlan p = bplan(cout, cin);
+    job8[0] = (long long)(uintptr_t)w;
+    job8[1] = (long long)(uintptr_t)packed;
+    job8[2] = cout;
+    job8[3] = cin;
+    job8[4] = p.MB;
+    job8[5] = p.chunks;
+    job8[6] = mode;
+    job8[7] = (long long)p.packed_elems;
+    return SAN_OK;
+}
+
+int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* stream) {
+    SAN_CHECK_ARG(jobs_dev && njobs > 0, "empty job table");
+    hipLaunchKernelGGL(pack_bf16x3_batch_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                          float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff,
+                          int cout, float* part_stats, int n, int h, int w, void* stream) {
+    SAN_CHECK_ARG(x && w_packed && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
+    SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + cout <= y_ctot, "bad channel view");
+    SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
+    const BPlan p = bplan(cout, cin);
+    BArgs a{};
+    a.x = x;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_slope = in_slope;
+    a.wp = (const uint4*)w_packed;
+    a.bias = bias;
+    a.y = y;
+    a.part = part_stats;
+    a.x_ctot = x_ctot;
+    a.x_coff = x_coff;
+    a.cin = cin;
+    a.y_ctot = y_ctot;
+    a.y_coff = y_coff;
+    a.cout = cout;
+    a.N = n;
+    a.H = h;
+    a.W = w;
+    a.tiles_x = san_cdiv(w, kTW);
+    a.tiles_y = san_cdiv(h, kTH);
+    a.cgs = p.cgs;
+    a.chunks = p.chunks;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (p.MB) {
+        case 2: rc = launch_b<2>(a, s); break;
+        case 3: rc = launch_b<3>(a, s); break;
+        case 4: rc = launch_b<4>(a, s); break;
+        default: rc = launch_b<5>(a, s); break;
+    }
+    if (rc != SAN_OK) return rc;
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+}  // extern "C"

@@ -7,6 +7,7 @@ ATen compute kernel is launched on the hot path.
 from __future__ import annotations
 
 import ctypes
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
@@ -297,8 +298,8 @@ class _PackRegistry:
         if dead:
             self.table = None
 
-    def _register(self, w: torch.Tensor, mode: int):
-        _chk(w, name="weight")
+    def _alloc(self, w: torch.Tensor, mode: int):
+        """(dims, packed buffer) for a new job."""
         if mode == 1:
             cin, cout, ks = w.shape[0], w.shape[1], w.shape[2]
             nfl = lib().query("san_conv_packed_floats", cout, cin, ks)
@@ -308,13 +309,26 @@ class _PackRegistry:
         else:
             cout, cin, ks = w.shape[0], w.shape[1], w.shape[2]
             nfl = lib().query("san_conv_packed_floats", cout, cin, ks)
+        return (cout, cin, ks), torch.empty(nfl, device=w.device, dtype=torch.float32)
+
+    def _register(self, w: torch.Tensor, mode: int):
+        _chk(w, name="weight")
+        dims, packed = self._alloc(w, mode)
         if len(self.jobs) >= 4096:
             self._prune()
-        job = {"wref": weakref.ref(w), "ptr": w.data_ptr(), "mode": mode, "dims": (cout, cin, ks), "version": -1,
-               "packed": torch.empty(nfl, device=w.device, dtype=torch.float32), "device": w.device}
+        job = {"wref": weakref.ref(w), "ptr": w.data_ptr(), "mode": mode, "dims": dims, "version": -1,
+               "packed": packed, "device": w.device}
         self.jobs[(id(w), mode)] = job
         self.table = None
         return job
+
+    def _fill_job(self, row, j):
+        cout, cin, ks = j["dims"]
+        lib().call("san_conv_pack_job", ctypes.c_void_p(ctypes.addressof(row)), ctypes.c_void_p(j["ptr"]),
+                   _p(j["packed"]), cout, cin, ks, j["mode"])
+
+    def _batch(self):
+        lib().call("san_conv_pack_batch", _p(self.table), len(self.order), _stream())
 
     def _run(self, device):
         """Re-pack every live job on `device` in one launch."""
@@ -326,13 +340,11 @@ class _PackRegistry:
             host = torch.zeros((len(self.order), 8), dtype=torch.int64)
             row = (ctypes.c_longlong * 8)()
             for i, j in enumerate(self.order):
-                cout, cin, ks = j["dims"]
-                lib().call("san_conv_pack_job", ctypes.c_void_p(ctypes.addressof(row)), ctypes.c_void_p(j["ptr"]),
-                           _p(j["packed"]), cout, cin, ks, j["mode"])
+                self._fill_job(row, j)
                 host[i] = torch.tensor(list(row), dtype=torch.int64)
             self.table = host.to(device)
         if self.order:
-            lib().call("san_conv_pack_batch", _p(self.table), len(self.order), _stream())
+            self._batch()
         for j in self.order:
             w = j["wref"]()
             j["version"] = w._version if w is not None else -1
@@ -362,6 +374,40 @@ class _PackRegistry:
 PACKS = _PackRegistry()
 
 
+class _PackRegistryBf16(_PackRegistry):
+    """The same bookkeeping for the bf16x3 kernels' weight images (csrc/san_conv_bf16.hip): mode 0 forward,
+    mode 2 data gradient; dims = (cout, cin) of the convolution that will run."""
+
+    def _alloc(self, w: torch.Tensor, mode: int):
+        if mode == 2:
+            cout, cin = w.shape[1], w.shape[0]          # the data-gradient conv maps forward cout -> forward cin
+        else:
+            cout, cin = w.shape[0], w.shape[1]
+        nbytes = lib().query("san_conv_bf16x3_packed_bytes", cout, cin)
+        return (cout, cin, 3), torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+
+    def _fill_job(self, row, j):
+        cout, cin, _ = j["dims"]
+        lib().call("san_conv_bf16x3_pack_job", ctypes.c_void_p(ctypes.addressof(row)), ctypes.c_void_p(j["ptr"]),
+                   _p(j["packed"]), cout, cin, j["mode"])
+
+    def _batch(self):
+        lib().call("san_conv_bf16x3_pack_batch", _p(self.table), len(self.order), _stream())
+
+    def _pack_one(self, job, w):
+        cout, cin, _ = job["dims"]
+        lib().call("san_conv_bf16x3_pack", _p(w.detach()), _p(job["packed"]), cout, cin, job["mode"], _stream())
+        job["version"] = w._version
+
+
+PACKS16 = _PackRegistryBf16()
+USE_BF16X3 = [os.environ.get("SAN_NO_BF16X3", "0") != "1"]
+
+
+def bf16x3_eligible(cin: int, cout: int, h: int, w: int, ks: int) -> bool:
+    return USE_BF16X3[0] and bool(lib().query("san_conv_bf16x3_eligible", cin, cout, h, w, ks))
+
+
 def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     """Packed copy of a Conv2d (or, transposed, ConvTranspose2d 2x2) weight for the MFMA kernels."""
     return PACKS.get(w, 1 if transposed else 0)
@@ -375,9 +421,18 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert cin == x.c and cout == y.c, (cin, x.c, cout, y.c)
     assert x.buf.shape[2:] == y.buf.shape[2:]
-    wp = packed_weight(weight)
     n, h, w = x.n, x.h, x.w
     part = None
+    if out_scale is None and bf16x3_eligible(cin, cout, h, w, ks):
+        # bf16 matrix cores, operands split in three (fp32-level accuracy), csrc/san_conv_bf16.hip
+        wp = PACKS16.get(weight, 0)
+        if stats:
+            part = arena.get("part" + tag, (n, cout, lib().query("san_conv_bf16x3_stat_tiles", n, h, w), 3), x.buf.device)
+        bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
+                 y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
+        _timed("conv3x3", 2.0 * n * h * w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_bf16x3_fwd", *bargs))
+        return part
+    wp = packed_weight(weight)
     if stats:
         tiles = lib().query("san_conv_stat_tiles", n, h, w, cin, cout, ks)
         part = arena.get("part" + tag, (n, cout, tiles, 3), x.buf.device)
@@ -571,6 +626,13 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
     """dx.buf[:, dx.coff:+cin] = dL/d(conv input) for dy = dL/d(conv output) (materialised)."""
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert dy.c == cout and dx.c == cin
+    if bf16x3_eligible(cout, cin, dy.h, dy.w, ks):       # the data-gradient conv maps cout -> cin channels
+        wp = PACKS16.get(weight, 2)
+        bargs = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
+                 _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), dy.n, dy.h, dy.w, _stream())
+        _timed("conv3x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * 9, "FLOP",
+               lambda: lib().call("san_conv2d_bf16x3_fwd", *bargs))
+        return
     wp = packed_weight_dgrad(weight)
     args = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
             _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), _p(None), _p(None), dy.n, dy.h, dy.w, ks, _stream())
