@@ -49,7 +49,7 @@ struct BArgs {
     const float* x;
     const float* in_scale;
     const float* in_shift;
-    const uint4* wp;           // packed weights [cg][chunk][step][MB][part][64 lanes] x 16 B
+    const uint4* wp;           // packed weights [chunk][step][block of 16 couts][part][64 lanes] x 16 B
     const float* bias;
     float* y;
     float* part;               // statistics tiles [n][cout][tiles][3] or null
@@ -57,7 +57,7 @@ struct BArgs {
     int x_ctot, x_coff, cin;
     int y_ctot, y_coff, cout;
     int N, H, W;
-    int tiles_x, tiles_y, cgs, chunks;
+    int tiles_x, tiles_y, cgs, chunks, nblkp;   // nblkp: channel blocks in the packed image (>= cgs * MB)
 };
 
 // round-to-nearest-even bf16 of f, returned as the fp32 it represents (upper 16 bits)
@@ -149,11 +149,13 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 }
             }
         }
-        const uint4* src = a.wp + ((size_t)cg * a.chunks + chunk) * WCH;
+        // this group's MB blocks of every K-step: 7 contiguous pieces of MB*192 uint4
+        const uint4* src = a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192;
 #pragma unroll
         for (int q = 0; q < WSL; ++q) {
             const int e = tid + q * kT;
-            wst[q] = e < WCH ? src[e] : make_uint4(0, 0, 0, 0);
+            const int st_ = e / (MB * 192), within = e - st_ * (MB * 192);
+            wst[q] = e < WCH ? src[(size_t)st_ * a.nblkp * 192 + within] : make_uint4(0, 0, 0, 0);
         }
     };
 
@@ -311,24 +313,23 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 }
 
 // ---------------------------------------------------------------- packing
-// packed[cg][chunk][step][m][part][lane][i] (bf16): lane = (co16 = lane & 15, kg = lane >> 4);
-// co = (cg MB + m) 16 + co16; group g = 4 step + kg -> tap = g / 3, ci = chunk 24 + (g % 3) 8 + i.
-// mode 0: w is the forward weight [cout][cin][3][3]; mode 2 (data gradient): w is the forward weight of
-// the layer being differentiated, [cin_here = its cout ... ] i.e. value = w[ci][co][8 - tap].
+// packed[chunk][step][blk][part][lane][i] (bf16), blk over nblkp = ceil(cout/16) + 4 blocks (zero padded so any
+// grouping of up to 5 blocks per workgroup stays inside): lane = (co16 = lane & 15, kg = lane >> 4);
+// co = 16 blk + co16; group g = 4 step + kg -> tap = g / 3, ci = chunk 24 + (g % 3) 8 + i.
+// mode 0: w is the forward weight [cout][cin][3][3]; mode 2 (data gradient): (cout, cin) are those of the
+// data-gradient convolution and w is the forward weight of the layer being differentiated: value = w[ci][co][8 - tap].
 __device__ __forceinline__ void pack_one(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t idx, int cout,
-                                         int cin, int MB, int chunks, int mode) {
+                                         int cin, int nblkp, int mode) {
     const int i = (int)(idx & 7);
     const int lane = (int)((idx >> 3) & 63);
     size_t r = idx >> 9;
     const int part = (int)(r % 3);
     r /= 3;
-    const int m = (int)(r % MB);
-    r /= MB;
+    const int blk = (int)(r % nblkp);
+    r /= nblkp;
     const int step = (int)(r % kSteps);
-    r /= kSteps;
-    const int chunk = (int)(r % chunks);
-    const int cg = (int)(r / chunks);
-    const int co = (cg * MB + m) * 16 + (lane & 15);
+    const int chunk = (int)(r / kSteps);
+    const int co = blk * 16 + (lane & 15);
     const int g = 4 * step + (lane >> 4);
     const int tap = g / 3;
     const int ci = chunk * kCKC + (g - 3 * tap) * 8 + i;
@@ -341,35 +342,51 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, uint16_t* 
 }
 
 __global__ void pack_bf16x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t total, int cout,
-                                   int cin, int MB, int chunks, int mode) {
+                                   int cin, int nblkp, int mode) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-        pack_one(w, packed, idx, cout, cin, MB, chunks, mode);
+        pack_one(w, packed, idx, cout, cin, nblkp, mode);
 }
 
-// batched: 8 x int64 per job = {w, packed, cout, cin, MB, chunks, mode, total}
+// batched: 8 x int64 per job = {w, packed, cout, cin, nblkp, 0, mode, total}
 __global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
     const long long* j = jobs + 8 * (size_t)blockIdx.y;
     const float* w = reinterpret_cast<const float*>(j[0]);
     uint16_t* packed = reinterpret_cast<uint16_t*>(j[1]);
     const size_t total = (size_t)j[7];
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-        pack_one(w, packed, idx, (int)j[2], (int)j[3], (int)j[4], (int)j[5], (int)j[6]);
+        pack_one(w, packed, idx, (int)j[2], (int)j[3], (int)j[4], (int)j[6]);
 }
 
 struct BPlan {
-    int MB, cgs, chunks;
+    int nblkp, chunks;
     size_t packed_elems;       // bf16 elements
 };
 
 BPlan bplan(int cout, int cin) {
     BPlan p{};
-    const int nblk = san_cdiv(cout, 16);
-    p.cgs = san_cdiv(nblk, 5);
-    p.MB = san_cdiv(nblk, p.cgs);
-    if (p.MB < 2) p.MB = 2;
+    p.nblkp = san_cdiv(cout, 16) + 4;
     p.chunks = san_cdiv(cin, kCKC);
-    p.packed_elems = (size_t)p.cgs * p.chunks * kSteps * p.MB * 3 * 64 * 8;
+    p.packed_elems = (size_t)p.chunks * kSteps * p.nblkp * 3 * 64 * 8;
     return p;
+}
+
+// Output-channel blocks per workgroup for this launch: the LDS budget allows one workgroup per CU, so
+// prefer the largest MB (input tile staged once for more channels) that still gives every CU a workgroup;
+// cost model = dispatch rounds x (MB + ~1.5 blocks' worth of per-tile staging).
+int pick_mb(int cout, int tiles) {
+    const int nblk = san_cdiv(cout, 16);
+    int best = 2;
+    float best_c = 1e30f;
+    for (int mb = 5; mb >= 2; --mb) {
+        const int m = mb < nblk ? mb : (nblk < 2 ? 2 : nblk);
+        const int wgs = tiles * san_cdiv(nblk, m);
+        const float c = (float)san_cdiv(wgs, 256) * ((float)m + 1.5f);
+        if (c < best_c - 1e-6f) {
+            best_c = c;
+            best = m;
+        }
+    }
+    return best > 5 ? 5 : best;
 }
 
 template <int MB>
@@ -398,6 +415,7 @@ extern "C" {
 int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks) {
     if (ks != 3) return 0;
     if (cout < 32 || cin < 24) return 0;
+    if (cout < 48 && cin < 64) return 0;          // 32 -> 32 @320^2: the fp32 kernel is still 12 % faster
     if (h < 8 || w < 16) return 0;
     return 1;
 }
@@ -417,7 +435,7 @@ int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mo
     size_t blocks = (p.packed_elems + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)packed,
-                       p.packed_elems, cout, cin, p.MB, p.chunks, mode);
+                       p.packed_elems, cout, cin, p.nblkp, mode);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
@@ -430,8 +448,8 @@ int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int 
     job8[1] = (long long)(uintptr_t)packed;
     job8[2] = cout;
     job8[3] = cin;
-    job8[4] = p.MB;
-    job8[5] = p.chunks;
+    job8[4] = p.nblkp;
+    job8[5] = 0;
     job8[6] = mode;
     job8[7] = (long long)p.packed_elems;
     return SAN_OK;
@@ -472,11 +490,13 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const
     a.W = w;
     a.tiles_x = san_cdiv(w, kTW);
     a.tiles_y = san_cdiv(h, kTH);
-    a.cgs = p.cgs;
+    const int mb = pick_mb(cout, a.tiles_x * a.tiles_y * n);
+    a.cgs = san_cdiv(san_cdiv(cout, 16), mb);
     a.chunks = p.chunks;
+    a.nblkp = p.nblkp;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    switch (p.MB) {
+    switch (mb) {
         case 2: rc = launch_b<2>(a, s); break;
         case 3: rc = launch_b<3>(a, s); break;
         case 4: rc = launch_b<4>(a, s); break;
