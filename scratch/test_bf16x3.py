@@ -35,14 +35,16 @@ for n, cin, cout, h, w in [(2, 24, 32, 16, 32), (1, 72, 72, 20, 44), (2, 36, 72,
     ed = rel(dx, a64.grad)
     print(f"n={n} {cin}->{cout} {h}x{w}: fwd rel {e:.2e}  mean abs {em:.2e}  var rel {ev:.2e}  count {tot.min().item():.0f}/{h*w}  dgrad rel {ed:.2e}", flush=True)
 print("timing (N=8):")
-for cin, cout, s in [(36,72,80),(72,72,80),(144,72,80),(72,144,40),(144,144,40),(288,144,40),(144,288,20),(288,288,20),(32,32,320),(96,32,320),(64,64,160),(128,64,160)]:
+import ctypes
+elig_real = ops.bf16x3_eligible
+for cin, cout, s in [(18,36,160),(36,36,160),(72,36,160),(36,18,320),(18,18,320),(32,32,320),(36,72,80),(144,72,80)]:
     x = torch.randn(8, cin, s, s, device=dev); wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     sc = torch.rand(8, cin, device=dev) + 0.5; sh = torch.randn(8, cin, device=dev)
     y = torch.empty(8, cout, s, s, device=dev); xa = ops.Act(x, 0, cin, sc, sh, 0.2); ya = ops.full(y)
     res = []
     for flag in (True, False):
-        ops.USE_BF16X3[0] = flag
+        ops.bf16x3_eligible = (lambda *a, f=flag: f)
         res.append(bench(lambda: ops.conv2d(xa, wt, None, ya, stats=True)))
-    ops.USE_BF16X3[0] = True
+    ops.bf16x3_eligible = elig_real
     fl = 2.0 * 8 * s * s * cin * cout * 9
     print(f"conv3 {cin:3d}->{cout:3d} @{s:3d}: bf16x3 {res[0]:7.1f} us ({fl/res[0]/1e6:6.1f} TF)   fp32 {res[1]:7.1f} us ({fl/res[1]/1e6:6.1f} TF)", flush=True)

@@ -78,6 +78,21 @@ __device__ __forceinline__ void split3(float f, uint32_t& p1, uint32_t& p2, uint
     p3 = __builtin_bit_cast(uint32_t, c) >> 16;
 }
 
+// two values at once on the hardware converter: v_cvt_pk_bf16_f32 rounds to nearest even and packs (lo = f0, hi = f1);
+// the fp32 value of a bf16 is its bits shifted left by 16
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+typedef __attribute__((ext_vector_type(2))) float fl2;
+__device__ __forceinline__ uint32_t cvt_pk(float f0, float f1) {
+    const fl2 v = {f0, f1};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+}
+__device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = cvt_pk(f0, f1);
+    const float r0 = f0 - __builtin_bit_cast(float, p1 << 16), r1 = f1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = cvt_pk(r0, r1);
+    p3 = cvt_pk(r0 - __builtin_bit_cast(float, p2 << 16), r1 - __builtin_bit_cast(float, p2 & 0xffff0000u));
+}
+
 template <int MB>
 __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     constexpr int WCH = kSteps * MB * 3 * 64;          // uint4 per (cg, chunk) weight image
@@ -186,20 +201,18 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         // ---- registers -> LDS: lazy activation, split into three bf16 parts, [pixel][channel] image
 #pragma unroll
         for (int s = 0; s < kUnits; ++s) {
-            uint32_t q1[8], q2[8], q3[8];
+            uint32_t q1[4], q2[4], q3[4];
             const int c0 = chunk * kCKC + s_chg[s] * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float v = (s_in[s] && c0 + i < a.cin) ? san_act(st[s][i], psc[s][i], psh[s][i], a.in_slope) : 0.f;
-                split3(v, q1[i], q2[i], q3[i]);
+            for (int i = 0; i < 8; i += 2) {
+                const float v0 = (s_in[s] && c0 + i < a.cin) ? san_act(st[s][i], psc[s][i], psh[s][i], a.in_slope) : 0.f;
+                const float v1 = (s_in[s] && c0 + i + 1 < a.cin) ? san_act(st[s][i + 1], psc[s][i + 1], psh[s][i + 1], a.in_slope) : 0.f;
+                split3_pair(v0, v1, q1[i >> 1], q2[i >> 1], q3[i >> 1]);
             }
             if (s_loff[s] >= 0) {
-                *reinterpret_cast<uint4*>(lds_a + s_loff[s]) =
-                    make_uint4(q1[0] | (q1[1] << 16), q1[2] | (q1[3] << 16), q1[4] | (q1[5] << 16), q1[6] | (q1[7] << 16));
-                *reinterpret_cast<uint4*>(lds_a + kPartB + s_loff[s]) =
-                    make_uint4(q2[0] | (q2[1] << 16), q2[2] | (q2[3] << 16), q2[4] | (q2[5] << 16), q2[6] | (q2[7] << 16));
-                *reinterpret_cast<uint4*>(lds_a + 2 * kPartB + s_loff[s]) =
-                    make_uint4(q3[0] | (q3[1] << 16), q3[2] | (q3[3] << 16), q3[4] | (q3[5] << 16), q3[6] | (q3[7] << 16));
+                *reinterpret_cast<uint4*>(lds_a + s_loff[s]) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+                *reinterpret_cast<uint4*>(lds_a + kPartB + s_loff[s]) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+                *reinterpret_cast<uint4*>(lds_a + 2 * kPartB + s_loff[s]) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
             }
         }
 #pragma unroll
@@ -209,19 +222,24 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         }
         __syncthreads();
         if (chunk + 1 < a.chunks) prefetch(chunk + 1);
-        // ---- 7 K-steps: (MB + 4) x 3 sixteen-byte operand reads feed 6 x MB x 4 MFMAs
-#pragma unroll 1
-        for (int s = 0; s < kSteps; ++s) {
-            Frag wa[MB][3], xa[4][3];
+        // ---- 7 K-steps: (MB + 4) x 3 sixteen-byte operand reads feed 6 x MB x 4 MFMAs; the reads of step s+1
+        // are issued before the MFMAs of step s (two operand sets, compile-time indices after unrolling)
+        Frag wa[2][MB][3], xa[2][4][3];
+        auto load_step = [&](int s, Frag (&wq)[MB][3], Frag (&xq)[4][3]) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wa[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
+                for (int p = 0; p < 3; ++p) wq[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
             const int to = tapoff[s];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) xa[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
+                for (int p = 0; p < 3; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
+        };
+        load_step(0, wa[0], xa[0]);
+#pragma unroll
+        for (int s = 0; s < kSteps; ++s) {
+            if (s + 1 < kSteps) load_step(s + 1, wa[(s + 1) & 1], xa[(s + 1) & 1]);
 #pragma unroll
             for (int pw = 0; pw < 3; ++pw)
 #pragma unroll
@@ -230,7 +248,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
-                            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[m][pw].v, xa[b][px].v, acc[m][b], 0, 0, 0);
+                            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1][m][pw].v, xa[s & 1][b][px].v, acc[m][b], 0, 0, 0);
         }
     }
 

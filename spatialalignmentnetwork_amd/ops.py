@@ -48,7 +48,7 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
-TIMED_KERNELS = ("conv3x3", "wgrad3x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
+TIMED_KERNELS = ("conv3x3", "conv3x3_bf16x3", "wgrad3x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
 
 
 def _timed(name, work, unit, fn):
@@ -430,7 +430,7 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
             part = arena.get("part" + tag, (n, cout, lib().query("san_conv_bf16x3_stat_tiles", n, h, w), 3), x.buf.device)
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
                  y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
-        _timed("conv3x3", 2.0 * n * h * w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_bf16x3_fwd", *bargs))
+        _timed("conv3x3_bf16x3", 2.0 * n * h * w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_bf16x3_fwd", *bargs))
         return part
     wp = packed_weight(weight)
     if stats:
@@ -630,7 +630,7 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
         wp = PACKS16.get(weight, 2)
         bargs = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
                  _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), dy.n, dy.h, dy.w, _stream())
-        _timed("conv3x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * 9, "FLOP",
+        _timed("conv3x3_bf16x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * 9, "FLOP",
                lambda: lib().call("san_conv2d_bf16x3_fwd", *bargs))
         return
     wp = packed_weight_dgrad(weight)

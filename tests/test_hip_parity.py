@@ -659,7 +659,7 @@ def test_metrics_vs_reference(S, tag):
     assert abs(M.ssim(g(gt), g(pred)) - (1.0 - S.O.ssimloss(gt, pred).item())) < 2e-5
 
 
-@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 24, 32, 16, 32), (1, 72, 72, 20, 44), (2, 36, 72, 40, 40), (1, 96, 32, 33, 50),
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 24, 48, 16, 32), (1, 72, 72, 20, 44), (2, 36, 72, 40, 40), (1, 96, 32, 33, 50),
                                             (2, 144, 144, 24, 24), (1, 288, 144, 16, 16), (1, 64, 64, 9, 17)])
 def test_conv_bf16x3_vs_float64(S, n, cin, cout, h, w):
     """The bf16 matrix-core convolution with three-way split operands (csrc/san_conv_bf16.hip) against float64:
