@@ -13,6 +13,7 @@ for tag, d in (('FETCH_SIZE', '/tmp/pmc_f'), ('WRITE_SIZE', '/tmp/pmc_w')):
             if r['Counter_Name'] != tag: continue
             k = r['Kernel_Name']
             key = ('cal_apply' if 'apply_kernel' in k else 'cal_rss' if 'rss_kernel' in k and 'bwd' not in k else
+                   'conv_bf16x3' if 'conv_bf16x3_kernel' in k else
                    'conv_mfma_3x3' if 'conv_mfma_kernel' in k and ', 3, ' in k else
                    'conv_mfma_1x1' if 'conv_mfma_kernel' in k else
                    'wgrad_vec_3x3' if 'conv_wgrad_vec_kernel<3' in k else
