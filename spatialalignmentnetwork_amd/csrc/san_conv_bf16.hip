@@ -96,7 +96,8 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
 template <int MB>
 __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     constexpr int WCH = kSteps * MB * 3 * 64;          // uint4 per (cg, chunk) weight image
-    constexpr int WSL = (WCH + kT - 1) / kT;           // weight staging slots per thread
+    constexpr int NWU = kSteps * MB * 3;               // ... = NWU wave-wide pieces (64 lanes x 16 B), one per (step, block, part)
+    constexpr int WSL = (NWU + kT / 64 - 1) / (kT / 64); // pieces per wave: wave w moves pieces w, w + 4, ...
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* lds_a = smem;                       // 3 parts x kPartB
     uint4* lds_w = reinterpret_cast<uint4*>(smem + 3 * kPartB);
@@ -144,33 +145,41 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         s_chg[s] = chg;
     }
 
-    float st[kUnits][8], psc[kUnits][8], psh[kUnits][8];
-    uint4 wst[WSL];
-    const float* xb = a.x + (size_t)(n * a.x_ctot + a.x_coff) * HWp;
-    const int aff = n * a.x_ctot + a.x_coff;
+    float st[kUnits][8];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 wst[WSL];                                   // (a plain vector type: the struct uint4 copy kept this array in scratch)
+    const float* xs[kUnits];                          // slot's pixel in channel 0 of this sample's view
+#pragma unroll
+    for (int s = 0; s < kUnits; ++s) xs[s] = a.x + (size_t)(n * a.x_ctot + a.x_coff) * HWp + s_goff[s];
+    // The chunk's lazy affine (24 scales + 24 shifts of this sample) travels through a double-buffered LDS
+    // table: thread t < 48 fetches ONE value with the tile and stores it during the previous chunk's staging
+    // phase (two barriers before anyone reads it) -- not 64 loads per thread per chunk.
+    float* lds_aff = reinterpret_cast<float*>(smem + 3 * kPartB + (size_t)WCH * 16);
+    const bool has_aff = a.in_scale != nullptr;
+    float my_aff = 0.f;
+    auto fetch_aff = [&](int chunk) {
+        if (tid < 48) {
+            const int ci = min(chunk * kCKC + (tid < 24 ? tid : tid - 24), a.cin - 1);
+            const float* src = tid < 24 ? a.in_scale : a.in_shift;
+            my_aff = has_aff ? src[n * a.x_ctot + a.x_coff + ci] : (tid < 24 ? 1.f : 0.f);
+        }
+    };
     auto prefetch = [&](int chunk) {
 #pragma unroll
         for (int s = 0; s < kUnits; ++s) {
             const int c0 = chunk * kCKC + s_chg[s] * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int ci = min(c0 + i, a.cin - 1);
-                st[s][i] = xb[(size_t)ci * HWp + s_goff[s]];
-                psc[s][i] = 1.f;
-                psh[s][i] = 0.f;
-                if (a.in_scale) {                       // fetched with the tile, not at first use
-                    psc[s][i] = a.in_scale[aff + ci];
-                    psh[s][i] = a.in_shift[aff + ci];
-                }
-            }
+            for (int i = 0; i < 8; ++i) st[s][i] = xs[s][min(c0 + i, a.cin - 1) * HWp];
         }
-        // this group's MB blocks of every K-step: 7 contiguous pieces of MB*192 uint4
-        const uint4* src = a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192;
+        fetch_aff(chunk + 1);                         // stored as the next table during this chunk's staging phase
+        // this group's MB blocks of every K-step: 7 contiguous runs of MB*3 pieces.  The piece index is wave-uniform,
+        // so its step / offset arithmetic runs on the scalar unit and the load is base + lane.
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane);
 #pragma unroll
         for (int q = 0; q < WSL; ++q) {
-            const int e = tid + q * kT;
-            const int st_ = e / (MB * 192), within = e - st_ * (MB * 192);
-            wst[q] = e < WCH ? src[(size_t)st_ * a.nblkp * 192 + within] : make_uint4(0, 0, 0, 0);
+            const int u = min(wave + q * (kT / 64), NWU - 1);
+            const int st_ = u / (MB * 3);
+            wst[q] = src[(st_ * a.nblkp * 3 + (u - st_ * (MB * 3))) * 64];
         }
     };
 
@@ -195,18 +204,26 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) boff[b] = ((2 * wave + (b >> 1)) * kHW_ + 16 * (b & 1) + nn) * kPS;
 
+    fetch_aff(0);
+    if (tid < 48) lds_aff[tid] = my_aff;              // chunk 0's table; visible after the loop's first barrier
     prefetch(0);
     for (int chunk = 0; chunk < a.chunks; ++chunk) {
         __syncthreads();
-        // ---- registers -> LDS: lazy activation, split into three bf16 parts, [pixel][channel] image
+        // ---- registers -> LDS: lazy activation, split into three bf16 parts, [pixel][channel] image.  Channels past
+        // cin were loaded from a clamped (real) channel and meet zero weights: no select needed for them.
+        const float* afc = lds_aff + (chunk & 1) * 48;
+        if (tid < 48) lds_aff[((chunk + 1) & 1) * 48 + tid] = my_aff;      // the NEXT chunk's table (prefetched below)
 #pragma unroll
         for (int s = 0; s < kUnits; ++s) {
             uint32_t q1[4], q2[4], q3[4];
-            const int c0 = chunk * kCKC + s_chg[s] * 8;
+            const f4 sc0 = *reinterpret_cast<const f4*>(afc + s_chg[s] * 8), sc1 = *reinterpret_cast<const f4*>(afc + s_chg[s] * 8 + 4);
+            const f4 sh0 = *reinterpret_cast<const f4*>(afc + 24 + s_chg[s] * 8), sh1 = *reinterpret_cast<const f4*>(afc + 24 + s_chg[s] * 8 + 4);
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
-                const float v0 = (s_in[s] && c0 + i < a.cin) ? san_act(st[s][i], psc[s][i], psh[s][i], a.in_slope) : 0.f;
-                const float v1 = (s_in[s] && c0 + i + 1 < a.cin) ? san_act(st[s][i + 1], psc[s][i + 1], psh[s][i + 1], a.in_slope) : 0.f;
+                const float sca = i < 4 ? sc0[i] : sc1[i - 4], scb = i < 4 ? sc0[i + 1] : sc1[i - 3];
+                const float sha = i < 4 ? sh0[i] : sh1[i - 4], shb = i < 4 ? sh0[i + 1] : sh1[i - 3];
+                const float v0 = s_in[s] ? san_act(st[s][i], sca, sha, a.in_slope) : 0.f;
+                const float v1 = s_in[s] ? san_act(st[s][i + 1], scb, shb, a.in_slope) : 0.f;
                 split3_pair(v0, v1, q1[i >> 1], q2[i >> 1], q3[i >> 1]);
             }
             if (s_loff[s] >= 0) {
@@ -217,8 +234,8 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < WSL; ++q) {
-            const int e = tid + q * kT;
-            if (e < WCH) lds_w[e] = wst[q];
+            const int u = wave + q * (kT / 64);
+            if (u < NWU) *reinterpret_cast<u32x4*>(lds_w + u * 64 + lane) = wst[q];
         }
         __syncthreads();
         if (chunk + 1 < a.chunks) prefetch(chunk + 1);
@@ -409,7 +426,7 @@ int pick_mb(int cout, int tiles) {
 
 template <int MB>
 int launch_b(const BArgs& a, hipStream_t s) {
-    constexpr size_t lds = 3 * (size_t)kPartB + (size_t)kSteps * MB * 3 * 64 * 16;
+    constexpr size_t lds = 3 * (size_t)kPartB + (size_t)kSteps * MB * 3 * 64 * 16 + 2 * 48 * sizeof(float);
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB>),
