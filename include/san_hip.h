@@ -338,6 +338,19 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
                           float* y, int y_ctot, int y_coff, int cout, float* part_stats,
                           int n, int h, int w, void* stream);
 
+/* 3x3 weight gradient on the bf16 matrix cores, fp32-level accuracy (csrc/san_wgrad_bf16.hip): same
+ * contract as san_conv2d_wgrad for ks = 3 (backward of F.conv2d at varnet.py:140,143 / unet.py:119-140
+ * w.r.t. the weight), used where san_conv_wgrad_bf16x3_eligible() says so.  scratch: 16-byte aligned
+ * device buffer of san_conv_wgrad_bf16x3_scratch_bytes(n,h,w,cin,cout) bytes (split bf16 planes of x
+ * and dy + per-workgroup partial tiles); nothing is kept in it after the call returns. */
+int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int ks);
+size_t san_conv_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cout);
+int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin,
+                            const float* in_scale, const float* in_shift, float in_slope,
+                            const float* dy, int dy_ctot, int dy_coff, int cout,
+                            float* dw, int accumulate, void* scratch,
+                            int n, int h, int w, void* stream);
+
 /* Batched weight packing for training, where every weight changes every step: san_conv_pack_job
  * fills one HOST table entry (8 x int64) for a weight/packed-buffer pair -- mode 0: Conv2d forward
  * (san_conv_pack_weights_fwd), 1: ConvTranspose2d 2x2 (san_conv_pack_weights transposed), 2: Conv2d

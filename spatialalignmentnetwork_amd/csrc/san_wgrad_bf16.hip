@@ -1,0 +1,486 @@
+// 3x3 weight gradient on the bf16 matrix cores with fp32-grade accuracy ("bf16x3", as san_conv_bf16.hip):
+//   dw[co][ci][ky][kx] (+)= sum_{n,y,x} dy[n][co][y][x] * T(x)[n][ci][y+ky-1][x+kx-1]
+// (the backward of F.conv2d at varnet.py:140,143 and unet.py:119-140 w.r.t. the weights).
+//
+// As a GEMM per tap the contraction index is the PIXEL, and v_mfma_f32_16x16x32_bf16 wants 8 consecutive
+// contraction elements per lane -- i.e. 8 neighbouring pixels of one channel row: in NCHW that is already
+// contiguous memory.  So there is no transposition and no LDS in the main loop:
+//
+//   pass 1 (split_planes_kernel, HBM-bound): T(x) and dy are split ONCE into three bf16 planes each
+//     (a = a1 + a2 + a3), stored [part][n][c / 16][Hp][Wp / 8][c % 16][8 pixels] with a zero frame (one zero
+//     row on top, zero rows below, one zero 8-pixel piece left and right, channels padded to 16) so that
+//     every read of pass 2 is unconditional -- and so that the 64 lanes of a wave (16 channels x 4
+//     neighbouring pieces) read 1 KB of CONTIGUOUS memory per operand load.
+//   pass 2 (wgrad_bf16x3_kernel): a wave owns one block of 16 input channels x NB blocks of 16 output
+//     channels x all 9 taps (9 NB accumulator tiles) and four "piece columns": an 8-pixel-wide column of L
+//     image rows per group of 16 lanes.  Per row step a lane loads its own 16-byte operand pieces straight from
+//     L2 into the MFMA operand registers (3 parts of one new x row, 3 parts x NB of one dy row; both are
+//     fetched one step ahead), derives the kx = 0 / 2 operands of the x row with 5 v_alignbit per part from
+//     the aligned piece and its two neighbour dwords, keeps the three x rows of the window in registers and
+//     issues 54 NB MFMAs (9 taps x NB x the six part products a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1).
+//     The four waves of a workgroup work on the same channel tile over different pixels and add their
+//     tiles through LDS, so one partial tile per workgroup goes to HBM.
+//   pass 3 (wgrad_bf16x3_reduce_kernel): fixed-order sum over the workgroups' partial tiles -> dw.
+//
+// Deterministic (no atomics).  Accuracy is that of the forward bf16x3 kernel (dropped terms O(2^-24)).
+#include "san_common.h"
+
+#include <cstdint>
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float fl2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+union Frag {
+    u32x4 u;
+    bf8 v;
+};
+
+constexpr int kWaves = 4;
+constexpr int kWT = kWaves * 64;
+
+__device__ __forceinline__ uint32_t cvt_pk(float a, float b) {
+    fl2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+}
+// (f0, f1) -> three packed bf16 pairs with p1 + p2 + p3 == f to ~2^-24 relative (low half = f0)
+__device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = cvt_pk(f0, f1);
+    const float r0 = f0 - __builtin_bit_cast(float, p1 << 16), r1 = f1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = cvt_pk(r0, r1);
+    p3 = cvt_pk(r0 - __builtin_bit_cast(float, p2 << 16), r1 - __builtin_bit_cast(float, p2 & 0xffff0000u));
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pass 1: fp32 NCHW view (+ lazy affine / LeakyReLU) -> three framed bf16 planes.  One thread per 8-pixel piece.
+struct SplitOne {
+    const float* src;
+    const float* scale;
+    const float* shift;
+    float slope;
+    int ctot, coff, C, CB;     // channel view; CB = blocks of 16 channels written (>= cdiv(C, 16), the rest zero)
+    uint16_t* out;
+    long long plane;           // elements per part plane
+    long long total;           // pieces = N * CB * Hp * npw * 16
+    int vec;                   // rows are 16-byte aligned and W % 4 == 0
+};
+struct SplitArgs {
+    SplitOne t[2];             // x, dy: one launch
+    unsigned blocks0;          // workgroups of t[0]
+    int H, W, Hp, npw;         // framed rows, framed pieces per row (= Wp / 8)
+};
+
+__global__ void __launch_bounds__(256) split_planes_kernel(const SplitArgs a) {
+    const int which = blockIdx.x >= a.blocks0;
+    const SplitOne& o = a.t[which];
+    const long long idx = (long long)(blockIdx.x - (which ? a.blocks0 : 0u)) * 256 + threadIdx.x;
+    if (idx >= o.total) return;
+    // [n][cb][row][piece][c16]: a wave = 16 channels x 4 pieces reads 16 full 128-byte lines, writes 1 KB contiguous
+    const int c16 = (int)(idx & 15);
+    long long t = idx >> 4;
+    const int pc = (int)(t % a.npw);
+    t /= a.npw;
+    const int row = (int)(t % a.Hp);
+    const int ncb = (int)(t / a.Hp);
+    const int n = ncb / o.CB, c = (ncb - n * o.CB) * 16 + c16;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    const int x0 = 8 * (pc - 1), y = row - 1;
+    if (c < o.C && y >= 0 && y < a.H && x0 >= 0 && x0 < a.W) {
+        const float* p = o.src + ((size_t)(n * o.ctot + o.coff + c) * a.H + y) * a.W + x0;
+        float sc = 1.f, sh = 0.f;
+        if (o.scale) {
+            sc = o.scale[n * o.ctot + o.coff + c];
+            sh = o.shift[n * o.ctot + o.coff + c];
+        }
+        if (o.vec) {
+            const f4 lo = *reinterpret_cast<const f4*>(p);
+            f4 hi = {0.f, 0.f, 0.f, 0.f};
+            const bool has_hi = x0 + 4 < a.W;
+            if (has_hi) hi = *reinterpret_cast<const f4*>(p + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = san_act(lo[i], sc, sh, o.slope);
+                v[4 + i] = has_hi ? san_act(hi[i], sc, sh, o.slope) : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (x0 + i < a.W) v[i] = san_act(p[i], sc, sh, o.slope);
+        }
+    }
+    u32x4 q1, q2, q3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint32_t p1, p2, p3;
+        split3_pair(v[2 * i], v[2 * i + 1], p1, p2, p3);
+        q1[i] = p1;
+        q2[i] = p2;
+        q3[i] = p3;
+    }
+    uint16_t* w = o.out + idx * 8;
+    *reinterpret_cast<u32x4*>(w) = q1;
+    *reinterpret_cast<u32x4*>(w + o.plane) = q2;
+    *reinterpret_cast<u32x4*>(w + 2 * o.plane) = q3;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// pass 2
+struct WBArgs {
+    const uint16_t* xs;        // framed planes of T(x): [3][N][ci_b][Hp][npw][16][8]
+    const uint16_t* dys;       // framed planes of dy:   [3][N][ncog * NB][Hp][npw][16][8]
+    long long xplane, dyplane; // elements per part plane
+    float* partial;            // [P][9][cin_pad][cout_pad]
+    int N, cin, cout;
+    int Hp, npw, npc, nbands, L;
+    int Q;                     // piece columns = N * nbands * npc
+    int P;                     // workgroup partitions of the piece columns (16 columns each)
+    int ci_b, ncog, cin_pad, cout_pad;
+};
+
+struct XRow {
+    Frag f[3][3];              // [part][kx]: the 8 pixels x0 + kx - 1 .. of one channel row
+};
+
+template <int NB>
+__global__ void __launch_bounds__(kWT) wgrad_bf16x3_kernel(const WBArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+
+    // XCD-aware order: consecutive logical ids (channel tile fastest, then pixel partition) share an L2
+    int lin;
+    {
+        const int total = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        lin = xcd * (total >> 3) + min(xcd, total & 7) + slot;
+    }
+    const int tiles = a.ci_b * a.ncog;
+    const int tile = lin % tiles, pp = lin / tiles;
+    const int cib = tile % a.ci_b, cog = tile / a.ci_b;
+
+    // this lane group's piece column
+    const int q = (pp * kWaves + wave) * 4 + g;
+    const bool valid = q < a.Q;
+    const int qc = min(q, a.Q - 1);
+    const int xp = qc % a.npc;
+    const int band = (qc / a.npc) % a.nbands;
+    const int n = qc / (a.npc * a.nbands);
+    const int r0 = band * a.L;                          // first image row; framed row index = image row + 1
+
+    const int rowstride = a.npw * 128;                  // elements per framed row of one channel block
+    int xcur = (((n * a.ci_b + cib) * a.Hp + r0) * a.npw + xp + 1) * 128 + c * 8;      // framed row r0 = image row r0 - 1
+    int dybase[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)   // a group without a column reads the zero top row of the frame, with row stride 0
+        dybase[nb] = (((n * a.ncog * NB + cog * NB + nb) * a.Hp + (valid ? r0 + 1 : 0)) * a.npw + xp + 1) * 128 + c * 8;
+    const int dystep = valid ? rowstride : 0;
+    int dyrow = 0;
+
+    const uint16_t* xpl[3] = {a.xs, a.xs + a.xplane, a.xs + 2 * a.xplane};
+    const uint16_t* dpl[3] = {a.dys, a.dys + a.dyplane, a.dys + 2 * a.dyplane};
+
+    u32x4 rd[3];
+    uint32_t rm[3], rp[3];
+    auto load_raw = [&]() {                             // the x row at xcur: aligned piece + the dword on each side
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint16_t* s = xpl[p] + xcur;
+            rd[p] = *reinterpret_cast<const u32x4*>(s);
+            rm[p] = *reinterpret_cast<const uint32_t*>(s - 122);      // pixels 6, 7 of the piece to the left
+            rp[p] = *reinterpret_cast<const uint32_t*>(s + 128);      // pixels 0, 1 of the piece to the right
+        }
+        xcur += rowstride;
+    };
+    auto make_row = [&](XRow& r) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const u32x4 d = rd[p];
+            const uint32_t s01 = __builtin_amdgcn_alignbit(d[1], d[0], 16), s12 = __builtin_amdgcn_alignbit(d[2], d[1], 16),
+                           s23 = __builtin_amdgcn_alignbit(d[3], d[2], 16);
+            r.f[p][1].u = d;
+            r.f[p][0].u = u32x4{__builtin_amdgcn_alignbit(d[0], rm[p], 16), s01, s12, s23};
+            r.f[p][2].u = u32x4{s01, s12, s23, __builtin_amdgcn_alignbit(rp[p], d[3], 16)};
+        }
+    };
+    Frag dyf[NB][3];
+    auto load_dy = [&](int nb) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) dyf[nb][p].u = *reinterpret_cast<const u32x4*>(dpl[p] + dybase[nb] + dyrow);
+    };
+
+    f4 acc[9][NB];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f4{0.f, 0.f, 0.f, 0.f};
+
+    XRow ra, rb, rc;
+    load_raw();
+    make_row(ra);
+    load_raw();
+    make_row(rb);
+    load_raw();
+    make_row(rc);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) load_dy(nb);
+    dyrow += dystep;
+
+    // one image row: r0 = rows above / at / below the dy row; the x row two below is fetched during the step
+    // and replaces r0's registers at its end; dy block nb of the next row is fetched once block nb is done.
+    // (the scheduling barriers pin the prefetches where they are written: left alone, the scheduler sinks every load
+    // to just before its first use -- fewer live registers, fully exposed latency)
+    auto step = [&](XRow& w0, XRow& w1, XRow& w2) {
+        load_raw();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+                for (int pb = 0; pb < 3 - pa; ++pb) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        acc[kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.f[pa][kx].v, dyf[nb][pb].v, acc[kx][nb], 0, 0, 0);
+                        acc[3 + kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.f[pa][kx].v, dyf[nb][pb].v, acc[3 + kx][nb], 0, 0, 0);
+                        acc[6 + kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2.f[pa][kx].v, dyf[nb][pb].v, acc[6 + kx][nb], 0, 0, 0);
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            load_dy(nb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        dyrow += dystep;
+        make_row(w0);
+    };
+    for (int t = 0; t < a.L; t += 3) {
+        step(ra, rb, rc);
+        step(rb, rc, ra);
+        step(rc, ra, rb);
+    }
+
+    // ---- the four waves' tiles -> one: waves 1..3 park theirs in LDS, wave 0 adds them in a fixed order
+    f4* red = reinterpret_cast<f4*>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) red[((wave - 1) * 9 * NB + t * NB + nb) * 64 + lane] = acc[t][nb];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.partial + (size_t)pp * 9 * a.cin_pad * a.cout_pad;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f4 s = acc[t][nb];
+#pragma unroll
+                for (int w = 0; w < kWaves - 1; ++w) s += red[(w * 9 * NB + t * NB + nb) * 64 + lane];
+                // D[m = 4 g + r][n = c]: rows = input channel of the block, columns = output channel
+                float* o = out + ((size_t)t * a.cin_pad + cib * 16 + 4 * g) * a.cout_pad + (cog * NB + nb) * 16 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(size_t)r * a.cout_pad] = s[r];
+            }
+    }
+}
+
+// pass 3: dw[co][ci][tap] (+)= sum_pp partial[pp][tap][ci][co], fixed order
+__global__ void __launch_bounds__(256) wgrad_bf16x3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                   int P, int cin, int cout, int cin_pad, int cout_pad,
+                                                                   int accumulate) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= cout * cin * 9) return;
+    const int co = e % cout;
+    const int ci = (e / cout) % cin;
+    const int tap = e / (cout * cin);
+    const size_t stride = (size_t)9 * cin_pad * cout_pad;
+    const float* p = partial + ((size_t)tap * cin_pad + ci) * cout_pad + co;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int pp = 0;
+    for (; pp + 4 <= P; pp += 4) {
+        s0 += p[(size_t)pp * stride];
+        s1 += p[(size_t)(pp + 1) * stride];
+        s2 += p[(size_t)(pp + 2) * stride];
+        s3 += p[(size_t)(pp + 3) * stride];
+    }
+    for (; pp < P; ++pp) s0 += p[(size_t)pp * stride];
+    const float s = (s0 + s1) + (s2 + s3);
+    float* o = dw + ((size_t)co * cin + ci) * 9 + tap;
+    *o = accumulate ? *o + s : s;
+}
+
+struct WBPlan {
+    int ci_b, nco_b, NB, ncog, npc, nbands, L, Hp, Wp, Q, P, tiles, cin_pad, cout_pad;
+    long long xplane, dyplane;
+    size_t x_bytes, dy_bytes, partial_bytes;
+};
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+WBPlan wb_plan(int n, int h, int w, int cin, int cout) {
+    WBPlan p{};
+    p.ci_b = san_cdiv(cin, 16);
+    p.nco_b = san_cdiv(cout, 16);
+    // output-channel blocks per wave: the split of nco_b into groups that wastes the fewest blocks, ties to the larger
+    int best = 0;
+    double best_eff = 0.0;
+    for (int nb = 4; nb >= 2; --nb) {                     // (NB = 5 does not fit the register file without spilling)
+        const int gcount = san_cdiv(p.nco_b, nb);
+        const double eff = (double)p.nco_b / (gcount * nb);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = nb;
+        }
+    }
+    p.NB = best;
+    p.ncog = san_cdiv(p.nco_b, p.NB);
+    p.tiles = p.ci_b * p.ncog;
+    p.npc = san_cdiv(w, 8);
+    // enough workgroups to fill the chip twice, but at least 6 rows per column (3 rows of window fill per column)
+    const int p_target = san_cdiv(512, p.tiles);
+    int nbands = san_cdiv(p_target * 16, n * p.npc);
+    const int max_bands = h / 6 > 1 ? h / 6 : 1;
+    if (nbands > max_bands) nbands = max_bands;
+    if (nbands < 1) nbands = 1;
+    p.L = 3 * san_cdiv(san_cdiv(h, nbands), 3);
+    p.nbands = san_cdiv(h, p.L);
+    p.Hp = p.nbands * p.L + 3;
+    p.Wp = 8 * (p.npc + 2);
+    p.Q = n * p.nbands * p.npc;
+    p.P = san_cdiv(p.Q, 16);
+    p.cin_pad = p.ci_b * 16;
+    p.cout_pad = p.ncog * p.NB * 16;
+    p.xplane = (long long)n * p.cin_pad * p.Hp * p.Wp;
+    p.dyplane = (long long)n * p.cout_pad * p.Hp * p.Wp;
+    p.x_bytes = align256((size_t)p.xplane * 6);
+    p.dy_bytes = align256((size_t)p.dyplane * 6);
+    p.partial_bytes = align256((size_t)p.P * 9 * p.cin_pad * p.cout_pad * sizeof(float));
+    return p;
+}
+
+template <int NB>
+int launch_wb(const WBArgs& a, int grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)(kWaves - 1) * 9 * NB * 64 * sizeof(f4);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<NB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            san_set_error("cannot reserve %d bytes of LDS for the bf16x3 weight gradient", (int)lds);
+            return SAN_E_UNSUPPORTED;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((wgrad_bf16x3_kernel<NB>), dim3(grid), dim3(kWT), lds, s, a);
+    return SAN_OK;
+}
+
+SplitOne split_one(const float* src, int ctot, int coff, int C, int CB, const float* scale, const float* shift, float slope,
+                   int n, int w, const WBPlan& p, uint16_t* out, long long plane) {
+    SplitOne o{};
+    o.src = src;
+    o.scale = scale;
+    o.shift = shift;
+    o.slope = slope;
+    o.ctot = ctot;
+    o.coff = coff;
+    o.C = C;
+    o.CB = CB;
+    o.out = out;
+    o.plane = plane;
+    o.total = (long long)n * CB * p.Hp * (p.Wp / 8) * 16;
+    o.vec = ((uintptr_t)src & 15) == 0 && (w % 4) == 0;
+    return o;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when san_conv2d_wgrad_bf16x3 takes this layer: 3x3, both channel counts fill 16-wide MFMA tiles
+int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int ks) {
+    if (ks != 3 || n <= 0) return 0;
+    if (cin < 32 || cout < 32) return 0;
+    if (h < 6 || w < 8) return 0;
+    const WBPlan p = wb_plan(n, h, w, cin, cout);
+    if (p.xplane >= (1ll << 30) || p.dyplane >= (1ll << 30)) return 0;      // 32-bit element offsets in the kernel
+    return 1;
+}
+
+// bytes of scratch san_conv2d_wgrad_bf16x3 needs (split planes of x and dy + the partial tiles)
+size_t san_conv_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    const WBPlan p = wb_plan(n, h, w, cin, cout);
+    return p.x_bytes + p.dy_bytes + p.partial_bytes;
+}
+
+int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                            float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                            void* scratch, int n, int h, int w, void* stream) {
+    SAN_CHECK_ARG(x && dy && dw && scratch, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
+    SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && dy_coff >= 0 && dy_coff + cout <= dy_ctot, "bad channel view");
+    SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
+    SAN_CHECK_ARG(san_conv_wgrad_bf16x3_eligible(n, h, w, cin, cout, 3), "layer not eligible (see san_conv_wgrad_bf16x3_eligible)");
+    SAN_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
+    const WBPlan p = wb_plan(n, h, w, cin, cout);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned char* base = static_cast<unsigned char*>(scratch);
+    uint16_t* xs = reinterpret_cast<uint16_t*>(base);
+    uint16_t* dys = reinterpret_cast<uint16_t*>(base + p.x_bytes);
+    float* partial = reinterpret_cast<float*>(base + p.x_bytes + p.dy_bytes);
+
+    SplitArgs sa{};
+    sa.t[0] = split_one(x, x_ctot, x_coff, cin, p.ci_b, in_scale, in_shift, in_slope, n, w, p, xs, p.xplane);
+    sa.t[1] = split_one(dy, dy_ctot, dy_coff, cout, p.cout_pad / 16, nullptr, nullptr, 1.f, n, w, p, dys, p.dyplane);
+    sa.blocks0 = (unsigned)((sa.t[0].total + 255) / 256);
+    sa.H = h;
+    sa.W = w;
+    sa.Hp = p.Hp;
+    sa.npw = p.Wp / 8;
+    hipLaunchKernelGGL(split_planes_kernel, dim3(sa.blocks0 + (unsigned)((sa.t[1].total + 255) / 256)), dim3(256), 0, s, sa);
+    SAN_LAUNCH_CHECK();
+
+    WBArgs a{};
+    a.xs = xs;
+    a.dys = dys;
+    a.xplane = p.xplane;
+    a.dyplane = p.dyplane;
+    a.partial = partial;
+    a.N = n;
+    a.cin = cin;
+    a.cout = cout;
+    a.Hp = p.Hp;
+    a.npw = p.Wp / 8;
+    a.npc = p.npc;
+    a.nbands = p.nbands;
+    a.L = p.L;
+    a.Q = p.Q;
+    a.P = p.P;
+    a.ci_b = p.ci_b;
+    a.ncog = p.ncog;
+    a.cin_pad = p.cin_pad;
+    a.cout_pad = p.cout_pad;
+    const int grid = p.P * p.tiles;
+    int rc = SAN_OK;
+    switch (p.NB) {
+        case 2: rc = launch_wb<2>(a, grid, s); break;
+        case 3: rc = launch_wb<3>(a, grid, s); break;
+        default: rc = launch_wb<4>(a, grid, s); break;
+    }
+    if (rc != SAN_OK) return rc;
+    SAN_LAUNCH_CHECK();
+    const int count = cout * cin * 9;
+    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 256)), dim3(256), 0, s, partial, dw, p.P, cin, cout,
+                       p.cin_pad, p.cout_pad, accumulate);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+}  // extern "C"

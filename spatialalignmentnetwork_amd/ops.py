@@ -48,7 +48,7 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
-TIMED_KERNELS = ("conv3x3", "conv3x3_bf16x3", "wgrad3x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
+TIMED_KERNELS = ("conv3x3", "conv3x3_bf16x3", "wgrad3x3", "wgrad3x3_bf16x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
 
 
 def _timed(name, work, unit, fn):
@@ -102,6 +102,15 @@ class Arena:
         t = self._bufs.get(key)
         if t is None:
             t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
+            self._bufs[key] = t
+        return t
+
+    def scratch(self, name: str, nbytes: int, device) -> torch.Tensor:
+        """One grow-only byte buffer per name (launches on one stream are ordered, so successive users may share it)."""
+        key = (name, "scratch", str(device))
+        t = self._bufs.get(key)
+        if t is None or t.numel() < nbytes:
+            t = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
             self._bufs[key] = t
         return t
 
@@ -645,12 +654,19 @@ def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, ar
     """dw [cout, cin, ks, ks] (+)= correlation of dy with the lazily activated forward input x."""
     cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
     assert x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
+    flops = 2.0 * x.n * x.h * x.w * cout * cin * ks * ks
+    if USE_BF16X3[0] and lib().query("san_conv_wgrad_bf16x3_eligible", x.n, x.h, x.w, cin, cout, ks):
+        nbytes = lib().query("san_conv_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
+        scratch = arena.scratch("wgrad_bf16x3", nbytes, x.buf.device)
+        args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
+                cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
+        _timed("wgrad3x3_bf16x3", flops, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args))
+        return
     P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout, ks)
     partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff, cout,
             _p(_chk(dw, name="dw")), int(accumulate), _p(partial), x.n, x.h, x.w, ks, _stream())
-    _timed("wgrad3x3" if ks == 3 else "wgrad1x1", 2.0 * x.n * x.h * x.w * cout * cin * ks * ks, "FLOP",
-           lambda: lib().call("san_conv2d_wgrad", *args))
+    _timed("wgrad3x3" if ks == 3 else "wgrad1x1", flops, "FLOP", lambda: lib().call("san_conv2d_wgrad", *args))
 
 
 def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA) -> None:
