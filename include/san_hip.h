@@ -340,9 +340,11 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
 
 /* 3x3 weight gradient on the bf16 matrix cores, fp32-level accuracy (csrc/san_wgrad_bf16.hip): same
  * contract as san_conv2d_wgrad for ks = 3 (backward of F.conv2d at varnet.py:140,143 / unet.py:119-140
- * w.r.t. the weight), used where san_conv_wgrad_bf16x3_eligible() says so.  scratch: 16-byte aligned
+ * w.r.t. the weight).  _supported(): the kernel can run the layer; _eligible(): it is also the faster
+ * choice (what the dispatcher asks).  scratch: 16-byte aligned
  * device buffer of san_conv_wgrad_bf16x3_scratch_bytes(n,h,w,cin,cout) bytes (split bf16 planes of x
  * and dy + per-workgroup partial tiles); nothing is kept in it after the call returns. */
+int san_conv_wgrad_bf16x3_supported(int n, int h, int w, int cin, int cout, int ks);
 int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int ks);
 size_t san_conv_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cout);
 int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin,

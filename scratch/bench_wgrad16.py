@@ -20,10 +20,11 @@ def run(N, cin, cout, h, w, check, time=True):
     for name, flag in (("bf16x3", True), ("fp32", False)):
         ops.USE_BF16X3[0] = flag
         dw = torch.full((cout, cin, 3, 3), float('nan'), device=dev)
-        ops.conv2d_wgrad(xa, da, dw)
+        fn = ops.conv2d_wgrad_bf16x3 if flag else ops.conv2d_wgrad
+        fn(xa, da, dw)
         out[name] = dw.clone()
         if time:
-            t = bench(lambda: ops.conv2d_wgrad(xa, da, dw))
+            t = bench(lambda: fn(xa, da, dw))
             msg += f"  {name} {t:8.1f} us ({2.0 * N * h * w * cin * cout * 9 / t / 1e6:6.1f} TF)"
     ops.USE_BF16X3[0] = True
     if check:
@@ -36,13 +37,13 @@ def run(N, cin, cout, h, w, check, time=True):
             msg += f"  {name} rel {err:.2e} max {mx:.2e}"
         # accumulate path
         dw = out["bf16x3"].clone()
-        ops.conv2d_wgrad(xa, da, dw, accumulate=True)
+        ops.conv2d_wgrad_bf16x3(xa, da, dw, accumulate=True)
         msg += f"  acc {((dw.double() - 2 * wt.grad).norm() / wt.grad.norm()).item():.1e}"
     print(msg, flush=True)
 if '--check' in sys.argv:
     for N, cin, cout, h, w in [(2, 32, 32, 16, 32), (1, 72, 72, 20, 44), (2, 36, 72, 40, 40), (1, 96, 32, 33, 52), (2, 144, 144, 24, 24),
                                (1, 288, 144, 16, 16), (3, 40, 50, 7, 12), (1, 32, 48, 23, 23), (2, 64, 64, 30, 46)]:
         run(N, cin, cout, h, w, True, time=False)
-for cin, cout, s in [(36, 36, 160), (72, 36, 160), (36, 72, 80), (72, 72, 80), (144, 72, 80), (72, 144, 40), (144, 144, 40), (288, 144, 40),
+for cin, cout, s in [(18, 18, 320), (36, 18, 320), (18, 36, 160), (32, 16, 320), (24, 24, 160), (36, 36, 160), (72, 36, 160), (36, 72, 80), (72, 72, 80), (144, 72, 80), (72, 144, 40), (144, 144, 40), (288, 144, 40),
                      (144, 288, 20), (288, 288, 20), (32, 32, 320), (96, 32, 320), (64, 64, 160), (128, 64, 160), (64, 64, 80), (64, 64, 40)]:
     run(8, cin, cout, s, s, False)

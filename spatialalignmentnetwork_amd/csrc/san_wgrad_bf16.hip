@@ -403,13 +403,20 @@ SplitOne split_one(const float* src, int ctot, int coff, int C, int CB, const fl
 
 extern "C" {
 
-// 1 when san_conv2d_wgrad_bf16x3 takes this layer: 3x3, both channel counts fill 16-wide MFMA tiles
-int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int ks) {
-    if (ks != 3 || n <= 0) return 0;
-    if (cin < 32 || cout < 32) return 0;
-    if (h < 6 || w < 8) return 0;
+// 1 when the bf16x3 weight gradient is the faster choice for this layer (what the dispatcher asks); the kernel
+// itself runs any 3x3 layer whose split planes stay below 2^30 elements (san_conv_wgrad_bf16x3_supported).
+int san_conv_wgrad_bf16x3_supported(int n, int h, int w, int cin, int cout, int ks) {
+    if (ks != 3 || n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
     const WBPlan p = wb_plan(n, h, w, cin, cout);
     if (p.xplane >= (1ll << 30) || p.dyplane >= (1ll << 30)) return 0;      // 32-bit element offsets in the kernel
+    return 1;
+}
+
+int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int ks) {
+    if (!san_conv_wgrad_bf16x3_supported(n, h, w, cin, cout, ks)) return 0;
+    if (cin < 32 || cout < 32) return 0;                     // 18- and 24-channel layers: the fp32 kernel is still faster
+    if (h < 6 || w < 8) return 0;
+    if ((double)n * h * w * cin * cout < 1.0e8) return 0;    // too little work to pay for three launches
     return 1;
 }
 
@@ -427,7 +434,7 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, con
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && dy_coff >= 0 && dy_coff + cout <= dy_ctot, "bad channel view");
     SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
-    SAN_CHECK_ARG(san_conv_wgrad_bf16x3_eligible(n, h, w, cin, cout, 3), "layer not eligible (see san_conv_wgrad_bf16x3_eligible)");
+    SAN_CHECK_ARG(san_conv_wgrad_bf16x3_supported(n, h, w, cin, cout, 3), "layer too large for 32-bit plane offsets (see san_conv_wgrad_bf16x3_supported)");
     SAN_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
     const WBPlan p = wb_plan(n, h, w, cin, cout);
     hipStream_t s = (hipStream_t)stream;

@@ -656,17 +656,27 @@ def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, ar
     assert x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
     flops = 2.0 * x.n * x.h * x.w * cout * cin * ks * ks
     if USE_BF16X3[0] and lib().query("san_conv_wgrad_bf16x3_eligible", x.n, x.h, x.w, cin, cout, ks):
-        nbytes = lib().query("san_conv_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
-        scratch = arena.scratch("wgrad_bf16x3", nbytes, x.buf.device)
-        args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
-                cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
-        _timed("wgrad3x3_bf16x3", flops, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args))
+        conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena)
         return
     P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout, ks)
     partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff, cout,
             _p(_chk(dw, name="dw")), int(accumulate), _p(partial), x.n, x.h, x.w, ks, _stream())
     _timed("wgrad3x3" if ks == 3 else "wgrad1x1", flops, "FLOP", lambda: lib().call("san_conv2d_wgrad", *args))
+
+
+def conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
+    """The 3x3 weight gradient on the bf16 matrix cores (three-way split operands, fp32-level accuracy;
+    csrc/san_wgrad_bf16.hip).  conv2d_wgrad dispatches here where san_conv_wgrad_bf16x3_eligible says so."""
+    cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
+    assert ks == 3 and x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
+    if not lib().query("san_conv_wgrad_bf16x3_supported", x.n, x.h, x.w, cin, cout, ks):
+        raise RuntimeError("layer too large for the bf16x3 weight gradient")
+    nbytes = lib().query("san_conv_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
+    scratch = arena.scratch("wgrad_bf16x3", nbytes, x.buf.device)
+    args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
+            cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
+    _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args))
 
 
 def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA) -> None:

@@ -692,6 +692,42 @@ def test_conv_bf16x3_vs_float64(S, n, cin, cout, h, w):
     assert rel_err(dx.cpu(), a64.grad.float()) < 3e-6
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 72, 72, 20, 44), (2, 36, 72, 40, 40), (1, 96, 32, 33, 52), (2, 144, 144, 24, 24),
+                                            (4, 288, 144, 16, 16), (8, 40, 50, 14, 12), (2, 32, 48, 31, 31), (2, 64, 64, 30, 46)])
+def test_wgrad_bf16x3_vs_float64(S, n, cin, cout, h, w):
+    """The bf16 matrix-core weight gradient with three-way split operands (csrc/san_wgrad_bf16.hip) against float64:
+    lazily activated input read through a channel view, dy through a channel view, widths that are not a multiple
+    of 8 or 4, ragged row bands, overwrite and accumulate.  Bar: 3e-6 relative L2 and 3e-6 of the largest entry."""
+    ops = S.ops
+    x = philox("wb.x", (n, cin + 3, h, w))
+    dy = philox("wb.dy", (n, cout + 2, h, w))
+    sc, sh = philox("wb.sc", (n, cin + 3), lo=0.5, hi=1.5), philox("wb.sh", (n, cin + 3))
+    act = torch.nn.functional.leaky_relu(x[:, 3:] * sc[:, 3:, None, None] + sh[:, 3:, None, None], 0.2).double()
+    wt = torch.zeros(cout, cin, 3, 3, dtype=torch.double, requires_grad=True)
+    torch.nn.functional.conv2d(act, wt, padding=1).backward(dy[:, 2:].double())
+    ref = wt.grad
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
+    xa, da = ops.Act(g(x), 3, cin, g(sc), g(sh), 0.2), ops.Act(g(dy), 2, cout, None, None, 1.0)
+    ops.conv2d_wgrad_bf16x3(xa, da, dw)
+    got = dw.cpu().double()
+    assert ((got - ref).norm() / ref.norm()).item() < 3e-6
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 3e-6
+    ops.conv2d_wgrad_bf16x3(xa, da, dw, accumulate=True)
+    assert ((dw.cpu().double() - 2 * ref).norm() / ref.norm()).item() < 6e-6
+    # bit-reproducible (fixed-order partial sums, no atomics)
+    dw2 = torch.empty_like(dw)
+    ops.conv2d_wgrad_bf16x3(xa, da, dw2)
+    assert torch.equal(dw2.cpu().double(), got)
+    # and the fp32 kernel agrees on the same inputs
+    ops.USE_BF16X3[0] = False
+    try:
+        dw3 = torch.empty_like(dw)
+        ops.conv2d_wgrad(xa, da, dw3)
+    finally:
+        ops.USE_BF16X3[0] = True
+    assert ((dw3.cpu().double() - ref).norm() / ref.norm()).item() < 3e-6
+
+
 def test_full_rec_step_with_bf16x3_convs(S):
     """The same 'Rec' step (48 x 80, 3 coils) with the bf16x3 convolution kernels switched on for the layers they
     take: forward outputs and losses at the same bars as the fp32 path; gradients compared NORM-WISE per network
