@@ -140,6 +140,7 @@ struct WBArgs {
     int Q;                     // piece columns = N * nbands * npc
     int P;                     // workgroup partitions of the piece columns (16 columns each)
     int ci_b, ncog, cin_pad, cout_pad;
+    int rowstride;             // elements per framed row of one channel block (npw * 128)
 };
 
 struct XRow {
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(kWT) wgrad_bf16x3_kernel(const WBArgs a) {
     const int n = qc / (a.npc * a.nbands);
     const int r0 = band * a.L;                          // first image row; framed row index = image row + 1
 
-    const int rowstride = a.npw * 128;                  // elements per framed row of one channel block
+    const int rowstride = a.rowstride;
     int xcur = (((n * a.ci_b + cib) * a.Hp + r0) * a.npw + xp + 1) * 128 + c * 8;      // framed row r0 = image row r0 - 1
     int dybase[NB];
 #pragma unroll
@@ -343,14 +344,21 @@ WBPlan wb_plan(int n, int h, int w, int cin, int cout) {
     p.ncog = san_cdiv(p.nco_b, p.NB);
     p.tiles = p.ci_b * p.ncog;
     p.npc = san_cdiv(w, 8);
-    // enough workgroups to fill the chip twice, but at least 6 rows per column (3 rows of window fill per column)
-    const int p_target = san_cdiv(512, p.tiles);
-    int nbands = san_cdiv(p_target * 16, n * p.npc);
-    const int max_bands = h / 6 > 1 ? h / 6 : 1;
-    if (nbands > max_bands) nbands = max_bands;
-    if (nbands < 1) nbands = 1;
-    p.L = 3 * san_cdiv(san_cdiv(h, nbands), 3);
-    p.nbands = san_cdiv(h, p.L);
+    // Row bands: a workgroup (one per CU: 4 waves x ~400 registers) runs L row steps plus about 4 steps' worth of
+    // fixed cost (window fill, LDS reduction, launch), and the grid runs in rounds of 256 workgroups: take the
+    // band count with the smallest rounds x (L + 4).
+    long long best_cost = -1;
+    for (int nbands = 1; nbands <= (h + 2) / 3; ++nbands) {
+        const int L = 3 * san_cdiv(san_cdiv(h, nbands), 3);
+        const int nb2 = san_cdiv(h, L);
+        const int wgs = san_cdiv(n * nb2 * p.npc, 16) * p.tiles;
+        const long long cost = (long long)san_cdiv(wgs, 256) * (L + 4);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            p.L = L;
+            p.nbands = nb2;
+        }
+    }
     p.Hp = p.nbands * p.L + 3;
     p.Wp = 8 * (p.npc + 2);
     p.Q = n * p.nbands * p.npc;
@@ -414,9 +422,12 @@ int san_conv_wgrad_bf16x3_supported(int n, int h, int w, int cin, int cout, int 
 
 int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int ks) {
     if (!san_conv_wgrad_bf16x3_supported(n, h, w, cin, cout, ks)) return 0;
-    if (cin < 32 || cout < 32) return 0;                     // 18- and 24-channel layers: the fp32 kernel is still faster
+    if (cin < 16 || cout < 16) return 0;
+    // a channel count below 32 pads to 32 (half-empty MFMA tiles and split planes): measured a win up to 160^2
+    // (18 -> 36 @160^2: 68 vs 86 us), a tie or worse at 320^2 (18 -> 18: 166 vs 157 us, 32 -> 16: 178 vs 142 us)
+    if ((cin < 32 || cout < 32) && (double)n * h * w > 8.0 * 160 * 160) return 0;
     if (h < 6 || w < 8) return 0;
-    if ((double)n * h * w * cin * cout < 1.0e8) return 0;    // too little work to pay for three launches
+    if ((double)n * h * w * cin * cout < 3.0e7) return 0;    // too little work to pay for three launches
     return 1;
 }
 
@@ -474,6 +485,7 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, con
     a.ncog = p.ncog;
     a.cin_pad = p.cin_pad;
     a.cout_pad = p.cout_pad;
+    a.rowstride = a.npw * 128;
     const int grid = p.P * p.tiles;
     int rc = SAN_OK;
     switch (p.NB) {
