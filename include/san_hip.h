@@ -345,6 +345,7 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
  * device buffer of san_conv_wgrad_bf16x3_scratch_bytes(n,h,w,cin,cout) bytes (split bf16 planes of x
  * and dy + per-workgroup partial tiles); nothing is kept in it after the call returns. */
 int san_conv_wgrad_bf16x3_supported(int n, int h, int w, int cin, int cout, int ks);
+int san_conv_wgrad_bf16x3_set_mode(int mode);   /* -1 automatic, 0 split-plane form, 1 direct form (tests / tuning) */
 int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int ks);
 size_t san_conv_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cout);
 int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin,

@@ -17,15 +17,16 @@ def run(N, cin, cout, h, w, check, time=True):
     xa = ops.Act(x, 0, cin, sc, sh, 0.2); da = ops.full(dy)
     out = {}
     msg = f"n={N} {cin:3d}->{cout:3d} {h:3d}x{w:3d}:"
-    for name, flag in (("bf16x3", True), ("fp32", False)):
+    for name, flag in (("split", True), ("direct", True), ("fp32", False)):
         ops.USE_BF16X3[0] = flag
+        ops.lib().call("san_conv_wgrad_bf16x3_set_mode", {"split": 0, "direct": 1, "fp32": -1}[name])
         dw = torch.full((cout, cin, 3, 3), float('nan'), device=dev)
         fn = ops.conv2d_wgrad_bf16x3 if flag else ops.conv2d_wgrad
         fn(xa, da, dw)
         out[name] = dw.clone()
         if time:
             t = bench(lambda: fn(xa, da, dw))
-            msg += f"  {name} {t:8.1f} us ({2.0 * N * h * w * cin * cout * 9 / t / 1e6:6.1f} TF)"
+            msg += f"  {name} {t:7.1f} us ({2.0 * N * h * w * cin * cout * 9 / t / 1e6:5.1f} TF)"
     ops.USE_BF16X3[0] = True
     if check:
         act = torch.nn.functional.leaky_relu(x * sc[:, :, None, None] + sh[:, :, None, None], 0.2).double()
@@ -36,7 +37,8 @@ def run(N, cin, cout, h, w, check, time=True):
             mx = ((out[name].double() - wt.grad).abs().max() / wt.grad.abs().max()).item()
             msg += f"  {name} rel {err:.2e} max {mx:.2e}"
         # accumulate path
-        dw = out["bf16x3"].clone()
+        ops.lib().call("san_conv_wgrad_bf16x3_set_mode", 1)
+        dw = out["direct"].clone()
         ops.conv2d_wgrad_bf16x3(xa, da, dw, accumulate=True)
         msg += f"  acc {((dw.double() - 2 * wt.grad).norm() / wt.grad.norm()).item():.1e}"
     print(msg, flush=True)
@@ -44,6 +46,6 @@ if '--check' in sys.argv:
     for N, cin, cout, h, w in [(2, 32, 32, 16, 32), (1, 72, 72, 20, 44), (2, 36, 72, 40, 40), (1, 96, 32, 33, 52), (2, 144, 144, 24, 24),
                                (1, 288, 144, 16, 16), (3, 40, 50, 7, 12), (1, 32, 48, 23, 23), (2, 64, 64, 30, 46)]:
         run(N, cin, cout, h, w, True, time=False)
-for cin, cout, s in [(18, 18, 320), (36, 18, 320), (18, 36, 160), (32, 16, 320), (24, 24, 160), (36, 36, 160), (72, 36, 160), (36, 72, 80), (72, 72, 80), (144, 72, 80), (72, 144, 40), (144, 144, 40), (288, 144, 40),
+for cin, cout, s in [(3, 18, 320), (4, 18, 320), (8, 8, 320), (8, 16, 160), (16, 16, 160), (16, 32, 80), (16, 8, 320), (18, 18, 320), (36, 18, 320), (18, 36, 160), (32, 16, 320), (24, 24, 160), (36, 36, 160), (72, 36, 160), (36, 72, 80), (72, 72, 80), (144, 72, 80), (72, 144, 40), (144, 144, 40), (288, 144, 40),
                      (144, 288, 20), (288, 288, 20), (32, 32, 320), (96, 32, 320), (64, 64, 160), (128, 64, 160), (64, 64, 80), (64, 64, 40)]:
     run(8, cin, cout, s, s, False)

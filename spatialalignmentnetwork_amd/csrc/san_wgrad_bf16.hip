@@ -292,6 +292,207 @@ __global__ void __launch_bounds__(kWT) wgrad_bf16x3_kernel(const WBArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// pass 2, direct form: the same tiling, but the wave reads the fp32 tensors themselves (no pass 1, no split planes)
+// and splits its operand pieces in registers: ~52 VALU per dy piece and ~120 per x row (lazy affine, LeakyReLU,
+// zero frame by predication, three-way split, the two shifted copies) against 54 NB MFMAs per row step.  That
+// costs the matrix pipe 25-50 % more issue time per step than pass 2 proper but saves the HBM round trip of the
+// split planes (10 bytes per element written and read back), which is the larger cost wherever the channel
+// counts are low or the images large.  Needs 16-byte aligned rows (W % 4 == 0).
+struct WDArgs {
+    const float* x;
+    const float* in_scale;
+    const float* in_shift;
+    float in_slope;
+    const float* dy;
+    float* partial;            // [P][9][cin_pad][cout_pad]
+    int x_ctot, x_coff, cin, dy_ctot, dy_coff, cout;
+    int H, W, npc, nbands, L;
+    int Q, P, ci_b, ncog, cin_pad, cout_pad;
+};
+
+template <int NB>
+__global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+    int lin;
+    {
+        const int total = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        lin = xcd * (total >> 3) + min(xcd, total & 7) + slot;
+    }
+    const int tiles = a.ci_b * a.ncog;
+    const int tile = lin % tiles, pp = lin / tiles;
+    const int cib = tile % a.ci_b, cog = tile / a.ci_b;
+
+    const int q = (pp * kWaves + wave) * 4 + g;
+    const bool valid = q < a.Q;
+    const int qc = min(q, a.Q - 1);
+    const int xp = qc % a.npc;
+    const int band = (qc / a.npc) % a.nbands;
+    const int n = qc / (a.npc * a.nbands);
+    const int r0 = band * a.L;
+    const int rend = valid ? min(r0 + a.L, a.H) : 0;   // dy rows [r0, rend) are this column's
+    const int H = a.H, W = a.W;
+    const int x0 = 8 * xp;
+    const bool hi_ok = x0 + 4 < W, left_ok = x0 > 0, right_ok = x0 + 8 < W;
+    const int d_hi = hi_ok ? 4 : 0, d_l = left_ok ? -1 : 0, d_r = right_ok ? 8 : 0;    // masked reads stay inside the row
+
+    const int ci = min(cib * 16 + c, a.cin - 1);        // lanes past the last channel redo it; their tile rows are never read
+    const int xbase = ((n * a.x_ctot + a.x_coff + ci) * H) * W + x0;
+    float sc = 1.f, sh = 0.f;
+    if (a.in_scale) {
+        sc = a.in_scale[n * a.x_ctot + a.x_coff + ci];
+        sh = a.in_shift[n * a.x_ctot + a.x_coff + ci];
+    }
+    const float slope = a.in_slope;
+    int dybase[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int co = min((cog * NB + nb) * 16 + c, a.cout - 1);
+        dybase[nb] = ((n * a.dy_ctot + a.dy_coff + co) * H) * W + x0;
+    }
+
+    // ---- x rows: raw fetch (aligned halves + the pixel on each side), then activation, frame, split, shifts
+    f4 xlo, xhi;
+    float xl, xr_;
+    int xrow = r0 - 1;                                  // image row of the raw registers
+    auto load_x = [&]() {
+        const float* p = a.x + xbase + min(max(xrow, 0), H - 1) * W;
+        xlo = *reinterpret_cast<const f4*>(p);
+        xhi = *reinterpret_cast<const f4*>(p + d_hi);
+        xl = p[d_l];
+        xr_ = p[d_r];
+    };
+    auto make_row = [&](XRow& r) {
+        const bool ok = (unsigned)xrow < (unsigned)H;
+        const bool okh = ok && hi_ok;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = ok ? san_act(xlo[i], sc, sh, slope) : 0.f;
+            v[4 + i] = okh ? san_act(xhi[i], sc, sh, slope) : 0.f;
+        }
+        const float vl = (ok && left_ok) ? san_act(xl, sc, sh, slope) : 0.f;
+        const float vr = (ok && right_ok) ? san_act(xr_, sc, sh, slope) : 0.f;
+        uint32_t d[3][4], dm[3], dp[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], d[0][i], d[1][i], d[2][i]);
+        split3_pair(0.f, vl, dm[0], dm[1], dm[2]);       // high half = the pixel to the left
+        split3_pair(vr, 0.f, dp[0], dp[1], dp[2]);       // low half = the pixel to the right
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const uint32_t s01 = __builtin_amdgcn_alignbit(d[p][1], d[p][0], 16), s12 = __builtin_amdgcn_alignbit(d[p][2], d[p][1], 16),
+                           s23 = __builtin_amdgcn_alignbit(d[p][3], d[p][2], 16);
+            r.f[p][1].u = u32x4{d[p][0], d[p][1], d[p][2], d[p][3]};
+            r.f[p][0].u = u32x4{__builtin_amdgcn_alignbit(d[p][0], dm[p], 16), s01, s12, s23};
+            r.f[p][2].u = u32x4{s01, s12, s23, __builtin_amdgcn_alignbit(dp[p], d[p][3], 16)};
+        }
+        ++xrow;
+    };
+
+    // ---- dy rows
+    f4 dlo[NB], dhi[NB];
+    int dyrow = r0;                                     // image row of the raw registers
+    auto load_dy = [&]() {
+        const int ro = min(dyrow, H - 1) * W;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float* p = a.dy + dybase[nb] + ro;
+            dlo[nb] = *reinterpret_cast<const f4*>(p);
+            dhi[nb] = *reinterpret_cast<const f4*>(p + d_hi);
+        }
+    };
+    Frag dyf[NB][3];
+    auto make_dy = [&]() {
+        const bool ok = dyrow < rend;
+        const bool okh = ok && hi_ok;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            uint32_t d[3][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                split3_pair(ok ? dlo[nb][2 * i] : 0.f, ok ? dlo[nb][2 * i + 1] : 0.f, d[0][i], d[1][i], d[2][i]);
+                split3_pair(okh ? dhi[nb][2 * i] : 0.f, okh ? dhi[nb][2 * i + 1] : 0.f, d[0][2 + i], d[1][2 + i], d[2][2 + i]);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dyf[nb][p].u = u32x4{d[p][0], d[p][1], d[p][2], d[p][3]};
+        }
+        ++dyrow;
+    };
+
+    f4 acc[9][NB];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[t][nb] = f4{0.f, 0.f, 0.f, 0.f};
+
+    XRow ra, rb, rc;
+    load_x();
+    make_row(ra);
+    load_x();
+    make_row(rb);
+    load_x();
+    make_row(rc);
+    load_dy();
+    load_x();                                           // row r0 + 2, converted at the end of the first step
+    __builtin_amdgcn_sched_barrier(0);
+
+    auto step = [&](XRow& w0, XRow& w1, XRow& w2) {
+        make_dy();                                      // the dy row fetched during the previous step
+        __builtin_amdgcn_sched_barrier(0);
+        load_dy();                                      // next dy row: a whole step ahead of its use
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+                for (int pb = 0; pb < 3 - pa; ++pb)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        acc[kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.f[pa][kx].v, dyf[nb][pb].v, acc[kx][nb], 0, 0, 0);
+                        acc[3 + kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.f[pa][kx].v, dyf[nb][pb].v, acc[3 + kx][nb], 0, 0, 0);
+                        acc[6 + kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2.f[pa][kx].v, dyf[nb][pb].v, acc[6 + kx][nb], 0, 0, 0);
+                    }
+        __builtin_amdgcn_sched_barrier(0);
+        make_row(w0);                                   // the x row fetched during the previous step replaces the oldest
+        load_x();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int t = 0; t < a.L; t += 3) {
+        step(ra, rb, rc);
+        step(rb, rc, ra);
+        step(rc, ra, rb);
+    }
+
+    f4* red = reinterpret_cast<f4*>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) red[((wave - 1) * 9 * NB + t * NB + nb) * 64 + lane] = acc[t][nb];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.partial + (size_t)pp * 9 * a.cin_pad * a.cout_pad;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f4 s = acc[t][nb];
+#pragma unroll
+                for (int w = 0; w < kWaves - 1; ++w) s += red[(w * 9 * NB + t * NB + nb) * 64 + lane];
+                float* o = out + ((size_t)t * a.cin_pad + cib * 16 + 4 * g) * a.cout_pad + (cog * NB + nb) * 16 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[(size_t)r * a.cout_pad] = s[r];
+            }
+    }
+}
+
 // pass 3: dw[co][ci][tap] (+)= sum_pp partial[pp][tap][ci][co], fixed order
 __global__ void __launch_bounds__(256) wgrad_bf16x3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                    int P, int cin, int cout, int cin_pad, int cout_pad,
@@ -332,7 +533,7 @@ WBPlan wb_plan(int n, int h, int w, int cin, int cout) {
     // output-channel blocks per wave: the split of nco_b into groups that wastes the fewest blocks, ties to the larger
     int best = 0;
     double best_eff = 0.0;
-    for (int nb = 4; nb >= 2; --nb) {                     // (NB = 5 does not fit the register file without spilling)
+    for (int nb = 4; nb >= 1; --nb) {                     // (NB = 5 does not fit the register file without spilling)
         const int gcount = san_cdiv(p.nco_b, nb);
         const double eff = (double)p.nco_b / (gcount * nb);
         if (eff > best_eff + 1e-9) {
@@ -389,6 +590,22 @@ int launch_wb(const WBArgs& a, int grid, hipStream_t s) {
     return SAN_OK;
 }
 
+template <int NB>
+int launch_wd(const WDArgs& a, int grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)(kWaves - 1) * 9 * NB * 64 * sizeof(f4);
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_direct_kernel<NB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            san_set_error("cannot reserve %d bytes of LDS for the bf16x3 weight gradient", (int)lds);
+            return SAN_E_UNSUPPORTED;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((wgrad_bf16x3_direct_kernel<NB>), dim3(grid), dim3(kWT), lds, s, a);
+    return SAN_OK;
+}
+
 SplitOne split_one(const float* src, int ctot, int coff, int C, int CB, const float* scale, const float* shift, float slope,
                    int n, int w, const WBPlan& p, uint16_t* out, long long plane) {
     SplitOne o{};
@@ -407,9 +624,25 @@ SplitOne split_one(const float* src, int ctot, int coff, int C, int CB, const fl
     return o;
 }
 
+// the direct form (no split planes) needs 16-byte aligned rows and 32-bit element offsets into the fp32 tensors
+int g_wb_mode = -1;            // -1 automatic, 0 split planes, 1 direct (tests / tuning: san_conv_wgrad_bf16x3_set_mode)
+bool wb_direct(const float* x, const float* dy, int n, int h, int w, int x_ctot, int dy_ctot) {
+    const bool can = (w % 4) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0 &&
+                     (double)n * (x_ctot > dy_ctot ? x_ctot : dy_ctot) * h * w < (double)(1ll << 30);
+    if (!can) return false;
+    if (g_wb_mode >= 0) return g_wb_mode == 1;
+    return true;
+}
+
 }  // namespace
 
 extern "C" {
+
+// tuning / test hook: -1 automatic choice between the two forms of pass 2, 0 split planes, 1 direct
+int san_conv_wgrad_bf16x3_set_mode(int mode) {
+    g_wb_mode = mode;
+    return SAN_OK;
+}
 
 // 1 when the bf16x3 weight gradient is the faster choice for this layer (what the dispatcher asks); the kernel
 // itself runs any 3x3 layer whose split planes stay below 2^30 elements (san_conv_wgrad_bf16x3_supported).
@@ -422,12 +655,13 @@ int san_conv_wgrad_bf16x3_supported(int n, int h, int w, int cin, int cout, int 
 
 int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int ks) {
     if (!san_conv_wgrad_bf16x3_supported(n, h, w, cin, cout, ks)) return 0;
-    if (cin < 16 || cout < 16) return 0;
-    // a channel count below 32 pads to 32 (half-empty MFMA tiles and split planes): measured a win up to 160^2
-    // (18 -> 36 @160^2: 68 vs 86 us), a tie or worse at 320^2 (18 -> 18: 166 vs 157 us, 32 -> 16: 178 vs 142 us)
-    if ((cin < 32 || cout < 32) && (double)n * h * w > 8.0 * 160 * 160) return 0;
     if (h < 6 || w < 8) return 0;
-    if ((double)n * h * w * cin * cout < 3.0e7) return 0;    // too little work to pay for three launches
+    const double work = (double)n * h * w * (cin > 16 ? cin : 16) * (cout > 16 ? cout : 16);
+    if (work < 2.0e7) return 0;                               // too little work to pay for the extra launch
+    if ((w % 4) == 0) return 1;   // direct form: measured faster than the fp32 kernel from 3 -> 18 @320^2 (71 vs 88 us) upwards
+    // split-plane form (rows not 16-byte aligned): the planes' HBM round trip needs full tiles to pay off
+    if (cin < 16 || cout < 16) return 0;
+    if ((cin < 32 || cout < 32) && (double)n * h * w > 8.0 * 160 * 160) return 0;
     return 1;
 }
 
@@ -454,44 +688,78 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, con
     uint16_t* dys = reinterpret_cast<uint16_t*>(base + p.x_bytes);
     float* partial = reinterpret_cast<float*>(base + p.x_bytes + p.dy_bytes);
 
-    SplitArgs sa{};
-    sa.t[0] = split_one(x, x_ctot, x_coff, cin, p.ci_b, in_scale, in_shift, in_slope, n, w, p, xs, p.xplane);
-    sa.t[1] = split_one(dy, dy_ctot, dy_coff, cout, p.cout_pad / 16, nullptr, nullptr, 1.f, n, w, p, dys, p.dyplane);
-    sa.blocks0 = (unsigned)((sa.t[0].total + 255) / 256);
-    sa.H = h;
-    sa.W = w;
-    sa.Hp = p.Hp;
-    sa.npw = p.Wp / 8;
-    hipLaunchKernelGGL(split_planes_kernel, dim3(sa.blocks0 + (unsigned)((sa.t[1].total + 255) / 256)), dim3(256), 0, s, sa);
-    SAN_LAUNCH_CHECK();
-
-    WBArgs a{};
-    a.xs = xs;
-    a.dys = dys;
-    a.xplane = p.xplane;
-    a.dyplane = p.dyplane;
-    a.partial = partial;
-    a.N = n;
-    a.cin = cin;
-    a.cout = cout;
-    a.Hp = p.Hp;
-    a.npw = p.Wp / 8;
-    a.npc = p.npc;
-    a.nbands = p.nbands;
-    a.L = p.L;
-    a.Q = p.Q;
-    a.P = p.P;
-    a.ci_b = p.ci_b;
-    a.ncog = p.ncog;
-    a.cin_pad = p.cin_pad;
-    a.cout_pad = p.cout_pad;
-    a.rowstride = a.npw * 128;
     const int grid = p.P * p.tiles;
     int rc = SAN_OK;
-    switch (p.NB) {
-        case 2: rc = launch_wb<2>(a, grid, s); break;
-        case 3: rc = launch_wb<3>(a, grid, s); break;
-        default: rc = launch_wb<4>(a, grid, s); break;
+    if (wb_direct(x, dy, n, h, w, x_ctot, dy_ctot)) {
+        WDArgs d{};
+        d.x = x;
+        d.in_scale = in_scale;
+        d.in_shift = in_shift;
+        d.in_slope = in_slope;
+        d.dy = dy;
+        d.partial = partial;
+        d.x_ctot = x_ctot;
+        d.x_coff = x_coff;
+        d.cin = cin;
+        d.dy_ctot = dy_ctot;
+        d.dy_coff = dy_coff;
+        d.cout = cout;
+        d.H = h;
+        d.W = w;
+        d.npc = p.npc;
+        d.nbands = p.nbands;
+        d.L = p.L;
+        d.Q = p.Q;
+        d.P = p.P;
+        d.ci_b = p.ci_b;
+        d.ncog = p.ncog;
+        d.cin_pad = p.cin_pad;
+        d.cout_pad = p.cout_pad;
+        switch (p.NB) {
+            case 1: rc = launch_wd<1>(d, grid, s); break;
+            case 2: rc = launch_wd<2>(d, grid, s); break;
+            case 3: rc = launch_wd<3>(d, grid, s); break;
+            default: rc = launch_wd<4>(d, grid, s); break;
+        }
+    } else {
+        SplitArgs sa{};
+        sa.t[0] = split_one(x, x_ctot, x_coff, cin, p.ci_b, in_scale, in_shift, in_slope, n, w, p, xs, p.xplane);
+        sa.t[1] = split_one(dy, dy_ctot, dy_coff, cout, p.cout_pad / 16, nullptr, nullptr, 1.f, n, w, p, dys, p.dyplane);
+        sa.blocks0 = (unsigned)((sa.t[0].total + 255) / 256);
+        sa.H = h;
+        sa.W = w;
+        sa.Hp = p.Hp;
+        sa.npw = p.Wp / 8;
+        hipLaunchKernelGGL(split_planes_kernel, dim3(sa.blocks0 + (unsigned)((sa.t[1].total + 255) / 256)), dim3(256), 0, s, sa);
+        SAN_LAUNCH_CHECK();
+
+        WBArgs a{};
+        a.xs = xs;
+        a.dys = dys;
+        a.xplane = p.xplane;
+        a.dyplane = p.dyplane;
+        a.partial = partial;
+        a.N = n;
+        a.cin = cin;
+        a.cout = cout;
+        a.Hp = p.Hp;
+        a.npw = p.Wp / 8;
+        a.npc = p.npc;
+        a.nbands = p.nbands;
+        a.L = p.L;
+        a.Q = p.Q;
+        a.P = p.P;
+        a.ci_b = p.ci_b;
+        a.ncog = p.ncog;
+        a.cin_pad = p.cin_pad;
+        a.cout_pad = p.cout_pad;
+        a.rowstride = a.npw * 128;
+        switch (p.NB) {
+            case 1: rc = launch_wb<1>(a, grid, s); break;
+            case 2: rc = launch_wb<2>(a, grid, s); break;
+            case 3: rc = launch_wb<3>(a, grid, s); break;
+            default: rc = launch_wb<4>(a, grid, s); break;
+        }
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();

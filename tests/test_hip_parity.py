@@ -692,13 +692,18 @@ def test_conv_bf16x3_vs_float64(S, n, cin, cout, h, w):
     assert rel_err(dx.cpu(), a64.grad.float()) < 3e-6
 
 
+@pytest.mark.parametrize("mode", [1, 0], ids=["direct", "split"])
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 72, 72, 20, 44), (2, 36, 72, 40, 40), (1, 96, 32, 33, 52), (2, 144, 144, 24, 24),
-                                            (4, 288, 144, 16, 16), (8, 40, 50, 14, 12), (2, 32, 48, 31, 31), (2, 64, 64, 30, 46)])
-def test_wgrad_bf16x3_vs_float64(S, n, cin, cout, h, w):
+                                            (4, 288, 144, 16, 16), (8, 40, 50, 14, 12), (2, 32, 48, 31, 31), (2, 64, 64, 30, 46),
+                                            (2, 3, 18, 32, 40), (3, 18, 2, 17, 36), (1, 8, 8, 64, 64)])
+def test_wgrad_bf16x3_vs_float64(S, n, cin, cout, h, w, mode):
     """The bf16 matrix-core weight gradient with three-way split operands (csrc/san_wgrad_bf16.hip) against float64:
     lazily activated input read through a channel view, dy through a channel view, widths that are not a multiple
-    of 8 or 4, ragged row bands, overwrite and accumulate.  Bar: 3e-6 relative L2 and 3e-6 of the largest entry."""
+    of 8 or 4, ragged row bands, overwrite and accumulate, in both forms of the kernel (direct: operands split in
+    registers; split: bf16 planes written first -- the form taken when W % 4 != 0 whatever the mode).
+    Bar: 3e-6 relative L2 and 3e-6 of the largest entry."""
     ops = S.ops
+    ops.lib().call("san_conv_wgrad_bf16x3_set_mode", mode)
     x = philox("wb.x", (n, cin + 3, h, w))
     dy = philox("wb.dy", (n, cout + 2, h, w))
     sc, sh = philox("wb.sc", (n, cin + 3), lo=0.5, hi=1.5), philox("wb.sh", (n, cin + 3))
@@ -708,6 +713,13 @@ def test_wgrad_bf16x3_vs_float64(S, n, cin, cout, h, w):
     ref = wt.grad
     dw = torch.full((cout, cin, 3, 3), float("nan"), device=DEV)
     xa, da = ops.Act(g(x), 3, cin, g(sc), g(sh), 0.2), ops.Act(g(dy), 2, cout, None, None, 1.0)
+    try:
+        _wgrad_bf16x3_checks(ops, xa, da, dw, ref)
+    finally:
+        ops.lib().call("san_conv_wgrad_bf16x3_set_mode", -1)
+
+
+def _wgrad_bf16x3_checks(ops, xa, da, dw, ref):
     ops.conv2d_wgrad_bf16x3(xa, da, dw)
     got = dw.cpu().double()
     assert ((got - ref).norm() / ref.norm()).item() < 3e-6
