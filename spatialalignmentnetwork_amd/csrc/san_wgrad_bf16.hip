@@ -526,14 +526,15 @@ struct WBPlan {
 
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-WBPlan wb_plan(int n, int h, int w, int cin, int cout) {
+// max_nb: 4 for the split-plane form (NB = 5 spills there), 5 for the direct form
+WBPlan wb_plan(int n, int h, int w, int cin, int cout, int max_nb = 4) {
     WBPlan p{};
     p.ci_b = san_cdiv(cin, 16);
     p.nco_b = san_cdiv(cout, 16);
     // output-channel blocks per wave: the split of nco_b into groups that wastes the fewest blocks, ties to the larger
     int best = 0;
     double best_eff = 0.0;
-    for (int nb = 4; nb >= 1; --nb) {                     // (NB = 5 does not fit the register file without spilling)
+    for (int nb = max_nb; nb >= 1; --nb) {
         const int gcount = san_cdiv(p.nco_b, nb);
         const double eff = (double)p.nco_b / (gcount * nb);
         if (eff > best_eff + 1e-9) {
@@ -668,8 +669,9 @@ int san_conv_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout, int k
 // bytes of scratch san_conv2d_wgrad_bf16x3 needs (split planes of x and dy + the partial tiles)
 size_t san_conv_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cout) {
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
-    const WBPlan p = wb_plan(n, h, w, cin, cout);
-    return p.x_bytes + p.dy_bytes + p.partial_bytes;
+    const WBPlan p = wb_plan(n, h, w, cin, cout), d = wb_plan(n, h, w, cin, cout, 5);
+    const size_t split = p.x_bytes + p.dy_bytes + p.partial_bytes;       // either form may be taken (pointer alignment)
+    return split > d.partial_bytes ? split : d.partial_bytes;
 }
 
 int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
@@ -681,16 +683,17 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, con
     SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
     SAN_CHECK_ARG(san_conv_wgrad_bf16x3_supported(n, h, w, cin, cout, 3), "layer too large for 32-bit plane offsets (see san_conv_wgrad_bf16x3_supported)");
     SAN_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
-    const WBPlan p = wb_plan(n, h, w, cin, cout);
+    const bool direct = wb_direct(x, dy, n, h, w, x_ctot, dy_ctot);
+    const WBPlan p = wb_plan(n, h, w, cin, cout, direct ? 5 : 4);
     hipStream_t s = (hipStream_t)stream;
     unsigned char* base = static_cast<unsigned char*>(scratch);
     uint16_t* xs = reinterpret_cast<uint16_t*>(base);
     uint16_t* dys = reinterpret_cast<uint16_t*>(base + p.x_bytes);
-    float* partial = reinterpret_cast<float*>(base + p.x_bytes + p.dy_bytes);
+    float* partial = direct ? reinterpret_cast<float*>(base) : reinterpret_cast<float*>(base + p.x_bytes + p.dy_bytes);
 
     const int grid = p.P * p.tiles;
     int rc = SAN_OK;
-    if (wb_direct(x, dy, n, h, w, x_ctot, dy_ctot)) {
+    if (direct) {
         WDArgs d{};
         d.x = x;
         d.in_scale = in_scale;
@@ -719,7 +722,8 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, con
             case 1: rc = launch_wd<1>(d, grid, s); break;
             case 2: rc = launch_wd<2>(d, grid, s); break;
             case 3: rc = launch_wd<3>(d, grid, s); break;
-            default: rc = launch_wd<4>(d, grid, s); break;
+            case 4: rc = launch_wd<4>(d, grid, s); break;
+            default: rc = launch_wd<5>(d, grid, s); break;
         }
     } else {
         SplitArgs sa{};
