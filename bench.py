@@ -223,7 +223,7 @@ def main():
         out = {
             "metric": "slices/sec (320x320, 12-cascade VarNet+align)", "value": total_slices / dt, "unit": "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (U-Net levels 2-4 and alignment convs: bf16x3 split, fp32-equivalent)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3x3 weight gradients and the convolutions of U-Net levels 2-4 / alignment net: bf16x3 split, fp32-equivalent)", "data": "synthetic",
             "config": {"workload": ("train step (regime Rec: fwd + hand-written bwd + grad all-reduce + AdamW) " if args.mode == "train" else "inference pass ") + f"set_input+align+warp+VarNet{args.cascades}+SSIM, "
                                    f"{n} slices/GPU of {h}x{w} single-coil, 4x equispaced mask, random-init weights",
                        "slices_per_gpu": n, "global_batch": n * world, "cascades": args.cascades,
@@ -245,13 +245,14 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
             for key, field in ((dom, "roofline"), ("fft_dc", "roofline_fft_dc"), ("conv3x3", "roofline_conv_fp32"),
-                               ("conv3x3_bf16x3", "roofline_conv_bf16x3"), ("wgrad3x3", "roofline_wgrad")):
+                               ("conv3x3_bf16x3", "roofline_conv_bf16x3"), ("wgrad3x3_bf16x3", "roofline_wgrad_bf16x3"),
+                               ("wgrad3x3", "roofline_wgrad_fp32")):
                 if key not in tot or (field != "roofline" and key == dom):
                     continue
                 d = tot[key]
                 sec = d["ms"] * 1e-3
                 extra = {}
-                if key == "conv3x3_bf16x3":
+                if key in ("conv3x3_bf16x3", "wgrad3x3_bf16x3"):
                     # algorithmic (fp32) FLOPs are what the layer needs; the kernel issues six bf16 products per MAC,
                     # so against the bf16 roof the matrix pipe sees 6x that
                     ach, peak, unit, bound = 6.0 * d["work"] / sec / 1e12, BF16_PEAK_TFLOPS, "TFLOP/s", "mfma"

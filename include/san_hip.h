@@ -354,6 +354,17 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin,
                             float* dw, int accumulate, void* scratch,
                             int n, int h, int w, void* stream);
 
+/* 1x1 weight gradient on the bf16 matrix cores (same file): san_conv2d_wgrad's contract for ks = 1 -- the
+ * 2x2 transposed convolutions (varnet.py:159-192, run as 1x1 convolutions to 4 cout + pixel shuffle) and the
+ * alignment net's 1x1 layers (unet.py:119-140).  Needs h*w % 4 == 0 and 16-byte aligned x / dy. */
+int san_conv1x1_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout);
+size_t san_conv1x1_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cout);
+int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin,
+                             const float* in_scale, const float* in_shift, float in_slope,
+                             const float* dy, int dy_ctot, int dy_coff, int cout,
+                             float* dw, int accumulate, void* scratch,
+                             int n, int h, int w, void* stream);
+
 /* Batched weight packing for training, where every weight changes every step: san_conv_pack_job
  * fills one HOST table entry (8 x int64) for a weight/packed-buffer pair -- mode 0: Conv2d forward
  * (san_conv_pack_weights_fwd), 1: ConvTranspose2d 2x2 (san_conv_pack_weights transposed), 2: Conv2d

@@ -493,16 +493,149 @@ __global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 1x1 weight gradient (the 2x2 transposed convolutions run as 1x1 convolutions to 4 cout + pixel shuffle, and the
+// alignment net's 1x1 layers): no spatial coupling, so a channel plane is one flat run of H*W pixels.  A wave owns
+// one block of 16 input channels x NB blocks of 16 output channels and a span of 32 L consecutive pixels; per step
+// its four lane groups take four neighbouring 8-pixel pieces (128 contiguous bytes per channel), split them in
+// registers and issue 6 NB MFMAs.  VALU-bound (~52 operations per piece against 6 MFMAs), which is still several
+// times faster than the fp32 kernel on these short-K, wide-channel shapes.  Needs H*W % 4 == 0 and 16-byte bases.
+struct W1Args {
+    const float* x;
+    const float* in_scale;
+    const float* in_shift;
+    float in_slope;
+    const float* dy;
+    float* partial;            // [P][1][cin_pad][cout_pad]
+    int x_ctot, x_coff, cin, dy_ctot, dy_coff, cout;
+    int HW, L, S;              // pixels per plane, steps per span, spans per image
+    int Q, P, ci_b, ncog, cin_pad, cout_pad;
+};
+
+template <int NB>
+__global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+    int lin;
+    {
+        const int total = gridDim.x, id = blockIdx.x;
+        const int xcd = id & 7, slot = id >> 3;
+        lin = xcd * (total >> 3) + min(xcd, total & 7) + slot;
+    }
+    const int tiles = a.ci_b * a.ncog;
+    const int tile = lin % tiles, pp = lin / tiles;
+    const int cib = tile % a.ci_b, cog = tile / a.ci_b;
+
+    const int q = pp * kWaves + wave;                   // this wave's span
+    const bool valid = q < a.Q;
+    const int qc = min(q, a.Q - 1);
+    const int n = qc / a.S, sp = qc - n * a.S;
+    const int HW = a.HW;
+    const int pend = valid ? min((sp + 1) * 32 * a.L, HW) : 0;       // pixels [sp * 32 L, pend) are this wave's
+    int px = sp * 32 * a.L + 8 * g;                     // this lane group's piece of the current step
+
+    const int ci = min(cib * 16 + c, a.cin - 1);
+    const int xbase = (n * a.x_ctot + a.x_coff + ci) * HW;
+    float sc = 1.f, sh = 0.f;
+    if (a.in_scale) {
+        sc = a.in_scale[n * a.x_ctot + a.x_coff + ci];
+        sh = a.in_shift[n * a.x_ctot + a.x_coff + ci];
+    }
+    const float slope = a.in_slope;
+    int dybase[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) dybase[nb] = (n * a.dy_ctot + a.dy_coff + min((cog * NB + nb) * 16 + c, a.cout - 1)) * HW;
+
+    f4 xlo, xhi, dlo[NB], dhi[NB];
+    int pxl = px;                                       // pixel of the raw registers
+    auto load = [&]() {
+        const int p0 = min(pxl, HW - 4), p1 = min(pxl + 4, HW - 4);      // masked reads stay inside the plane
+        xlo = *reinterpret_cast<const f4*>(a.x + xbase + p0);
+        xhi = *reinterpret_cast<const f4*>(a.x + xbase + p1);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            dlo[nb] = *reinterpret_cast<const f4*>(a.dy + dybase[nb] + p0);
+            dhi[nb] = *reinterpret_cast<const f4*>(a.dy + dybase[nb] + p1);
+        }
+    };
+    Frag xf[3], dyf[NB][3];
+    auto convert = [&]() {
+        const bool ok = pxl < pend, okh = pxl + 4 < pend;
+        uint32_t d[3][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            split3_pair(ok ? san_act(xlo[2 * i], sc, sh, slope) : 0.f, ok ? san_act(xlo[2 * i + 1], sc, sh, slope) : 0.f, d[0][i], d[1][i],
+                        d[2][i]);
+            split3_pair(okh ? san_act(xhi[2 * i], sc, sh, slope) : 0.f, okh ? san_act(xhi[2 * i + 1], sc, sh, slope) : 0.f, d[0][2 + i],
+                        d[1][2 + i], d[2][2 + i]);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) xf[p].u = u32x4{d[p][0], d[p][1], d[p][2], d[p][3]};
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                split3_pair(ok ? dlo[nb][2 * i] : 0.f, ok ? dlo[nb][2 * i + 1] : 0.f, d[0][i], d[1][i], d[2][i]);
+                split3_pair(okh ? dhi[nb][2 * i] : 0.f, okh ? dhi[nb][2 * i + 1] : 0.f, d[0][2 + i], d[1][2 + i], d[2][2 + i]);
+            }
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dyf[nb][p].u = u32x4{d[p][0], d[p][1], d[p][2], d[p][3]};
+        }
+        pxl += 32;
+    };
+
+    f4 acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = f4{0.f, 0.f, 0.f, 0.f};
+    load();
+    for (int t = 0; t < a.L; ++t) {
+        convert();                                      // the pieces fetched during the previous step
+        __builtin_amdgcn_sched_barrier(0);
+        load();                                         // next step's pieces (clamped past the end; masked when converted)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pa = 0; pa < 3; ++pa)
+#pragma unroll
+            for (int pb = 0; pb < 3 - pa; ++pb)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[pa].v, dyf[nb][pb].v, acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    f4* red = reinterpret_cast<f4*>(smem);
+    if (wave > 0) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) red[((wave - 1) * NB + nb) * 64 + lane] = acc[nb];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* out = a.partial + (size_t)pp * a.cin_pad * a.cout_pad;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            f4 s = acc[nb];
+#pragma unroll
+            for (int w = 0; w < kWaves - 1; ++w) s += red[(w * NB + nb) * 64 + lane];
+            float* o = out + ((size_t)cib * 16 + 4 * g) * a.cout_pad + (cog * NB + nb) * 16 + c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[(size_t)r * a.cout_pad] = s[r];
+        }
+    }
+}
+
 // pass 3: dw[co][ci][tap] (+)= sum_pp partial[pp][tap][ci][co], fixed order
 __global__ void __launch_bounds__(256) wgrad_bf16x3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                    int P, int cin, int cout, int cin_pad, int cout_pad,
-                                                                   int accumulate) {
+                                                                   int accumulate, int taps) {
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= cout * cin * 9) return;
+    if (e >= cout * cin * taps) return;
     const int co = e % cout;
     const int ci = (e / cout) % cin;
     const int tap = e / (cout * cin);
-    const size_t stride = (size_t)9 * cin_pad * cout_pad;
+    const size_t stride = (size_t)taps * cin_pad * cout_pad;
     const float* p = partial + ((size_t)tap * cin_pad + ci) * cout_pad + co;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int pp = 0;
@@ -514,7 +647,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16x3_reduce_kernel(const float* _
     }
     for (; pp < P; ++pp) s0 += p[(size_t)pp * stride];
     const float s = (s0 + s1) + (s2 + s3);
-    float* o = dw + ((size_t)co * cin + ci) * 9 + tap;
+    float* o = dw + ((size_t)co * cin + ci) * taps + tap;
     *o = accumulate ? *o + s : s;
 }
 
@@ -623,6 +756,54 @@ SplitOne split_one(const float* src, int ctot, int coff, int C, int CB, const fl
     o.total = (long long)n * CB * p.Hp * (p.Wp / 8) * 16;
     o.vec = ((uintptr_t)src & 15) == 0 && (w % 4) == 0;
     return o;
+}
+
+struct W1Plan {
+    int ci_b, nco_b, NB, ncog, L, S, Q, P, cin_pad, cout_pad;
+    size_t partial_bytes;
+};
+
+W1Plan w1_plan(int n, int hw, int cin, int cout) {
+    W1Plan p{};
+    p.ci_b = san_cdiv(cin, 16);
+    p.nco_b = san_cdiv(cout, 16);
+    int best = 1;
+    double best_eff = 0.0;
+    for (int nb = 5; nb >= 1; --nb) {
+        const double eff = (double)p.nco_b / (san_cdiv(p.nco_b, nb) * nb);
+        if (eff > best_eff + 1e-9) {
+            best_eff = eff;
+            best = nb;
+        }
+    }
+    p.NB = best;
+    p.ncog = san_cdiv(p.nco_b, p.NB);
+    const int tiles = p.ci_b * p.ncog;
+    const int steps = san_cdiv(hw, 32);                 // per image
+    long long best_cost = -1;
+    for (int L = 1; L <= steps; ++L) {
+        const int S = san_cdiv(steps, L);
+        const int wgs = san_cdiv(n * S, kWaves) * tiles;
+        const long long cost = (long long)san_cdiv(wgs, 256) * (L + 6);    // ~6 steps' worth of fixed cost per workgroup
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            p.L = L;
+            p.S = S;
+        }
+    }
+    p.Q = n * p.S;
+    p.P = san_cdiv(p.Q, kWaves);
+    p.cin_pad = p.ci_b * 16;
+    p.cout_pad = p.ncog * p.NB * 16;
+    p.partial_bytes = align256((size_t)p.P * p.cin_pad * p.cout_pad * sizeof(float));
+    return p;
+}
+
+template <int NB>
+int launch_w1(const W1Args& a, int grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)(kWaves - 1) * NB * 64 * sizeof(f4);
+    hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB>), dim3(grid), dim3(kWT), lds, s, a);
+    return SAN_OK;
 }
 
 // the direct form (no split planes) needs 16-byte aligned rows and 32-bit element offsets into the fp32 tensors
@@ -769,7 +950,73 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, con
     SAN_LAUNCH_CHECK();
     const int count = cout * cin * 9;
     hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 256)), dim3(256), 0, s, partial, dw, p.P, cin, cout,
-                       p.cin_pad, p.cout_pad, accumulate);
+                       p.cin_pad, p.cout_pad, accumulate, 9);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+// ---- 1x1 form (see wgrad1x1_bf16x3_kernel) ----
+int san_conv1x1_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    if (((long long)h * w) % 4 != 0) return 0;
+    if ((double)n * (cin > cout ? cin : cout) * h * w >= (double)(1ll << 30)) return 0;      // 32-bit element offsets
+    if ((double)n * h * w * (cin > 16 ? cin : 16) * (cout > 16 ? cout : 16) < 2.0e7) return 0;
+    return 1;
+}
+
+size_t san_conv1x1_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    return w1_plan(n, h * w, cin, cout).partial_bytes;
+}
+
+int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                             float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                             void* scratch, int n, int h, int w, void* stream) {
+    SAN_CHECK_ARG(x && dy && dw && scratch, "null pointer");
+    SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
+    SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && dy_coff >= 0 && dy_coff + cout <= dy_ctot, "bad channel view");
+    SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
+    SAN_CHECK_ARG(((long long)h * w) % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)dy)) & 15) == 0, "needs 16-byte aligned channel planes");
+    SAN_CHECK_ARG((double)n * (x_ctot > dy_ctot ? x_ctot : dy_ctot) * h * w < (double)(1ll << 30), "tensor too large for 32-bit offsets");
+    SAN_CHECK_ARG(((uintptr_t)scratch & 15) == 0, "scratch must be 16-byte aligned");
+    const W1Plan p = w1_plan(n, h * w, cin, cout);
+    hipStream_t s = (hipStream_t)stream;
+    W1Args a{};
+    a.x = x;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_slope = in_slope;
+    a.dy = dy;
+    a.partial = static_cast<float*>(scratch);
+    a.x_ctot = x_ctot;
+    a.x_coff = x_coff;
+    a.cin = cin;
+    a.dy_ctot = dy_ctot;
+    a.dy_coff = dy_coff;
+    a.cout = cout;
+    a.HW = h * w;
+    a.L = p.L;
+    a.S = p.S;
+    a.Q = p.Q;
+    a.P = p.P;
+    a.ci_b = p.ci_b;
+    a.ncog = p.ncog;
+    a.cin_pad = p.cin_pad;
+    a.cout_pad = p.cout_pad;
+    const int grid = p.P * p.ci_b * p.ncog;
+    int rc = SAN_OK;
+    switch (p.NB) {
+        case 1: rc = launch_w1<1>(a, grid, s); break;
+        case 2: rc = launch_w1<2>(a, grid, s); break;
+        case 3: rc = launch_w1<3>(a, grid, s); break;
+        case 4: rc = launch_w1<4>(a, grid, s); break;
+        default: rc = launch_w1<5>(a, grid, s); break;
+    }
+    if (rc != SAN_OK) return rc;
+    SAN_LAUNCH_CHECK();
+    const int count = cout * cin;
+    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 256)), dim3(256), 0, s, a.partial, dw, p.P, cin, cout,
+                       p.cin_pad, p.cout_pad, accumulate, 1);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

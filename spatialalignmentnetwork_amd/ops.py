@@ -658,6 +658,10 @@ def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, ar
     if USE_BF16X3[0] and lib().query("san_conv_wgrad_bf16x3_eligible", x.n, x.h, x.w, cin, cout, ks):
         conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena)
         return
+    if (USE_BF16X3[0] and ks == 1 and lib().query("san_conv1x1_wgrad_bf16x3_eligible", x.n, x.h, x.w, cin, cout)
+            and (x.buf.data_ptr() | dy.buf.data_ptr()) % 16 == 0):
+        conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena)
+        return
     P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout, ks)
     partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff, cout,
@@ -677,6 +681,17 @@ def conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = Fa
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
             cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
     _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args))
+
+
+def conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
+    """The 1x1 weight gradient on the bf16 matrix cores (csrc/san_wgrad_bf16.hip, wgrad1x1_bf16x3_kernel)."""
+    cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
+    assert ks == 1 and x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
+    nbytes = lib().query("san_conv1x1_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
+    scratch = arena.scratch("wgrad_bf16x3", nbytes, x.buf.device)
+    args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
+            cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
+    _timed("wgrad1x1_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin, "FLOP", lambda: lib().call("san_conv1x1_wgrad_bf16x3", *args))
 
 
 def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA) -> None:

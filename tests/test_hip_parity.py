@@ -740,6 +740,31 @@ def _wgrad_bf16x3_checks(ops, xa, da, dw, ref):
     assert ((dw3.cpu().double() - ref).norm() / ref.norm()).item() < 3e-6
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 288, 576, 10, 12), (2, 36, 72, 40, 40), (3, 64, 64, 17, 20), (1, 32, 64, 33, 52),
+                                            (8, 20, 50, 7, 12), (1, 144, 288, 6, 6)])
+def test_wgrad1x1_bf16x3_vs_float64(S, n, cin, cout, h, w):
+    """The 1x1 weight gradient on the bf16 matrix cores (three-way split operands) against float64: channel views,
+    lazily activated input, plane sizes that are not a multiple of the 32-pixel step, ragged channel blocks,
+    overwrite / accumulate, bit-reproducibility.  Bar: 3e-6 relative L2 and of the largest entry."""
+    ops = S.ops
+    x = philox("w1.x", (n, cin + 3, h, w))
+    dy = philox("w1.dy", (n, cout + 2, h, w))
+    sc, sh = philox("w1.sc", (n, cin + 3), lo=0.5, hi=1.5), philox("w1.sh", (n, cin + 3))
+    act = torch.nn.functional.leaky_relu(x[:, 3:] * sc[:, 3:, None, None] + sh[:, 3:, None, None], 0.2).double()
+    ref = torch.einsum("nohw,nihw->oi", dy[:, 2:].double(), act)[:, :, None, None]
+    dw = torch.full((cout, cin, 1, 1), float("nan"), device=DEV)
+    xa, da = ops.Act(g(x), 3, cin, g(sc), g(sh), 0.2), ops.Act(g(dy), 2, cout, None, None, 1.0)
+    ops.conv2d_wgrad1x1_bf16x3(xa, da, dw)
+    got = dw.cpu().double()
+    assert ((got - ref).norm() / ref.norm()).item() < 3e-6
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 3e-6
+    ops.conv2d_wgrad1x1_bf16x3(xa, da, dw, accumulate=True)
+    assert ((dw.cpu().double() - 2 * ref).norm() / ref.norm()).item() < 6e-6
+    dw2 = torch.empty_like(dw)
+    ops.conv2d_wgrad1x1_bf16x3(xa, da, dw2)
+    assert torch.equal(dw2.cpu().double(), got)
+
+
 def test_full_rec_step_with_bf16x3_convs(S):
     """The same 'Rec' step (48 x 80, 3 coils) with the bf16x3 convolution kernels switched on for the layers they
     take: forward outputs and losses at the same bars as the fp32 path; gradients compared NORM-WISE per network
