@@ -202,6 +202,20 @@ int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, i
 int san_act_bwd_coef(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                      const float* sc, const float* sh, float slope, const float* coef,
                      float* dy, int d_ctot, int d_coff, int n, int c, int hw, void* stream);
+/* One-launch finalisations of the backward tapes (they replace chains of per-channel host-side tensor
+ * arithmetic).  part: the chunk sums san_plane_dot_stats / san_plane_stats wrote.
+ * san_bn_bwd_finalize: BatchNorm2d training backward (unet.py:125): dgamma[c] += (S2 - beta S1)/gamma,
+ *   dbeta[c] += S1, coef[n,c,4] = (dbeta/cnt, dgamma/cnt, 1/gamma, -beta/gamma) for san_act_bwd_coef.
+ * san_bias_grad_from_stats: db[c] += sum over samples and chunks of count*mean (part [n,c,tiles,3]).
+ * san_normunet_bwd_coefs: NormUnet.norm/unnorm backward (varnet.py:246-332): the two lazy affines
+ *   (a_sc, a_sh over g_ctot channels; m_sc, m_sh over x_ctot channels; zero beyond channel 1) with which
+ *   dL/dm = (a_sc g_xh + a_sh) + (m_sc m + m_sh). */
+int san_bn_bwd_finalize(const float* part, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                        float* coef, int n, int c, int tiles, double cnt, void* stream);
+int san_bias_grad_from_stats(const float* part, float* db, int n, int c, int tiles, void* stream);
+int san_normunet_bwd_coefs(const float* part_b, const float* part_a, int tiles, const float* scale,
+                           const float* shift, int x_ctot, const float* stdv, double nel,
+                           float* a_sc, float* a_sh, int g_ctot, float* m_sc, float* m_sh, int b, void* stream);
 int san_warp_bwd_grid(const float* img, const float* grid, const float* g, float* g_off,
                       int n, int c, int h, int w, void* stream);
 int san_gradient_loss_bwd(const float* offset, float* g, float gscale, int accumulate, int n, int h, int w,

@@ -981,6 +981,94 @@ static int wgrad_vec_launch(dim3 grid, hipStream_t s, const WgradArgs& a) {
     return SAN_OK;
 }
 
+
+// ---- small finalisation kernels that replace chains of one-element-per-channel ATen calls in the backward tapes ----
+// BatchNorm training backward (unet.py:125): from the per-chunk (sum u, sum u*yh) of san_plane_dot_stats, per channel
+//   dbeta = S1, dgamma = (S2 - beta S1) / gamma (accumulated into the parameter gradients) and the coefficients
+//   (m1, m2, p, q) = (dbeta/cnt, dgamma/cnt, 1/gamma, -beta/gamma) san_act_bwd_coef wants, for every sample.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                       const float* __restrict__ beta, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       float* __restrict__ coef, int n, int c, int tiles, double cnt) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = part + ((size_t)i * c + ch) * tiles * 2;
+        double a1 = 0.0, a2 = 0.0;
+        for (int t = 0; t < tiles; ++t) {
+            a1 += (double)p[2 * t];
+            a2 += (double)p[2 * t + 1];
+        }
+        s1 += a1;
+        s2 += a2;
+    }
+    const double ga = (double)gamma[ch], be = (double)beta[ch];
+    const double dg = (s2 - be * s1) / ga;
+    dgamma[ch] += (float)dg;
+    dbeta[ch] += (float)s1;
+    const float m1 = (float)(s1 / cnt), m2 = (float)(dg / cnt), pp = (float)(1.0 / ga), qq = (float)(-be / ga);
+    for (int i = 0; i < n; ++i) {
+        float* o = coef + ((size_t)i * c + ch) * 4;
+        o[0] = m1;
+        o[1] = m2;
+        o[2] = pp;
+        o[3] = qq;
+    }
+}
+
+// bias gradient from san_plane_stats chunks (count, mean, m2): db[c] += sum_{n,t} count * mean
+__global__ void bias_grad_kernel(const float* __restrict__ part, float* __restrict__ db, int n, int c, int tiles) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= c) return;
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const float* p = part + ((size_t)i * c + ch) * tiles * 3;
+        for (int t = 0; t < tiles; ++t) s += (double)p[3 * t] * (double)p[3 * t + 1];
+    }
+    db[ch] += (float)s;
+}
+
+// NormUnet backward (varnet.py:246-332): with B = chunk sums of (g_out, g_out*U), A = chunk sums of (g_xh, g_xh*xh),
+// s, t = the input's group-norm affine, sd = its std:  dmu = B1 - A1 s, dsig = B2 - A2 s, cco = dsig/(s (nel-1) sd);
+// the input gradient is then  g_m = (s g_xh + dmu/nel) + (cco s m + cco t),  written as two lazy affines.
+__global__ void normunet_bwd_coefs_kernel(const float* __restrict__ partB, const float* __restrict__ partA, int tiles,
+                                          const float* __restrict__ scale, const float* __restrict__ shift, int x_ctot,
+                                          const float* __restrict__ stdv, double nel, float* __restrict__ a_sc,
+                                          float* __restrict__ a_sh, int g_ctot, float* __restrict__ m_sc,
+                                          float* __restrict__ m_sh, int b) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int width = g_ctot > x_ctot ? g_ctot : x_ctot;
+    if (i >= b * width) return;
+    const int bi = i / width, j = i - bi * width;
+    float asc = 0.f, ash = 0.f, msc = 0.f, msh = 0.f;
+    if (j < 2) {
+        const float* pb = partB + ((size_t)bi * 2 + j) * tiles * 2;
+        const float* pa = partA + ((size_t)bi * 2 + j) * tiles * 2;
+        double b1 = 0.0, b2 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int t = 0; t < tiles; ++t) {
+            b1 += (double)pb[2 * t];
+            b2 += (double)pb[2 * t + 1];
+            a1 += (double)pa[2 * t];
+            a2 += (double)pa[2 * t + 1];
+        }
+        const double s = (double)scale[bi * x_ctot + j], t = (double)shift[bi * x_ctot + j], sd = (double)stdv[bi * 2 + j];
+        const double dmu = b1 - a1 * s, dsig = b2 - a2 * s;
+        const double cco = dsig / (s * (nel - 1.0) * sd);
+        asc = (float)s;
+        ash = (float)(dmu / nel);
+        msc = (float)(cco * s);
+        msh = (float)(cco * t);
+    }
+    if (j < g_ctot) {
+        a_sc[bi * g_ctot + j] = asc;
+        a_sh[bi * g_ctot + j] = ash;
+    }
+    if (j < x_ctot) {
+        m_sc[bi * x_ctot + j] = msc;
+        m_sh[bi * x_ctot + j] = msh;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1240,6 +1328,36 @@ int san_gradient_loss_bwd(const float* offset, float* g, float gscale, int accum
     if (bx > 256) bx = 256;
     hipLaunchKernelGGL(gradient_loss_bwd_kernel, dim3(bx, n * 2), dim3(kThreads), 0, (hipStream_t)stream, offset, g, h, w,
                        cx, cy, accumulate);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_bn_bwd_finalize(const float* part, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* coef,
+                        int n, int c, int tiles, double cnt, void* stream) {
+    SAN_CHECK_ARG(part && gamma && beta && dgamma && dbeta && coef, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && tiles > 0 && cnt > 0, "bad dims");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(san_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, part, gamma, beta,
+                       dgamma, dbeta, coef, n, c, tiles, cnt);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_bias_grad_from_stats(const float* part, float* db, int n, int c, int tiles, void* stream) {
+    SAN_CHECK_ARG(part && db, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && tiles > 0, "bad dims");
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(san_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, part, db, n, c, tiles);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_normunet_bwd_coefs(const float* part_b, const float* part_a, int tiles, const float* scale, const float* shift,
+                           int x_ctot, const float* stdv, double nel, float* a_sc, float* a_sh, int g_ctot, float* m_sc,
+                           float* m_sh, int b, void* stream) {
+    SAN_CHECK_ARG(part_b && part_a && scale && shift && stdv && a_sc && a_sh && m_sc && m_sh, "null pointer");
+    SAN_CHECK_ARG(b > 0 && tiles > 0 && x_ctot >= 2 && g_ctot >= 2 && nel > 1, "bad dims");
+    const int width = g_ctot > x_ctot ? g_ctot : x_ctot;
+    hipLaunchKernelGGL(normunet_bwd_coefs_kernel, dim3(san_cdiv(b * width, 64)), dim3(64), 0, (hipStream_t)stream, part_b,
+                       part_a, tiles, scale, shift, x_ctot, stdv, nel, a_sc, a_sh, g_ctot, m_sc, m_sh, b);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -724,6 +724,47 @@ def plane_dot_sums(g: Act, y: Act):
     return s[..., 0], s[..., 1]
 
 
+def plane_dot_part(g: Act, y: Act, tag: str = "", arena: Arena = GLOBAL_ARENA) -> torch.Tensor:
+    """The raw chunk sums [n, c, tiles, 2] of (u, u*yh) (see plane_dot_sums) for the one-launch finalisations."""
+    assert g.c == y.c
+    hw = y.h * y.w
+    tiles = lib().query("san_bwd_stat_tiles", hw)
+    part = arena.get("pdot" + tag, (y.n, y.c, tiles, 2), y.buf.device)
+    lib().call("san_plane_dot_stats", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+               float(y.slope), _p(part), y.n, y.c, hw, _stream())
+    return part
+
+
+def bn_bwd_coef(g: Act, y: Act, gamma: torch.Tensor, beta: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor,
+                arena: Arena = GLOBAL_ARENA) -> torch.Tensor:
+    """BatchNorm2d training backward (unet.py:125) for the activation y = lrelu(bn(conv)) read lazily: accumulates
+    dgamma / dbeta and returns coef [n, c, 4] for act_bwd_coef.  Two launches, no host arithmetic."""
+    part = plane_dot_part(g, y, "bn", arena)
+    coef = arena.get("bn_coef", (y.n, y.c, 4), y.buf.device)
+    lib().call("san_bn_bwd_finalize", _p(part), _p(_chk(gamma.detach(), name="gamma")), _p(_chk(beta.detach(), name="beta")),
+               _p(_chk(dgamma, name="dgamma")), _p(_chk(dbeta, name="dbeta")), _p(coef), y.n, y.c, int(part.shape[2]),
+               float(y.n * y.h * y.w), _stream())
+    return coef
+
+
+def bias_grad_acc(part: torch.Tensor, db: torch.Tensor) -> None:
+    """db[c] += sum of a plane_stats result (count * mean over samples and chunks)."""
+    n, c, tiles, _ = part.shape
+    lib().call("san_bias_grad_from_stats", _p(part), _p(_chk(db, name="db")), n, c, tiles, _stream())
+
+
+def normunet_bwd_coefs(part_b: torch.Tensor, part_a: torch.Tensor, xin: Act, std: torch.Tensor, nel: int, g_ctot: int,
+                       arena: Arena = GLOBAL_ARENA):
+    """The two lazy affines of NormUnet's input gradient (see san_normunet_bwd_coefs): (a_sc, a_sh, m_sc, m_sh)."""
+    b, dev = xin.n, xin.buf.device
+    a_sc, a_sh = arena.get("nub.a_sc", (b, g_ctot), dev), arena.get("nub.a_sh", (b, g_ctot), dev)
+    m_sc, m_sh = arena.get("nub.m_sc", (b, xin.ctot), dev), arena.get("nub.m_sh", (b, xin.ctot), dev)
+    assert xin.coff == 0
+    lib().call("san_normunet_bwd_coefs", _p(part_b), _p(part_a), int(part_b.shape[2]), _p(xin.scale), _p(xin.shift), xin.ctot,
+               _p(_chk(std, name="std")), float(nel), _p(a_sc), _p(a_sh), g_ctot, _p(m_sc), _p(m_sh), b, _stream())
+    return a_sc, a_sh, m_sc, m_sh
+
+
 def dc_weight_grad(G: torch.Tensor, k: torch.Tensor, k0: torch.Tensor, mask_f: torch.Tensor) -> torch.Tensor:
     """dL/d(dc_weight) of k' = k - w*M*(k-k0) - R given G = dL/dk' (0-d tensor)."""
     n, c, h, w = k.shape

@@ -253,22 +253,14 @@ class UNet(torch.nn.Module):
                 n, h, w = o.n, o.h, o.w
                 dy = tmp(o.c, h, w, n)
                 if bn is not None and bn.training:
-                    S1, S2 = ops.plane_dot_sums(g, o)            # per (n, c): sum u, sum u*yh
-                    S1, S2 = S1.sum(0), S2.sum(0)
-                    gamma, beta = bn.weight.detach().double(), bn.bias.detach().double()
-                    cnt = float(n * h * w)
-                    dbeta = S1
-                    dgamma = (S2 - beta * S1) / gamma            # sum u * yn, yn = (yh - beta)/gamma
-                    _grad_of(bn.weight).add_(dgamma.float())
-                    _grad_of(bn.bias).add_(dbeta.float())
-                    coef = torch.stack([dbeta / cnt, dgamma / cnt, 1.0 / gamma, -beta / gamma], dim=1).float()
-                    ops.act_bwd_coef(g, o, coef[None].expand(n, -1, -1).contiguous(), dy)
+                    # per channel over (N, H, W): dbeta = sum u, dgamma = sum u * yn with yn = (yh - beta)/gamma
+                    coef = ops.bn_bwd_coef(g, o, bn.weight, bn.bias, _grad_of(bn.weight), _grad_of(bn.bias))
+                    ops.act_bwd_coef(g, o, coef, dy)
                 else:
                     ops.act_bwd(g, o, dy, instance_norm=False)   # eval BN / plain activation read
                     if bn is not None:
                         raise NotImplementedError("backward through eval-mode BatchNorm parameters")
-                part = ops.plane_stats(dy, tag="abwd.b")
-                _grad_of(conv.bias).add_((part[..., 0] * part[..., 1]).sum(dim=(0, 2)))
+                ops.bias_grad_acc(ops.plane_stats(dy, tag="abwd.b"), _grad_of(conv.bias))
                 ops.conv2d_wgrad(x, dy, _grad_of(conv.weight), accumulate=True)
                 if self._produced.get(x.buf.data_ptr()):
                     gx = tmp(x.c, h, w, n)

@@ -244,8 +244,7 @@ class Unet(nn.Module):
         cur = tape["last_in"]
         gc = ops.full(g_conv.contiguous())
         # final 1x1 conv (+bias): bias gradient = plane sums of g
-        part = ops.plane_stats(gc, tag="bgrad")
-        _grad_of(last.bias).add_((part[..., 0] * part[..., 1]).sum(dim=(0, 2)))
+        ops.bias_grad_acc(ops.plane_stats(gc, tag="bgrad"), _grad_of(last.bias))
         ops.conv2d_wgrad(cur, gc, _grad_of(last.weight), accumulate=True)
         g = Act(ARENA.get(f"bwd.g.{cur.c}.{cur.h}", (n, cur.c, cur.h, cur.w), dev), 0, cur.c)
         ops.conv2d_dgrad(gc, last.weight, g)
@@ -343,25 +342,12 @@ class NormUnet(nn.Module):
         nel = h * w
         g_out = g_out.contiguous()
         isd = (1.0 / std).contiguous()
-        B1, B2 = ops.plane_dot_sums(ops.full(g_out), Act(out_planar, 0, 2, isd, (-mean * isd).contiguous(), 1.0))
+        part_b = ops.plane_dot_part(ops.full(g_out), Act(out_planar, 0, 2, isd, (-mean * isd).contiguous(), 1.0), "nu.b")
         g_u = ARENA.get("bwd.g_u", (b, 2, h, w), dev)
-        ops.apply(Act(g_out, 0, 2, std, torch.zeros_like(std), 1.0), ops.full(g_u))
+        ops.apply(Act(g_out, 0, 2, std, ARENA.get("bwd.zero_sh", tuple(std.shape), dev, zero=True), 1.0), ops.full(g_u))
         g_xh = self.unet.run_bwd(g_u, key)                         # [B, 2 or 3, H, W]
-        ctot = g_xh.shape[1]
-        A1, A2 = ops.plane_dot_sums(Act(g_xh, 0, 2), xin.view(0, 2))
-        s = xin.scale[:, 0:2].double()
-        t = xin.shift[:, 0:2].double()
-        dmu = B1 - A1 * s
-        dsig = B2 - A2 * s
-        cco = dsig / (s * (nel - 1) * std.double())
-        a_sc = torch.zeros((b, ctot), device=dev)
-        a_sh = torch.zeros((b, ctot), device=dev)
-        a_sc[:, 0:2] = s.float()
-        a_sh[:, 0:2] = (dmu / nel).float()
-        m_sc = torch.zeros((b, xin.ctot), device=dev)
-        m_sh = torch.zeros((b, xin.ctot), device=dev)
-        m_sc[:, 0:2] = (cco * s).float()
-        m_sh[:, 0:2] = (cco * t).float()
+        part_a = ops.plane_dot_part(Act(g_xh, 0, 2), xin.view(0, 2), "nu.a")
+        a_sc, a_sh, m_sc, m_sh = ops.normunet_bwd_coefs(part_b, part_a, xin, std, nel, g_xh.shape[1])
         g_m = torch.empty((b, 2, h, w), device=dev)
         ops.add(Act(g_xh, 0, 2, a_sc, a_sh, 1.0), Act(xin.buf, xin.coff, 2, m_sc, m_sh, 1.0), ops.full(g_m))
         g_ref = None
