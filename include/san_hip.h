@@ -213,6 +213,10 @@ int san_act_bwd_coef(const float* g, int g_ctot, int g_coff, const float* y, int
 int san_bn_bwd_finalize(const float* part, const float* gamma, const float* beta, float* dgamma, float* dbeta,
                         float* coef, int n, int c, int tiles, double cnt, void* stream);
 int san_bias_grad_from_stats(const float* part, float* db, int n, int c, int tiles, void* stream);
+/* BatchNorm2d running statistics in one launch: running = (1-m) running + m batch (variance times var_factor),
+ * *num_batches_tracked += 1 (int64, may be NULL).  unet.py:125 (torch.nn.BatchNorm2d training forward). */
+int san_bn_update_running(float* rmean, float* rvar, long long* num_batches_tracked, const float* bmean,
+                          const float* bvar, int c, float momentum, float var_factor, void* stream);
 int san_normunet_bwd_coefs(const float* part_b, const float* part_a, int tiles, const float* scale,
                            const float* shift, int x_ctot, const float* stdv, double nel,
                            float* a_sc, float* a_sh, int g_ctot, float* m_sc, float* m_sh, int b, void* stream);
@@ -370,13 +374,14 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin,
 
 /* 1x1 weight gradient on the bf16 matrix cores (same file): san_conv2d_wgrad's contract for ks = 1 -- the
  * 2x2 transposed convolutions (varnet.py:159-192, run as 1x1 convolutions to 4 cout + pixel shuffle) and the
- * alignment net's 1x1 layers (unet.py:119-140).  Needs h*w % 4 == 0 and 16-byte aligned x / dy. */
+ * alignment net's 1x1 layers (unet.py:119-140).  Needs h*w % 4 == 0 and 16-byte aligned x / dy.
+ * transposed = 1 writes dw as [cin][cout] (the ConvTranspose2d weight layout [Cin, Cout*4]) instead of [cout][cin]. */
 int san_conv1x1_wgrad_bf16x3_eligible(int n, int h, int w, int cin, int cout);
 size_t san_conv1x1_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cout);
 int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin,
                              const float* in_scale, const float* in_shift, float in_slope,
                              const float* dy, int dy_ctot, int dy_coff, int cout,
-                             float* dw, int accumulate, void* scratch,
+                             float* dw, int accumulate, int transposed, void* scratch,
                              int n, int h, int w, void* stream);
 
 /* Batched weight packing for training, where every weight changes every step: san_conv_pack_job

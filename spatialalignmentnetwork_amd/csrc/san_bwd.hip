@@ -1016,6 +1016,18 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, const flo
     }
 }
 
+// BatchNorm2d running statistics (unet.py:125, momentum m): running = (1 - m) running + m batch, the batch variance
+// scaled by var_factor (unbiased / count-scale correction); num_batches_tracked += 1
+__global__ void bn_update_running_kernel(float* __restrict__ rmean, float* __restrict__ rvar, long long* __restrict__ nbt,
+                                         const float* __restrict__ bmean, const float* __restrict__ bvar, int c, float m,
+                                         float var_factor) {
+    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch == 0 && nbt) *nbt += 1;
+    if (ch >= c) return;
+    rmean[ch] = rmean[ch] * (1.f - m) + m * bmean[ch];
+    rvar[ch] = rvar[ch] * (1.f - m) + m * (bvar[ch] * var_factor);
+}
+
 // bias gradient from san_plane_stats chunks (count, mean, m2): db[c] += sum_{n,t} count * mean
 __global__ void bias_grad_kernel(const float* __restrict__ part, float* __restrict__ db, int n, int c, int tiles) {
     const int ch = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1358,6 +1370,16 @@ int san_normunet_bwd_coefs(const float* part_b, const float* part_a, int tiles, 
     const int width = g_ctot > x_ctot ? g_ctot : x_ctot;
     hipLaunchKernelGGL(normunet_bwd_coefs_kernel, dim3(san_cdiv(b * width, 64)), dim3(64), 0, (hipStream_t)stream, part_b,
                        part_a, tiles, scale, shift, x_ctot, stdv, nel, a_sc, a_sh, g_ctot, m_sc, m_sh, b);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_bn_update_running(float* rmean, float* rvar, long long* num_batches_tracked, const float* bmean, const float* bvar,
+                          int c, float momentum, float var_factor, void* stream) {
+    SAN_CHECK_ARG(rmean && rvar && bmean && bvar, "null pointer");
+    SAN_CHECK_ARG(c > 0, "bad dims");
+    hipLaunchKernelGGL(bn_update_running_kernel, dim3(san_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, rmean, rvar,
+                       num_batches_tracked, bmean, bvar, c, momentum, var_factor);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -626,29 +626,39 @@ __global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
     }
 }
 
-// pass 3: dw[co][ci][tap] (+)= sum_pp partial[pp][tap][ci][co], fixed order
+// pass 3: dw[co][ci][tap] (+)= sum_pp partial[pp][tap][ci][co], fixed order.  64 consecutive output channels per
+// thread row (coalesced partial reads), the partitions dealt to 4 thread rows whose sums meet in LDS in a fixed order.
+// transposed: dw is [ci][co][tap] (the transposed convolution's weight layout).
 __global__ void __launch_bounds__(256) wgrad_bf16x3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
                                                                    int P, int cin, int cout, int cin_pad, int cout_pad,
-                                                                   int accumulate, int taps) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= cout * cin * taps) return;
-    const int co = e % cout;
-    const int ci = (e / cout) % cin;
-    const int tap = e / (cout * cin);
+                                                                   int accumulate, int taps, int transposed) {
+    __shared__ float red[3][64];
+    const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const bool live = e < cout * cin * taps;
+    const int ec = live ? e : 0;
+    const int co = ec % cout;
+    const int ci = (ec / cout) % cin;
+    const int tap = ec / (cout * cin);
     const size_t stride = (size_t)taps * cin_pad * cout_pad;
     const float* p = partial + ((size_t)tap * cin_pad + ci) * cout_pad + co;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int pp = 0;
-    for (; pp + 4 <= P; pp += 4) {
+    int pp = row;
+    for (; pp + 12 < P; pp += 16) {
         s0 += p[(size_t)pp * stride];
-        s1 += p[(size_t)(pp + 1) * stride];
-        s2 += p[(size_t)(pp + 2) * stride];
-        s3 += p[(size_t)(pp + 3) * stride];
+        s1 += p[(size_t)(pp + 4) * stride];
+        s2 += p[(size_t)(pp + 8) * stride];
+        s3 += p[(size_t)(pp + 12) * stride];
     }
-    for (; pp < P; ++pp) s0 += p[(size_t)pp * stride];
-    const float s = (s0 + s1) + (s2 + s3);
-    float* o = dw + ((size_t)co * cin + ci) * taps + tap;
-    *o = accumulate ? *o + s : s;
+    for (; pp < P; pp += 4) s0 += p[(size_t)pp * stride];
+    float s = (s0 + s1) + (s2 + s3);
+    if (row > 0) red[row - 1][lane] = s;
+    __syncthreads();
+    if (row == 0 && live) {
+        s = ((s + red[0][lane]) + red[1][lane]) + red[2][lane];
+        float* o = transposed ? dw + ((size_t)ci * cout + co) * taps + tap : dw + ((size_t)co * cin + ci) * taps + tap;
+        *o = accumulate ? *o + s : s;
+    }
 }
 
 struct WBPlan {
@@ -949,8 +959,8 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, con
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
     const int count = cout * cin * 9;
-    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 256)), dim3(256), 0, s, partial, dw, p.P, cin, cout,
-                       p.cin_pad, p.cout_pad, accumulate, 9);
+    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 64)), dim3(256), 0, s, partial, dw, p.P, cin, cout,
+                       p.cin_pad, p.cout_pad, accumulate, 9, 0);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
@@ -971,7 +981,7 @@ size_t san_conv1x1_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int 
 
 int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
                              float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
-                             void* scratch, int n, int h, int w, void* stream) {
+                             int transposed, void* scratch, int n, int h, int w, void* stream) {
     SAN_CHECK_ARG(x && dy && dw && scratch, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && dy_coff >= 0 && dy_coff + cout <= dy_ctot, "bad channel view");
@@ -1015,8 +1025,8 @@ int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, co
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
     const int count = cout * cin;
-    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 256)), dim3(256), 0, s, a.partial, dw, p.P, cin, cout,
-                       p.cin_pad, p.cout_pad, accumulate, 1);
+    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 64)), dim3(256), 0, s, a.partial, dw, p.P, cin, cout,
+                       p.cin_pad, p.cout_pad, accumulate, 1, transposed);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

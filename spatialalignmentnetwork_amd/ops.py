@@ -658,8 +658,7 @@ def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, ar
     if USE_BF16X3[0] and lib().query("san_conv_wgrad_bf16x3_eligible", x.n, x.h, x.w, cin, cout, ks):
         conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena)
         return
-    if (USE_BF16X3[0] and ks == 1 and lib().query("san_conv1x1_wgrad_bf16x3_eligible", x.n, x.h, x.w, cin, cout)
-            and (x.buf.data_ptr() | dy.buf.data_ptr()) % 16 == 0):
+    if ks == 1 and wgrad1x1_bf16x3_ok(x, dy):
         conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena)
         return
     P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout, ks)
@@ -683,14 +682,22 @@ def conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = Fa
     _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args))
 
 
-def conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
-    """The 1x1 weight gradient on the bf16 matrix cores (csrc/san_wgrad_bf16.hip, wgrad1x1_bf16x3_kernel)."""
-    cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
-    assert ks == 1 and x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
+def wgrad1x1_bf16x3_ok(x: Act, dy: Act) -> bool:
+    return bool(USE_BF16X3[0] and lib().query("san_conv1x1_wgrad_bf16x3_eligible", x.n, x.h, x.w, x.c, dy.c)
+                and (x.buf.data_ptr() | dy.buf.data_ptr()) % 16 == 0)
+
+
+def conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
+                           transposed: bool = False) -> None:
+    """The 1x1 weight gradient on the bf16 matrix cores (csrc/san_wgrad_bf16.hip, wgrad1x1_bf16x3_kernel).
+    transposed: dw is laid out [cin, cout(, ...)] -- a ConvTranspose2d weight [Cin, Cout, 2, 2] seen as [Cin, 4 Cout]."""
+    cin, cout = x.c, dy.c
+    assert dw.numel() == cin * cout and x.buf.shape[2:] == dy.buf.shape[2:]
+    assert transposed or (dw.shape[0], dw.shape[1]) == (cout, cin)
     nbytes = lib().query("san_conv1x1_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
     scratch = arena.scratch("wgrad_bf16x3", nbytes, x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
-            cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
+            cout, _p(_chk(dw, name="dw")), int(accumulate), int(transposed), _p(scratch), x.n, x.h, x.w, _stream())
     _timed("wgrad1x1_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin, "FLOP", lambda: lib().call("san_conv1x1_wgrad_bf16x3", *args))
 
 
@@ -745,6 +752,14 @@ def bn_bwd_coef(g: Act, y: Act, gamma: torch.Tensor, beta: torch.Tensor, dgamma:
                _p(_chk(dgamma, name="dgamma")), _p(_chk(dbeta, name="dbeta")), _p(coef), y.n, y.c, int(part.shape[2]),
                float(y.n * y.h * y.w), _stream())
     return coef
+
+
+def bn_update_running(bn, bmean: torch.Tensor, bvar: torch.Tensor, momentum: float, var_factor: float) -> None:
+    """BatchNorm2d running statistics and num_batches_tracked in one launch (unet.py:125)."""
+    c = bn.running_mean.shape[0]
+    lib().call("san_bn_update_running", _p(_chk(bn.running_mean, name="running_mean")), _p(_chk(bn.running_var, name="running_var")),
+               _p(_chk(bn.num_batches_tracked, torch.int64, "num_batches_tracked")), _p(_chk(bmean, name="bmean")),
+               _p(_chk(bvar, name="bvar")), c, float(momentum), float(var_factor), _stream())
 
 
 def bias_grad_acc(part: torch.Tensor, db: torch.Tensor) -> None:

@@ -338,11 +338,9 @@ def _update_running_stats(bn: torch.nn.BatchNorm2d, bmean: torch.Tensor, bvar_un
     ``count_scale`` = 4 for the Up blocks, whose statistics are taken at low
     resolution: the reference sees every value 4 times, which changes only the
     n/(n-1) factor of the unbiased variance."""
-    with torch.no_grad():
-        m = bn.momentum if bn.momentum is not None else 0.1
-        if count_scale != 1 and count > 1:
-            big = count * count_scale
-            bvar_unbiased = bvar_unbiased * ((count - 1) / count) * (big / (big - 1))
-        bn.running_mean.mul_(1 - m).add_(bmean, alpha=m)
-        bn.running_var.mul_(1 - m).add_(bvar_unbiased, alpha=m)
-        bn.num_batches_tracked += 1
+    m = bn.momentum if bn.momentum is not None else 0.1
+    factor = 1.0
+    if count_scale != 1 and count > 1:
+        big = count * count_scale
+        factor = ((count - 1) / count) * (big / (big - 1))
+    ops.bn_update_running(bn, bmean, bvar_unbiased, m, factor)

@@ -111,9 +111,13 @@ class TransposeConvBlock(nn.Module):
         wv = _view_cached(wt, (cin, 4 * cout, 1, 1))
         # dL/dx[ci] = sum_c' Wv[ci, c'] dy'[c']  == forward 1x1 conv with weight [cout'=Cin, cin'=4Cout]
         ops.conv2d(dyp, wv, None, g_in)
-        dwv = ARENA.get("bwd.dwv", (4 * cout, cin, 1, 1), dev)
-        ops.conv2d_wgrad(x, dyp, dwv, accumulate=False)
-        _grad_of(wt).add_(dwv.view(4 * cout, cin).t().reshape(cin, cout, 2, 2))
+        if ops.wgrad1x1_bf16x3_ok(x, dyp):
+            # the reduction writes [Cin][4 Cout] = the ConvTranspose2d weight layout: accumulate in place
+            ops.conv2d_wgrad1x1_bf16x3(x, dyp, _grad_of(wt), accumulate=True, transposed=True)
+        else:
+            dwv = ARENA.get("bwd.dwv", (4 * cout, cin, 1, 1), dev)
+            ops.conv2d_wgrad(x, dyp, dwv, accumulate=False)
+            _grad_of(wt).add_(dwv.view(4 * cout, cin).t().reshape(cin, cout, 2, 2))
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         n, _, h, w = image.shape

@@ -763,6 +763,10 @@ def test_wgrad1x1_bf16x3_vs_float64(S, n, cin, cout, h, w):
     dw2 = torch.empty_like(dw)
     ops.conv2d_wgrad1x1_bf16x3(xa, da, dw2)
     assert torch.equal(dw2.cpu().double(), got)
+    # transposed write (the ConvTranspose2d weight layout [Cin, Cout']), accumulating
+    dwt = torch.ones((cin, cout), device=DEV)
+    ops.conv2d_wgrad1x1_bf16x3(xa, da, dwt, accumulate=True, transposed=True)
+    assert torch.allclose(dwt.cpu().double() - 1.0, got[:, :, 0, 0].t(), rtol=0, atol=1e-6 * float(ref.abs().max()))
 
 
 def test_full_rec_step_with_bf16x3_convs(S):
