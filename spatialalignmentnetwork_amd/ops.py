@@ -22,26 +22,43 @@ NORM_INSTANCE, NORM_GROUP, NORM_BATCH = 0, 1, 2
 class KernelTimer:
     """Optional per-launch timing with HIP events on the launch stream (bench.py
     uses it for the roofline figures).  bracket(name, work, unit, fn) times one
-    C-ABI call; totals() needs a prior device synchronisation."""
+    C-ABI call; totals() needs a prior device synchronisation.
 
-    def __init__(self):
+    An event pair costs a few microseconds and keeps neighbouring kernels from
+    overlapping, so only every ``stride``-th launch of a family is bracketed (a
+    stride co-prime with the per-cascade layer counts walks through all layers);
+    every launch is still counted, and totals() scales the sampled time up."""
+
+    def __init__(self, stride: int = 7):
+        self.stride = max(1, int(stride))
         self.recs = []
+        self.seen = {}
 
     def bracket(self, name, work, unit, fn):
+        d = self.seen.setdefault(name, {"launches": 0, "work": 0.0, "unit": unit})
+        d["launches"] += 1
+        d["work"] += work
+        if (d["launches"] - 1) % self.stride:
+            fn()
+            return
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.recs.append((name, work, unit, e0, e1))
+        self.recs.append((name, work, e0, e1))
 
     def totals(self):
-        out = {}
-        for name, work, unit, e0, e1 in self.recs:
-            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0, "unit": unit})
-            d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["work"] += work
+        """{family: launches, work (all launches), sampled_launches / sampled_ms / sampled_work (the bracketed ones),
+        ms = sampled_ms scaled by work (the estimate for all launches)}"""
+        out = {k: dict(v, sampled_launches=0, sampled_ms=0.0, sampled_work=0.0) for k, v in self.seen.items()}
+        for name, work, e0, e1 in self.recs:
+            d = out[name]
+            d["sampled_launches"] += 1
+            d["sampled_ms"] += e0.elapsed_time(e1)
+            d["sampled_work"] += work
+        for d in out.values():
+            d["ms"] = d["sampled_ms"] * d["work"] / d["sampled_work"] if d["sampled_work"] > 0 else 0.0
         return out
 
 
