@@ -37,7 +37,7 @@ for n, cin, cout, h, w in [(2, 24, 32, 16, 32), (1, 72, 72, 20, 44), (2, 36, 72,
 print("timing (N=8):")
 import ctypes
 elig_real = ops.bf16x3_eligible
-for cin, cout, s in [(18,36,160),(36,36,160),(72,36,160),(36,18,320),(18,18,320),(32,32,320),(36,72,80),(144,72,80)]:
+for cin, cout, s in [(3,18,320),(8,8,320),(8,16,160),(16,16,160),(16,32,80),(18,2,320),(24,24,160),(64,32,320),(32,64,160),(18,36,320),(18,36,160),(36,36,160),(72,36,160),(36,18,320),(18,18,320),(32,32,320),(36,72,80),(144,72,80),(288,288,20),(144,288,20),(32,2,320)]:
     x = torch.randn(8, cin, s, s, device=dev); wt = torch.randn(cout, cin, 3, 3, device=dev) * 0.05
     sc = torch.rand(8, cin, device=dev) + 0.5; sh = torch.randn(8, cin, device=dev)
     y = torch.empty(8, cout, s, s, device=dev); xa = ops.Act(x, 0, cin, sc, sh, 0.2); ya = ops.full(y)

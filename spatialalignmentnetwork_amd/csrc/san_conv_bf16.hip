@@ -25,6 +25,7 @@
 #include "san_common.h"
 
 #include <cstdint>
+#include <cstdlib>
 
 namespace {
 
@@ -93,7 +94,11 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
     p3 = cvt_pk(r0 - __builtin_bit_cast(float, p2 << 16), r1 - __builtin_bit_cast(float, p2 & 0xffff0000u));
 }
 
-template <int MB>
+// WD ("weights direct"): the K-steps read their weight operands straight from the packed image in L2 instead of
+// staging each chunk's weights through LDS.  All four waves then fetch the same weights (4x the L1 traffic), but the
+// workgroup needs 49 KB of LDS instead of 92-156 KB, so three of them share a CU: measured +17..30 % for MB <= 4 with
+// up to 6 chunks (64->64 @160^2, 96->32 @320^2, 72->36 @160^2), -7..33 % for MB = 5 or deep K (288->288 @20^2).
+template <int MB, bool WD>
 __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     constexpr int WCH = kSteps * MB * 3 * 64;          // uint4 per (cg, chunk) weight image
     constexpr int NWU = kSteps * MB * 3;               // ... = NWU wave-wide pieces (64 lanes x 16 B), one per (step, block, part)
@@ -154,7 +159,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     // The chunk's lazy affine (24 scales + 24 shifts of this sample) travels through a double-buffered LDS
     // table: thread t < 48 fetches ONE value with the tile and stores it during the previous chunk's staging
     // phase (two barriers before anyone reads it) -- not 64 loads per thread per chunk.
-    float* lds_aff = reinterpret_cast<float*>(smem + 3 * kPartB + (size_t)WCH * 16);
+    float* lds_aff = reinterpret_cast<float*>(smem + 3 * kPartB + (WD ? (size_t)0 : (size_t)WCH * 16));
     const bool has_aff = a.in_scale != nullptr;
     float my_aff = 0.f;
     auto fetch_aff = [&](int chunk) {
@@ -172,14 +177,16 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
             for (int i = 0; i < 8; ++i) st[s][i] = xs[s][min(c0 + i, a.cin - 1) * HWp];
         }
         fetch_aff(chunk + 1);                         // stored as the next table during this chunk's staging phase
-        // this group's MB blocks of every K-step: 7 contiguous runs of MB*3 pieces.  The piece index is wave-uniform,
-        // so its step / offset arithmetic runs on the scalar unit and the load is base + lane.
-        const u32x4* src = reinterpret_cast<const u32x4*>(a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane);
-#pragma unroll
-        for (int q = 0; q < WSL; ++q) {
-            const int u = min(wave + q * (kT / 64), NWU - 1);
-            const int st_ = u / (MB * 3);
-            wst[q] = src[(st_ * a.nblkp * 3 + (u - st_ * (MB * 3))) * 64];
+        if constexpr (!WD) {
+            // this group's MB blocks of every K-step: 7 contiguous runs of MB*3 pieces.  The piece index is wave-uniform,
+            // so its step / offset arithmetic runs on the scalar unit and the load is base + lane.
+            const u32x4* src = reinterpret_cast<const u32x4*>(a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane);
+    #pragma unroll
+            for (int q = 0; q < WSL; ++q) {
+                const int u = min(wave + q * (kT / 64), NWU - 1);
+                const int st_ = u / (MB * 3);
+                wst[q] = src[(st_ * a.nblkp * 3 + (u - st_ * (MB * 3))) * 64];
+            }
         }
     };
 
@@ -232,21 +239,27 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 *reinterpret_cast<uint4*>(lds_a + 2 * kPartB + s_loff[s]) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
             }
         }
+        if constexpr (!WD) {
 #pragma unroll
-        for (int q = 0; q < WSL; ++q) {
-            const int u = wave + q * (kT / 64);
-            if (u < NWU) *reinterpret_cast<u32x4*>(lds_w + u * 64 + lane) = wst[q];
+            for (int q = 0; q < WSL; ++q) {
+                const int u = wave + q * (kT / 64);
+                if (u < NWU) *reinterpret_cast<u32x4*>(lds_w + u * 64 + lane) = wst[q];
+            }
         }
         __syncthreads();
         if (chunk + 1 < a.chunks) prefetch(chunk + 1);
         // ---- 7 K-steps: (MB + 4) x 3 sixteen-byte operand reads feed 6 x MB x 4 MFMAs; the reads of step s+1
         // are issued before the MFMAs of step s (two operand sets, compile-time indices after unrolling)
         Frag wa[2][MB][3], xa[2][4][3];
+        const uint4* wsrc = a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane;      // (WD)
         auto load_step = [&](int s, Frag (&wq)[MB][3], Frag (&xq)[4][3]) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) wq[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
+                for (int p = 0; p < 3; ++p) {
+                    if constexpr (WD) wq[m][p].u = wsrc[((s * a.nblkp + m) * 3 + p) * 64];
+                    else wq[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
+                }
             const int to = tapoff[s];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
@@ -424,12 +437,12 @@ int pick_mb(int cout, int tiles) {
     return best > 5 ? 5 : best;
 }
 
-template <int MB>
+template <int MB, bool WD>
 int launch_b(const BArgs& a, hipStream_t s) {
-    constexpr size_t lds = 3 * (size_t)kPartB + (size_t)kSteps * MB * 3 * 64 * 16 + 2 * 48 * sizeof(float);
+    constexpr size_t lds = 3 * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -437,9 +450,16 @@ int launch_b(const BArgs& a, hipStream_t s) {
         configured = true;
     }
     const int total = a.tiles_x * a.tiles_y * a.cgs * a.N;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<MB>), dim3(total), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD>), dim3(total), dim3(kT), lds, s, a);
     return SAN_OK;
 }
+
+int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): force the weights-direct choice
+struct B16Env {
+    B16Env() {
+        if (const char* e = getenv("SAN_B16_WD")) g_b16_wd = atoi(e);
+    }
+} g_b16_env;
 
 }  // namespace
 
@@ -449,8 +469,10 @@ extern "C" {
 // packs the weights with san_conv_bf16x3_pack and sizes statistics with san_conv_bf16x3_stat_tiles.
 int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks) {
     if (ks != 3) return 0;
-    if (cout < 32 || cin < 24) return 0;
-    if (cout < 48 && cin < 64) return 0;          // 32 -> 32 @320^2: the fp32 kernel is still 12 % faster
+    // measured against the fp32 4x4x1 kernel (N = 8): faster from 18 -> 18 (66 vs 92 us @320^2) and 24 -> 24 upwards
+    // since the weights-direct form; 16 -> 16 ties, below that the 16-wide tiles are mostly padding (8 -> 8: 67 vs 33 us)
+    const int lo = cin < cout ? cin : cout, hi = cin < cout ? cout : cin;
+    if (lo < 16 || hi < 18) return 0;
     if (h < 8 || w < 16) return 0;
     return 1;
 }
@@ -531,11 +553,16 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const
     a.nblkp = p.nblkp;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    switch (mb) {
-        case 2: rc = launch_b<2>(a, s); break;
-        case 3: rc = launch_b<3>(a, s); break;
-        case 4: rc = launch_b<4>(a, s); break;
-        default: rc = launch_b<5>(a, s); break;
+    int wd = (mb <= 4 && p.chunks <= 6 && h * w >= 1600) ? 1 : 0;        // see the WD note at the kernel
+    if (g_b16_wd >= 0) wd = g_b16_wd && mb <= 4;
+    switch (mb * 2 + wd) {
+        case 4: rc = launch_b<2, false>(a, s); break;
+        case 5: rc = launch_b<2, true>(a, s); break;
+        case 6: rc = launch_b<3, false>(a, s); break;
+        case 7: rc = launch_b<3, true>(a, s); break;
+        case 8: rc = launch_b<4, false>(a, s); break;
+        case 9: rc = launch_b<4, true>(a, s); break;
+        default: rc = launch_b<5, false>(a, s); break;
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
