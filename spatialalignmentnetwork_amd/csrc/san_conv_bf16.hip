@@ -455,9 +455,11 @@ int launch_b(const BArgs& a, hipStream_t s) {
 }
 
 int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): force the weights-direct choice
+int g_b16_mb = -1;             // tuning hook (SAN_B16_MB=2..5): force the channel blocks per workgroup
 struct B16Env {
     B16Env() {
         if (const char* e = getenv("SAN_B16_WD")) g_b16_wd = atoi(e);
+        if (const char* e = getenv("SAN_B16_MB")) g_b16_mb = atoi(e);
     }
 } g_b16_env;
 
@@ -547,7 +549,8 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const
     a.W = w;
     a.tiles_x = san_cdiv(w, kTW);
     a.tiles_y = san_cdiv(h, kTH);
-    const int mb = pick_mb(cout, a.tiles_x * a.tiles_y * n);
+    int mb = pick_mb(cout, a.tiles_x * a.tiles_y * n);
+    if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
     a.cgs = san_cdiv(san_cdiv(cout, 16), mb);
     a.chunks = p.chunks;
     a.nblkp = p.nblkp;
