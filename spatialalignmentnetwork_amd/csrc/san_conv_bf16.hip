@@ -467,6 +467,13 @@ struct B16Env {
 
 extern "C" {
 
+// tuning / test hook: wd = -1 automatic, 0 LDS-staged weights, 1 weights-direct where MB <= 4; mb = -1 automatic or 2..5
+int san_conv_bf16x3_set_tuning(int wd, int mb) {
+    g_b16_wd = wd;
+    g_b16_mb = mb;
+    return SAN_OK;
+}
+
 // 1 when san_conv2d_bf16x3_fwd takes this layer (3x3, channel counts that fill 16-wide tiles); the caller then
 // packs the weights with san_conv_bf16x3_pack and sizes statistics with san_conv_bf16x3_stat_tiles.
 int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks) {

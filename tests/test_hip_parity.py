@@ -659,14 +659,24 @@ def test_metrics_vs_reference(S, tag):
     assert abs(M.ssim(g(gt), g(pred)) - (1.0 - S.O.ssimloss(gt, pred).item())) < 2e-5
 
 
+@pytest.mark.parametrize("wd", [-1, 0, 1], ids=["auto", "lds-weights", "direct-weights"])
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 24, 48, 16, 32), (1, 72, 72, 20, 44), (2, 36, 72, 40, 40), (1, 96, 32, 33, 50),
-                                            (2, 144, 144, 24, 24), (1, 288, 144, 16, 16), (1, 64, 64, 9, 17)])
-def test_conv_bf16x3_vs_float64(S, n, cin, cout, h, w):
+                                            (2, 144, 144, 24, 24), (1, 288, 144, 16, 16), (1, 64, 64, 9, 17), (2, 18, 18, 48, 64),
+                                            (1, 36, 18, 64, 64), (2, 18, 36, 40, 48)])
+def test_conv_bf16x3_vs_float64(S, n, cin, cout, h, w, wd):
     """The bf16 matrix-core convolution with three-way split operands (csrc/san_conv_bf16.hip) against float64:
     forward with lazy affine + LeakyReLU input, bias, channel views and fused statistics, and the data gradient.
     Bars: 3e-6 relative on outputs (fp32-level: the split drops O(2^-24) terms), 2e-5 on merged statistics."""
     ops = S.ops
     assert ops.bf16x3_eligible(cin, cout, h, w, 3)
+    ops.lib().call("san_conv_bf16x3_set_tuning", wd, -1)
+    try:
+        _conv_bf16x3_checks(ops, n, cin, cout, h, w)
+    finally:
+        ops.lib().call("san_conv_bf16x3_set_tuning", -1, -1)
+
+
+def _conv_bf16x3_checks(ops, n, cin, cout, h, w):
     x = philox("b16.x", (n, cin + 3, h, w))
     wt = philox("b16.w", (cout, cin, 3, 3)) * (1.0 / (cin * 9) ** 0.5)
     sc, sh = philox("b16.sc", (n, cin + 3), lo=0.5, hi=1.5), philox("b16.sh", (n, cin + 3))
