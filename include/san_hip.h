@@ -357,6 +357,19 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
                           float* y, int y_ctot, int y_coff, int cout, float* part_stats,
                           int n, int h, int w, void* stream);
 
+/* The same kernel as a 1x1 convolution (the alignment net's 1x1 layers, unet.py:64-77; the data gradient of
+ * the transposed convolutions): weights packed with the _ks entry points (ks = 1 or 3; the plain ones are
+ * ks = 3), statistics tiles as san_conv_bf16x3_stat_tiles. */
+size_t san_conv_bf16x3_packed_bytes_ks(int cout, int cin, int ks);
+int san_conv_bf16x3_pack_ks(const float* w, void* packed, int cout, int cin, int mode, int ks, void* stream);
+int san_conv_bf16x3_pack_job_ks(long long* job8, const float* w, void* packed, int cout, int cin, int mode, int ks);
+int san_conv1x1_bf16x3_eligible(int cin, int cout, int h, int w);
+int san_conv1x1_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
+                           const float* in_scale, const float* in_shift, float in_slope,
+                           const void* w_packed, const float* bias,
+                           float* y, int y_ctot, int y_coff, int cout, float* part_stats,
+                           int n, int h, int w, void* stream);
+
 /* 3x3 weight gradient on the bf16 matrix cores, fp32-level accuracy (csrc/san_wgrad_bf16.hip): same
  * contract as san_conv2d_wgrad for ks = 3 (backward of F.conv2d at varnet.py:140,143 / unet.py:119-140
  * w.r.t. the weight).  _supported(): the kernel can run the layer; _eligible(): it is also the faster

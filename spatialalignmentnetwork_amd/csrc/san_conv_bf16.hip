@@ -98,8 +98,13 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
 // staging each chunk's weights through LDS.  All four waves then fetch the same weights (4x the L1 traffic), but the
 // workgroup needs 49 KB of LDS instead of 92-156 KB, so three of them share a CU: measured +17..30 % for MB <= 4 with
 // up to 6 chunks (64->64 @160^2, 96->32 @320^2, 72->36 @160^2), -7..33 % for MB = 5 or deep K (288->288 @20^2).
-template <int MB, bool WD>
+// KS = 1: the same kernel as a 1x1 convolution (the alignment net's 1x1 layers, the data gradient of the transposed
+// convolutions): one K-step per 24-channel chunk (three channel groups at the centre tap + the zero group), always WD;
+// only the tile's interior is staged.
+template <int MB, bool WD, int KS>
 __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
+    constexpr int kSteps = KS == 3 ? 7 : 1;            // (shadows the 3x3 constant)
+    static_assert(KS == 3 || WD, "the 1x1 form reads its weights directly");
     constexpr int WCH = kSteps * MB * 3 * 64;          // uint4 per (cg, chunk) weight image
     constexpr int NWU = kSteps * MB * 3;               // ... = NWU wave-wide pieces (64 lanes x 16 B), one per (step, block, part)
     constexpr int WSL = (NWU + kT / 64 - 1) / (kT / 64); // pieces per wave: wave w moves pieces w, w + 4, ...
@@ -143,6 +148,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
             p = used ? kT + tid - chg * (kNP - kT) : 0;
         }
         const int pr = p / kHW_, pc = p - pr * kHW_;
+        if (KS == 1) used = used && pr >= 1 && pr <= kTH && pc >= 1 && pc <= kTW;       // no halo
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
         s_in[s] = used && gy >= 0 && gy < H && gx >= 0 && gx < W;
         s_goff[s] = s_in[s] ? gy * W + gx : 0;
@@ -202,10 +208,14 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     int tapoff[kSteps];
 #pragma unroll
     for (int s = 0; s < kSteps; ++s) {
-        const int g = min(4 * s + kg, 26);
-        const int tap = g / 3, chg = g - 3 * tap;
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        tapoff[s] = (ky * kHW_ + kx) * kPS + chg * 16;
+        if (KS == 3) {
+            const int g = min(4 * s + kg, 26);
+            const int tap = g / 3, chg = g - 3 * tap;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            tapoff[s] = (ky * kHW_ + kx) * kPS + chg * 16;
+        } else {
+            tapoff[s] = (kHW_ + 1) * kPS + min(kg, 2) * 16;        // centre tap; group 3 meets zero weights
+        }
     }
     int boff[4];                                        // block b: row 2 wave + (b >> 1), columns 16 (b & 1) ..
 #pragma unroll
@@ -216,6 +226,20 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     prefetch(0);
     for (int chunk = 0; chunk < a.chunks; ++chunk) {
         __syncthreads();
+        Frag wa[2][MB][3], xa[2][4][3];
+        const uint4* wsrc = a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane;      // (WD)
+        auto load_w = [&](int s, Frag (&wq)[MB][3]) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    if constexpr (WD) wq[m][p].u = wsrc[((s * a.nblkp + m) * 3 + p) * 64];
+                    else wq[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
+                }
+        };
+        // KS = 1 has one K-step per chunk: its weights do not depend on the staged tile, so they are fetched here,
+        // a whole staging phase ahead of their use
+        if constexpr (KS == 1) load_w(0, wa[0]);
         // ---- registers -> LDS: lazy activation, split into three bf16 parts, [pixel][channel] image.  Channels past
         // cin were loaded from a clamped (real) channel and meet zero weights: no select needed for them.
         const float* afc = lds_aff + (chunk & 1) * 48;
@@ -246,30 +270,25 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 if (u < NWU) *reinterpret_cast<u32x4*>(lds_w + u * 64 + lane) = wst[q];
             }
         }
-        __syncthreads();
-        if (chunk + 1 < a.chunks) prefetch(chunk + 1);
         // ---- 7 K-steps: (MB + 4) x 3 sixteen-byte operand reads feed 6 x MB x 4 MFMAs; the reads of step s+1
         // are issued before the MFMAs of step s (two operand sets, compile-time indices after unrolling)
-        Frag wa[2][MB][3], xa[2][4][3];
-        const uint4* wsrc = a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane;      // (WD)
-        auto load_step = [&](int s, Frag (&wq)[MB][3], Frag (&xq)[4][3]) {
-#pragma unroll
-            for (int m = 0; m < MB; ++m)
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    if constexpr (WD) wq[m][p].u = wsrc[((s * a.nblkp + m) * 3 + p) * 64];
-                    else wq[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
-                }
+        auto load_x = [&](int s, Frag (&xq)[4][3]) {
             const int to = tapoff[s];
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
         };
-        load_step(0, wa[0], xa[0]);
+        __syncthreads();
+        if (chunk + 1 < a.chunks) prefetch(chunk + 1);
+        if constexpr (KS == 3) load_w(0, wa[0]);
+        load_x(0, xa[0]);
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) {
-            if (s + 1 < kSteps) load_step(s + 1, wa[(s + 1) & 1], xa[(s + 1) & 1]);
+            if (s + 1 < kSteps) {
+                load_w(s + 1, wa[(s + 1) & 1]);
+                load_x(s + 1, xa[(s + 1) & 1]);
+            }
 #pragma unroll
             for (int pw = 0; pw < 3; ++pw)
 #pragma unroll
@@ -366,8 +385,10 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 // co = 16 blk + co16; group g = 4 step + kg -> tap = g / 3, ci = chunk 24 + (g % 3) 8 + i.
 // mode 0: w is the forward weight [cout][cin][3][3]; mode 2 (data gradient): (cout, cin) are those of the
 // data-gradient convolution and w is the forward weight of the layer being differentiated: value = w[ci][co][8 - tap].
+// ks = 1: one step per chunk, group kg < 3 -> channels chunk 24 + 8 kg + i of the single tap, kg = 3 zero;
+// mode 0: w[co][ci], mode 2: w[ci][co].
 __device__ __forceinline__ void pack_one(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t idx, int cout,
-                                         int cin, int nblkp, int mode) {
+                                         int cin, int nblkp, int mode, int ks) {
     const int i = (int)(idx & 7);
     const int lane = (int)((idx >> 3) & 63);
     size_t r = idx >> 9;
@@ -375,34 +396,38 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, uint16_t* 
     r /= 3;
     const int blk = (int)(r % nblkp);
     r /= nblkp;
-    const int step = (int)(r % kSteps);
-    const int chunk = (int)(r / kSteps);
+    const int steps = ks == 1 ? 1 : kSteps;
+    const int step = (int)(r % steps);
+    const int chunk = (int)(r / steps);
     const int co = blk * 16 + (lane & 15);
     const int g = 4 * step + (lane >> 4);
     const int tap = g / 3;
     const int ci = chunk * kCKC + (g - 3 * tap) * 8 + i;
     float v = 0.f;
-    if (tap < 9 && ci < cin && co < cout)
+    if (ks == 1) {
+        if (tap == 0 && ci < cin && co < cout) v = mode == 2 ? w[(size_t)ci * cout + co] : w[(size_t)co * cin + ci];
+    } else if (tap < 9 && ci < cin && co < cout) {
         v = mode == 2 ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
+    }
     uint32_t p1, p2, p3;
     split3(v, p1, p2, p3);
     packed[idx] = (uint16_t)(part == 0 ? p1 : (part == 1 ? p2 : p3));
 }
 
 __global__ void pack_bf16x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t total, int cout,
-                                   int cin, int nblkp, int mode) {
+                                   int cin, int nblkp, int mode, int ks) {
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-        pack_one(w, packed, idx, cout, cin, nblkp, mode);
+        pack_one(w, packed, idx, cout, cin, nblkp, mode, ks);
 }
 
-// batched: 8 x int64 per job = {w, packed, cout, cin, nblkp, 0, mode, total}
+// batched: 8 x int64 per job = {w, packed, cout, cin, nblkp, ks (0 = 3), mode, total}
 __global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
     const long long* j = jobs + 8 * (size_t)blockIdx.y;
     const float* w = reinterpret_cast<const float*>(j[0]);
     uint16_t* packed = reinterpret_cast<uint16_t*>(j[1]);
     const size_t total = (size_t)j[7];
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-        pack_one(w, packed, idx, (int)j[2], (int)j[3], (int)j[4], (int)j[6]);
+        pack_one(w, packed, idx, (int)j[2], (int)j[3], (int)j[4], (int)j[6], j[5] == 1 ? 1 : 3);
 }
 
 struct BPlan {
@@ -410,11 +435,11 @@ struct BPlan {
     size_t packed_elems;       // bf16 elements
 };
 
-BPlan bplan(int cout, int cin) {
+BPlan bplan(int cout, int cin, int ks = 3) {
     BPlan p{};
     p.nblkp = san_cdiv(cout, 16) + 4;
     p.chunks = san_cdiv(cin, kCKC);
-    p.packed_elems = (size_t)p.chunks * kSteps * p.nblkp * 3 * 64 * 8;
+    p.packed_elems = (size_t)p.chunks * (ks == 1 ? 1 : kSteps) * p.nblkp * 3 * 64 * 8;
     return p;
 }
 
@@ -437,12 +462,12 @@ int pick_mb(int cout, int tiles) {
     return best > 5 ? 5 : best;
 }
 
-template <int MB, bool WD>
+template <int MB, bool WD, int KS = 3>
 int launch_b(const BArgs& a, hipStream_t s) {
     constexpr size_t lds = 3 * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -450,7 +475,7 @@ int launch_b(const BArgs& a, hipStream_t s) {
         configured = true;
     }
     const int total = a.tiles_x * a.tiles_y * a.cgs * a.N;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD>), dim3(total), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS>), dim3(total), dim3(kT), lds, s, a);
     return SAN_OK;
 }
 
@@ -486,39 +511,48 @@ int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks) {
     return 1;
 }
 
-size_t san_conv_bf16x3_packed_bytes(int cout, int cin) { return bplan(cout, cin).packed_elems * 2; }
+size_t san_conv_bf16x3_packed_bytes_ks(int cout, int cin, int ks) { return bplan(cout, cin, ks).packed_elems * 2; }
+size_t san_conv_bf16x3_packed_bytes(int cout, int cin) { return san_conv_bf16x3_packed_bytes_ks(cout, cin, 3); }
 
 int san_conv_bf16x3_stat_tiles(int n, int h, int w) {
     (void)n;
     return san_cdiv(w, kTW) * san_cdiv(h, kTH) * 4;
 }
 
-int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mode, void* stream) {
+int san_conv_bf16x3_pack_ks(const float* w, void* packed, int cout, int cin, int mode, int ks, void* stream) {
     SAN_CHECK_ARG(w && packed, "null pointer");
-    SAN_CHECK_ARG(cout > 0 && cin > 0 && (mode == 0 || mode == 2), "bad dims / mode");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && (mode == 0 || mode == 2) && (ks == 1 || ks == 3), "bad dims / mode / ks");
     // mode 2: `cout`, `cin` are those of the DATA-GRADIENT convolution (cout = forward cin, cin = forward cout)
-    const BPlan p = bplan(cout, cin);
+    const BPlan p = bplan(cout, cin, ks);
     size_t blocks = (p.packed_elems + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)packed,
-                       p.packed_elems, cout, cin, p.nblkp, mode);
+                       p.packed_elems, cout, cin, p.nblkp, mode, ks);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
 
-int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int cout, int cin, int mode) {
+int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mode, void* stream) {
+    return san_conv_bf16x3_pack_ks(w, packed, cout, cin, mode, 3, stream);
+}
+
+int san_conv_bf16x3_pack_job_ks(long long* job8, const float* w, void* packed, int cout, int cin, int mode, int ks) {
     SAN_CHECK_ARG(job8 && w && packed, "null pointer");
-    SAN_CHECK_ARG(cout > 0 && cin > 0 && (mode == 0 || mode == 2), "bad dims / mode");
-    const BPlan p = bplan(cout, cin);
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && (mode == 0 || mode == 2) && (ks == 1 || ks == 3), "bad dims / mode / ks");
+    const BPlan p = bplan(cout, cin, ks);
     job8[0] = (long long)(uintptr_t)w;
     job8[1] = (long long)(uintptr_t)packed;
     job8[2] = cout;
     job8[3] = cin;
     job8[4] = p.nblkp;
-    job8[5] = 0;
+    job8[5] = ks;
     job8[6] = mode;
     job8[7] = (long long)p.packed_elems;
     return SAN_OK;
+}
+
+int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int cout, int cin, int mode) {
+    return san_conv_bf16x3_pack_job_ks(job8, w, packed, cout, cin, mode, 3);
 }
 
 int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* stream) {
@@ -528,14 +562,14 @@ int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* strea
     return SAN_OK;
 }
 
-int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
-                          float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff,
-                          int cout, float* part_stats, int n, int h, int w, void* stream) {
+static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                           float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
+                           float* part_stats, int n, int h, int w, int ks, void* stream) {
     SAN_CHECK_ARG(x && w_packed && y, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + cout <= y_ctot, "bad channel view");
     SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
-    const BPlan p = bplan(cout, cin);
+    const BPlan p = bplan(cout, cin, ks);
     BArgs a{};
     a.x = x;
     a.in_scale = in_scale;
@@ -563,20 +597,50 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const
     a.nblkp = p.nblkp;
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    int wd = (mb <= 4 && p.chunks <= 6 && h * w >= 1600) ? 1 : 0;        // see the WD note at the kernel
-    if (g_b16_wd >= 0) wd = g_b16_wd && mb <= 4;
-    switch (mb * 2 + wd) {
-        case 4: rc = launch_b<2, false>(a, s); break;
-        case 5: rc = launch_b<2, true>(a, s); break;
-        case 6: rc = launch_b<3, false>(a, s); break;
-        case 7: rc = launch_b<3, true>(a, s); break;
-        case 8: rc = launch_b<4, false>(a, s); break;
-        case 9: rc = launch_b<4, true>(a, s); break;
-        default: rc = launch_b<5, false>(a, s); break;
+    if (ks == 1) {
+        switch (mb) {
+            case 2: rc = launch_b<2, true, 1>(a, s); break;
+            case 3: rc = launch_b<3, true, 1>(a, s); break;
+            case 4: rc = launch_b<4, true, 1>(a, s); break;
+            default: rc = launch_b<5, true, 1>(a, s); break;
+        }
+    } else {
+        int wd = (mb <= 4 && p.chunks <= 6 && h * w >= 1600) ? 1 : 0;        // see the WD note at the kernel
+        if (g_b16_wd >= 0) wd = g_b16_wd && mb <= 4;
+        switch (mb * 2 + wd) {
+            case 4: rc = launch_b<2, false>(a, s); break;
+            case 5: rc = launch_b<2, true>(a, s); break;
+            case 6: rc = launch_b<3, false>(a, s); break;
+            case 7: rc = launch_b<3, true>(a, s); break;
+            case 8: rc = launch_b<4, false>(a, s); break;
+            case 9: rc = launch_b<4, true>(a, s); break;
+            default: rc = launch_b<5, false>(a, s); break;
+        }
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
     return SAN_OK;
+}
+
+int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                          float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff,
+                          int cout, float* part_stats, int n, int h, int w, void* stream) {
+    return conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout,
+                           part_stats, n, h, w, 3, stream);
+}
+
+// 1x1 form: weights packed with san_conv_bf16x3_pack_ks(..., ks = 1); otherwise the contract of san_conv2d_bf16x3_fwd
+int san_conv1x1_bf16x3_eligible(int cin, int cout, int h, int w) {
+    if (cin < 16 || cout < 16) return 0;
+    if (h < 8 || w < 16) return 0;
+    return 1;
+}
+
+int san_conv1x1_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                           float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff,
+                           int cout, float* part_stats, int n, int h, int w, void* stream) {
+    return conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout,
+                           part_stats, n, h, w, 1, stream);
 }
 
 }  // extern "C"

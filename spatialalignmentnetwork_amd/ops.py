@@ -409,20 +409,21 @@ class _PackRegistryBf16(_PackRegistry):
             cout, cin = w.shape[1], w.shape[0]          # the data-gradient conv maps forward cout -> forward cin
         else:
             cout, cin = w.shape[0], w.shape[1]
-        nbytes = lib().query("san_conv_bf16x3_packed_bytes", cout, cin)
-        return (cout, cin, 3), torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+        ks = int(w.shape[2])
+        nbytes = lib().query("san_conv_bf16x3_packed_bytes_ks", cout, cin, ks)
+        return (cout, cin, ks), torch.empty(nbytes, device=w.device, dtype=torch.uint8)
 
     def _fill_job(self, row, j):
-        cout, cin, _ = j["dims"]
-        lib().call("san_conv_bf16x3_pack_job", ctypes.c_void_p(ctypes.addressof(row)), ctypes.c_void_p(j["ptr"]),
-                   _p(j["packed"]), cout, cin, j["mode"])
+        cout, cin, ks = j["dims"]
+        lib().call("san_conv_bf16x3_pack_job_ks", ctypes.c_void_p(ctypes.addressof(row)), ctypes.c_void_p(j["ptr"]),
+                   _p(j["packed"]), cout, cin, j["mode"], ks)
 
     def _batch(self):
         lib().call("san_conv_bf16x3_pack_batch", _p(self.table), len(self.order), _stream())
 
     def _pack_one(self, job, w):
-        cout, cin, _ = job["dims"]
-        lib().call("san_conv_bf16x3_pack", _p(w.detach()), _p(job["packed"]), cout, cin, job["mode"], _stream())
+        cout, cin, ks = job["dims"]
+        lib().call("san_conv_bf16x3_pack_ks", _p(w.detach()), _p(job["packed"]), cout, cin, job["mode"], ks, _stream())
         job["version"] = w._version
 
 
@@ -431,7 +432,11 @@ USE_BF16X3 = [os.environ.get("SAN_NO_BF16X3", "0") != "1"]
 
 
 def bf16x3_eligible(cin: int, cout: int, h: int, w: int, ks: int) -> bool:
-    return USE_BF16X3[0] and bool(lib().query("san_conv_bf16x3_eligible", cin, cout, h, w, ks))
+    if not USE_BF16X3[0]:
+        return False
+    if ks == 1:
+        return bool(lib().query("san_conv1x1_bf16x3_eligible", cin, cout, h, w))
+    return bool(lib().query("san_conv_bf16x3_eligible", cin, cout, h, w, ks))
 
 
 def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
@@ -456,7 +461,9 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
             part = arena.get("part" + tag, (n, cout, lib().query("san_conv_bf16x3_stat_tiles", n, h, w), 3), x.buf.device)
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
                  y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
-        _timed("conv3x3_bf16x3", 2.0 * n * h * w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_bf16x3_fwd", *bargs))
+        fn = "san_conv2d_bf16x3_fwd" if ks == 3 else "san_conv1x1_bf16x3_fwd"
+        _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
+               lambda: lib().call(fn, *bargs))
         return part
     wp = packed_weight(weight)
     if stats:
@@ -656,8 +663,9 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
         wp = PACKS16.get(weight, 2)
         bargs = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
                  _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), dy.n, dy.h, dy.w, _stream())
-        _timed("conv3x3_bf16x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * 9, "FLOP",
-               lambda: lib().call("san_conv2d_bf16x3_fwd", *bargs))
+        fn = "san_conv2d_bf16x3_fwd" if ks == 3 else "san_conv1x1_bf16x3_fwd"
+        _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
+               lambda: lib().call(fn, *bargs))
         return
     wp = packed_weight_dgrad(weight)
     args = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),

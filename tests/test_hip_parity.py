@@ -702,6 +702,38 @@ def _conv_bf16x3_checks(ops, n, cin, cout, h, w):
     assert rel_err(dx.cpu(), a64.grad.float()) < 3e-6
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 64, 16, 32), (1, 576, 288, 10, 20), (2, 72, 36, 40, 40), (1, 32, 64, 33, 50),
+                                            (2, 20, 50, 9, 17), (1, 144, 72, 24, 40)])
+def test_conv1x1_bf16x3_vs_float64(S, n, cin, cout, h, w):
+    """The bf16x3 kernel as a 1x1 convolution (alignment-net 1x1 layers, data gradient of the transposed convolutions):
+    forward with lazy affine + LeakyReLU input through a channel view, bias, fused statistics, and the 1x1 data
+    gradient, against float64.  Bars as for the 3x3 form: 3e-6 on outputs, 2e-5 on merged statistics."""
+    ops = S.ops
+    assert ops.bf16x3_eligible(cin, cout, h, w, 1)
+    x = philox("c1.x", (n, cin + 3, h, w))
+    wt = philox("c1.w", (cout, cin, 1, 1)) * (1.0 / cin ** 0.5)
+    sc, sh = philox("c1.sc", (n, cin + 3), lo=0.5, hi=1.5), philox("c1.sh", (n, cin + 3))
+    b = philox("c1.b", (cout,))
+    y = torch.empty((n, cout + 2, h, w), device=DEV)
+    part = ops.conv2d(ops.Act(g(x), 3, cin, g(sc), g(sh), 0.2), g(wt), g(b), ops.Act(y, 2, cout, None, None, 1.0), stats=True)
+    act = torch.nn.functional.leaky_relu(x[:, 3:] * sc[:, 3:, None, None] + sh[:, 3:, None, None], 0.2).double()
+    ref = torch.nn.functional.conv2d(act, wt.double(), b.double())
+    assert rel_err(y[:, 2:].cpu(), ref.float()) < 3e-6
+    p = part.cpu().double()
+    cnt, mean_t, m2_t = p[..., 0], p[..., 1], p[..., 2]
+    tot = cnt.sum(-1)
+    assert torch.all(tot == h * w)
+    mean = (cnt * mean_t).sum(-1) / tot
+    m2 = (m2_t + cnt * (mean_t - mean[..., None]) ** 2).sum(-1)
+    assert (mean - ref.mean(dim=(2, 3))).abs().max() < 2e-5
+    assert rel_err((m2 / tot).float(), ref.var(dim=(2, 3), unbiased=False).float()) < 2e-5
+    dy = philox("c1.dy", (n, cout, h, w))
+    dx = torch.empty((n, cin, h, w), device=DEV)
+    ops.conv2d_dgrad(ops.full(g(dy)), g(wt), ops.full(dx))
+    ref_dx = torch.einsum("nohw,oi->nihw", dy.double(), wt.double()[:, :, 0, 0])
+    assert rel_err(dx.cpu(), ref_dx.float()) < 3e-6
+
+
 @pytest.mark.parametrize("mode", [1, 0], ids=["direct", "split"])
 @pytest.mark.parametrize("n,cin,cout,h,w", [(2, 72, 72, 20, 44), (2, 36, 72, 40, 40), (1, 96, 32, 33, 52), (2, 144, 144, 24, 24),
                                             (4, 288, 144, 16, 16), (8, 40, 50, 14, 12), (2, 32, 48, 31, 31), (2, 64, 64, 30, 46),
