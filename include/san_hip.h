@@ -370,6 +370,16 @@ int san_conv1x1_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
                            float* y, int y_ctot, int y_coff, int cout, float* part_stats,
                            int n, int h, int w, void* stream);
 
+/* ConvTranspose2d 2x2 stride 2 (varnet.py:159-192) on the same kernel: 1x1 convolution to 4*cout virtual
+ * channels + pixel shuffle in the epilogue.  x [n, x_ctot, h, w] -> y [n, y_ctot, 2h, 2w] (8-byte aligned);
+ * weights: the [Cin, Cout, 2, 2] tensor packed with san_conv_bf16x3_pack_ks(w, packed, 4*cout, cin, 2, 1);
+ * part_stats [n, cout, 4 * san_conv_bf16x3_stat_tiles(n, h, w), 3] or NULL. */
+int san_tconv2x2_bf16x3_eligible(int cin, int cout, int h, int w);
+int san_tconv2x2_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
+                            const float* in_scale, const float* in_shift, float in_slope,
+                            const void* w_packed, float* y, int y_ctot, int y_coff, int cout,
+                            float* part_stats, int n, int h, int w, void* stream);
+
 /* 3x3 weight gradient on the bf16 matrix cores, fp32-level accuracy (csrc/san_wgrad_bf16.hip): same
  * contract as san_conv2d_wgrad for ks = 3 (backward of F.conv2d at varnet.py:140,143 / unet.py:119-140
  * w.r.t. the weight).  _supported(): the kernel can run the layer; _eligible(): it is also the faster

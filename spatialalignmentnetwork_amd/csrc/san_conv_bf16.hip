@@ -50,6 +50,7 @@ struct BArgs {
     const float* x;
     const float* in_scale;
     const float* in_shift;
+    int shuffle;               // 1: transposed convolution 2x2 s2 = 1x1 conv to 4 cout virtual channels + pixel shuffle (KS = 1)
     const uint4* wp;           // packed weights [chunk][step][block of 16 couts][part][64 lanes] x 16 B
     const float* bias;
     float* y;
@@ -358,12 +359,34 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 s2 += san_dpp_get<0x140, 0xf>(s2);
                 const int co = cbase + 16 * m + r;
                 if (nn == 0 && co < a.cout) {
-                    float* o = a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
+                    // transposed convolution: the 4 virtual channels of a real channel are 4 more statistics tiles
+                    float* o = a.shuffle ? a.part + ((size_t)(n * (a.cout >> 2) + (co >> 2)) * (tiles * 4) + (tile * 4 + wave) * 4 + (co & 3)) * 3
+                                         : a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
                     o[0] = cnt;
                     o[1] = cnt > 0.f ? pilot + s1 * inv : 0.f;
                     o[2] = cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f;
                 }
             }
+    }
+    if (a.shuffle) {
+        // virtual channel 4 c + 2 dy + dx of input pixel (y, x) is output pixel (2 y + dy, 2 x + dx) of channel c; a lane
+        // holds r = 0..3 = the four positions of one real channel: two 8-byte stores, 128 contiguous bytes per 16 lanes
+        typedef float fl2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int co = cbase + 16 * m;
+            if (co < a.cout) {
+                float* dst = a.y + (size_t)(n * a.y_ctot + a.y_coff + (co >> 2)) * (4 * (size_t)HWp);
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (valid[b]) {
+                        float* q = dst + (size_t)(2 * oy[b]) * (2 * W) + 2 * ox[b];
+                        *reinterpret_cast<fl2v*>(q) = fl2v{acc[m][b][0], acc[m][b][1]};
+                        *reinterpret_cast<fl2v*>(q + 2 * W) = fl2v{acc[m][b][2], acc[m][b][3]};
+                    }
+            }
+        }
+        return;
     }
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -564,11 +587,12 @@ int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* strea
 
 static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
                            float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
-                           float* part_stats, int n, int h, int w, int ks, void* stream) {
+                           float* part_stats, int n, int h, int w, int ks, void* stream, int shuffle = 0) {
     SAN_CHECK_ARG(x && w_packed && y, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
-    SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + cout <= y_ctot, "bad channel view");
+    SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + (shuffle ? cout / 4 : cout) <= y_ctot, "bad channel view");
     SAN_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "in_scale/in_shift must come together");
+    SAN_CHECK_ARG(!shuffle || (ks == 1 && cout % 4 == 0 && (((uintptr_t)y) & 7) == 0), "transposed form: 1x1, 4 virtual channels per channel, 8-byte aligned output");
     const BPlan p = bplan(cout, cin, ks);
     BArgs a{};
     a.x = x;
@@ -576,6 +600,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.in_shift = in_shift;
     a.in_slope = in_slope;
     a.wp = (const uint4*)w_packed;
+    a.shuffle = shuffle;
     a.bias = bias;
     a.y = y;
     a.part = part_stats;
@@ -641,6 +666,19 @@ int san_conv1x1_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, cons
                            int cout, float* part_stats, int n, int h, int w, void* stream) {
     return conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout,
                            part_stats, n, h, w, 1, stream);
+}
+
+// ConvTranspose2d(2x2, stride 2, no bias) (varnet.py:159-192) on the same kernel: a 1x1 convolution to 4 cout virtual
+// channels whose epilogue writes the pixel shuffle.  x [n, x_ctot, h, w] -> y [n, y_ctot, 2h, 2w]; weights: the
+// [Cin, Cout, 2, 2] tensor packed with san_conv_bf16x3_pack_ks(w, packed, 4 * cout, cin, mode 2, ks 1);
+// part_stats [n, cout, 4 * san_conv_bf16x3_stat_tiles(n, h, w), 3].
+int san_tconv2x2_bf16x3_eligible(int cin, int cout, int h, int w) { return san_conv1x1_bf16x3_eligible(cin, 4 * cout, h, w); }
+
+int san_tconv2x2_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                            float in_slope, const void* w_packed, float* y, int y_ctot, int y_coff, int cout,
+                            float* part_stats, int n, int h, int w, void* stream) {
+    return conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, nullptr, y, y_ctot, y_coff,
+                           4 * cout, part_stats, n, h, w, 1, stream, 1);
 }
 
 }  // extern "C"

@@ -405,6 +405,9 @@ class _PackRegistryBf16(_PackRegistry):
     mode 2 data gradient; dims = (cout, cin) of the convolution that will run."""
 
     def _alloc(self, w: torch.Tensor, mode: int):
+        if mode == 3:                                   # ConvTranspose2d [Cin, Cout, 2, 2] as a 1x1 conv to 4 Cout channels
+            return (4 * w.shape[1], w.shape[0], 1), torch.empty(
+                lib().query("san_conv_bf16x3_packed_bytes_ks", 4 * w.shape[1], w.shape[0], 1), device=w.device, dtype=torch.uint8)
         if mode == 2:
             cout, cin = w.shape[1], w.shape[0]          # the data-gradient conv maps forward cout -> forward cin
         else:
@@ -416,14 +419,15 @@ class _PackRegistryBf16(_PackRegistry):
     def _fill_job(self, row, j):
         cout, cin, ks = j["dims"]
         lib().call("san_conv_bf16x3_pack_job_ks", ctypes.c_void_p(ctypes.addressof(row)), ctypes.c_void_p(j["ptr"]),
-                   _p(j["packed"]), cout, cin, j["mode"], ks)
+                   _p(j["packed"]), cout, cin, 2 if j["mode"] == 3 else j["mode"], ks)
 
     def _batch(self):
         lib().call("san_conv_bf16x3_pack_batch", _p(self.table), len(self.order), _stream())
 
     def _pack_one(self, job, w):
         cout, cin, ks = job["dims"]
-        lib().call("san_conv_bf16x3_pack_ks", _p(w.detach()), _p(job["packed"]), cout, cin, job["mode"], ks, _stream())
+        lib().call("san_conv_bf16x3_pack_ks", _p(w.detach()), _p(job["packed"]), cout, cin, 2 if job["mode"] == 3 else job["mode"],
+                   ks, _stream())
         job["version"] = w._version
 
 
@@ -481,8 +485,17 @@ def tconv2x2(x: Act, weight: torch.Tensor, y: Act, stats: bool = False, arena: A
     cin, cout = weight.shape[0], weight.shape[1]
     assert cin == x.c and cout == y.c
     assert y.h == 2 * x.h and y.w == 2 * x.w
-    wp = packed_weight(weight, transposed=True)
     part = None
+    if USE_BF16X3[0] and lib().query("san_tconv2x2_bf16x3_eligible", cin, cout, x.h, x.w) and y.buf.data_ptr() % 8 == 0:
+        wp = PACKS16.get(weight, 3)
+        if stats:
+            tiles = 4 * lib().query("san_conv_bf16x3_stat_tiles", x.n, x.h, x.w)
+            part = arena.get("tpart" + tag, (x.n, cout, tiles, 3), x.buf.device)
+        bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(y.buf), y.ctot, y.coff,
+                 cout, _p(part), x.n, x.h, x.w, _stream())
+        _timed("tconv2x2_bf16x3", 2.0 * x.n * x.h * x.w * 4 * cout * cin, "FLOP", lambda: lib().call("san_tconv2x2_bf16x3_fwd", *bargs))
+        return part
+    wp = packed_weight(weight, transposed=True)
     if stats:
         tiles = lib().query("san_tconv_stat_tiles", x.n, x.h, x.w, cout)
         part = arena.get("tpart" + tag, (x.n, cout, tiles, 3), x.buf.device)

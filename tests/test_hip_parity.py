@@ -149,7 +149,8 @@ def test_conv_blocks_golden(S, ops_golden):
     assert rel_err(y.cpu(), as_t(ops_golden["tconvblock"])) < 1e-5
 
 
-@pytest.mark.parametrize("cin,cout,h,w", [(36, 18, 20, 20), (288, 144, 20, 20), (8, 4, 16, 24), (5, 3, 7, 9)])
+@pytest.mark.parametrize("cin,cout,h,w", [(36, 18, 20, 20), (288, 144, 20, 20), (8, 4, 16, 24), (5, 3, 7, 9), (72, 36, 33, 50),
+                                          (16, 8, 16, 24), (144, 72, 9, 17)])
 def test_tconv_vs_torch(S, cin, cout, h, w):
     n = 2
     x = philox("tc.x", (n, cin, h, w))
