@@ -757,20 +757,9 @@ def unshuffle2(x: Act, y: Act) -> None:
     lib().call("san_unshuffle2_fwd", _p(x.buf), x.ctot, x.coff, _p(y.buf), y.ctot, y.coff, x.n, x.c, y.h, y.w, _stream())
 
 
-def plane_dot_sums(g: Act, y: Act):
-    """(sum u, sum u*yh) per (n, c) with yh = y's lazy affine value and u = g * lrelu'(yh): [n, c] each."""
-    assert g.c == y.c
-    hw = y.h * y.w
-    tiles = lib().query("san_bwd_stat_tiles", hw)
-    part = torch.empty((y.n, y.c, tiles, 2), device=y.buf.device, dtype=torch.float32)
-    lib().call("san_plane_dot_stats", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
-               float(y.slope), _p(part), y.n, y.c, hw, _stream())
-    s = part.double().sum(dim=2)
-    return s[..., 0], s[..., 1]
-
-
 def plane_dot_part(g: Act, y: Act, tag: str = "", arena: Arena = GLOBAL_ARENA) -> torch.Tensor:
-    """The raw chunk sums [n, c, tiles, 2] of (u, u*yh) (see plane_dot_sums) for the one-launch finalisations."""
+    """The chunk sums [n, c, tiles, 2] of (u, u*yh) per plane, with yh = y's lazy affine value and u = g * lrelu'(yh):
+    the two plane reductions every normalisation backward needs; consumed by the one-launch finalisations."""
     assert g.c == y.c
     hw = y.h * y.w
     tiles = lib().query("san_bwd_stat_tiles", hw)
