@@ -17,9 +17,10 @@ Slices are independent, so N GPUs run N shards with no data-path collective
 Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max
 rank time) that also carries
   roofline      : the dominant kernel (by GPU time inside the timed region),
-                  algorithmic work / HIP-event time of its launches (every 7th
-                  launch of a kernel family is bracketed: an event pair around
-                  each of ~1,700 launches per step costs ~6 % of the step);
+                  algorithmic work / HIP-event time of its launches (every 29th
+                  launch of a kernel family is bracketed, run alone on the GPU:
+                  an event pair around each of ~1,700 launches per step costs
+                  ~6 % of the step and would serialise the two streams);
   roofline_fft_dc: the fused FFT + data-consistency kernels against HBM;
   cpu_baseline  : the CPU oracle (PyTorch CPU restatement of the reference) timed
                   on this box's host cores on a bounded sample (rank 0, N=1 only).
@@ -254,7 +255,7 @@ def main():
                 d = tot[key]
                 if d["sampled_launches"] == 0:
                     continue
-                # rate over the bracketed launches (every 7th of the family); "ms" is that rate applied to all launches
+                # rate over the bracketed launches (every 29th of the family); "ms" is that rate applied to all launches
                 sec = d["ms"] * 1e-3
                 extra = {}
                 if key in ("conv3x3_bf16x3", "wgrad3x3_bf16x3"):

@@ -133,7 +133,8 @@ class CSModel(BaseModel):
         opts = [self.optim_R] + ([self.optim_T] if train_T else [])
         for o in opts:
             o.zero_grad()                       # one memset of the flat gradient buffer per network
-        self.backward(train_T)
+        with ops.wgrad_overlap():               # weight gradients on a side stream, joined before the exchange / step
+            self.backward(train_T)
         dist = _active_dist()
         scale = 1.0
         if dist is not None:                    # data parallel: one in-place RCCL all-reduce per network;

@@ -25,11 +25,12 @@ class KernelTimer:
     C-ABI call; totals() needs a prior device synchronisation.
 
     An event pair costs a few microseconds and keeps neighbouring kernels from
-    overlapping, so only every ``stride``-th launch of a family is bracketed (a
-    stride co-prime with the per-cascade layer counts walks through all layers);
+    overlapping (and, inside wgrad_overlap, joins the two streams), so only every
+    ``stride``-th launch of a family is bracketed (a prime stride walks through
+    all layers of the periodic cascade structure);
     every launch is still counted, and totals() scales the sampled time up."""
 
-    def __init__(self, stride: int = 7):
+    def __init__(self, stride: int = 29):
         self.stride = max(1, int(stride))
         self.recs = []
         self.seen = {}
@@ -43,9 +44,18 @@ class KernelTimer:
             return
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
+        # inside wgrad_overlap two streams share the GPU: a bracketed launch is run alone (the other stream is joined
+        # before and held until after it), so that the time is the kernel's own and not the contention's
+        side, cur, other = _WG["stream"], None, None
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            other = _WG["main"] if cur == side else side
+            cur.wait_stream(other)
         e0.record()
         fn()
         e1.record()
+        if other is not None:
+            other.wait_stream(cur)
         self.recs.append((name, work, e0, e1))
 
     def totals(self):
@@ -113,13 +123,16 @@ def _creal(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
 class Arena:
     def __init__(self):
         self._bufs: Dict[Tuple, torch.Tensor] = {}
+        self._retired = []
 
-    def get(self, name: str, shape, device, dtype=torch.float32, zero: bool = False) -> torch.Tensor:
+    def get(self, name: str, shape, device, dtype=torch.float32, zero: bool = False, _no_wait: bool = False) -> torch.Tensor:
         key = (name, tuple(int(s) for s in shape), str(device), dtype)
         t = self._bufs.get(key)
         if t is None:
             t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
             self._bufs[key] = t
+        elif not _no_wait and _WG["busy"]:
+            _wait_if_busy(t)                    # a side-stream weight gradient may still be reading it (wgrad_overlap)
         return t
 
     def scratch(self, name: str, nbytes: int, device) -> torch.Tensor:
@@ -127,6 +140,8 @@ class Arena:
         key = (name, "scratch", str(device))
         t = self._bufs.get(key)
         if t is None or t.numel() < nbytes:
+            if t is not None:
+                self._retired.append(t)         # a side-stream kernel may still be using it: never hand its memory back
             t = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
             self._bufs[key] = t
         return t
@@ -688,16 +703,97 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
            lambda: lib().call("san_conv2d_fwd", *args))
 
 
+# ---------------------------------------------------------------------------
+# Weight gradients on a side stream.  Nothing in the backward chain consumes a weight gradient (only the optimiser
+# does), so inside ``with wgrad_overlap():`` every conv2d_wgrad* call is enqueued on a second HIP stream after the
+# work that produced its operands, and the main stream goes straight on to the data gradient and the HBM-bound
+# activation-backward kernels, which share the CUs with the matrix-bound weight gradient.  Hazards:
+#   * dy buffers are arena temporaries the main stream rewrites a layer later -> wgrad_dy_buffer() hands out up to
+#     four rotating copies and makes the main stream wait only when all of them still have a reader in flight;
+#     Arena.get() applies the same wait to any other buffer with a pending side-stream reader;
+#   * allocator-owned operands get record_stream();
+#   * leaving the context joins the side stream back into the main one (before the all-reduce / optimiser).
+# ---------------------------------------------------------------------------
+_WG = {"stream": None, "main": None, "pool": {}, "busy": {}}
+WGRAD_OVERLAP = [os.environ.get("SAN_NO_WGRAD_OVERLAP", "0") != "1"]
+
+
+class wgrad_overlap:
+    def __enter__(self):
+        if WGRAD_OVERLAP[0]:
+            dev = torch.cuda.current_device()
+            if dev not in _WG["pool"]:
+                _WG["pool"][dev] = torch.cuda.Stream(device=dev)
+            _WG["stream"] = _WG["pool"][dev]
+            _WG["main"] = torch.cuda.current_stream()
+        return self
+
+    def __exit__(self, *exc):
+        side = _WG["stream"]
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        _WG["stream"] = None
+        _WG["main"] = None
+        _WG["busy"].clear()
+        return False
+
+
+def _wait_if_busy(t: torch.Tensor) -> None:
+    ev = _WG["busy"].pop(t.data_ptr(), None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
+def wgrad_dy_buffer(name: str, shape, device, arena: Arena = GLOBAL_ARENA) -> torch.Tensor:
+    """An arena temporary that a weight gradient will read: the plain arena buffer outside wgrad_overlap, otherwise
+    one of up to four rotating copies without a side-stream reader in flight (else the oldest, after waiting)."""
+    if _WG["stream"] is None:
+        return arena.get(name, shape, device)
+    first = None
+    for k in range(4):
+        t = arena.get(name if k == 0 else f"{name}#{k}", shape, device, _no_wait=True)
+        ev = _WG["busy"].get(t.data_ptr())
+        if ev is None or ev.query():
+            _WG["busy"].pop(t.data_ptr(), None)
+            return t
+        if first is None:
+            first = t
+    _wait_if_busy(first)
+    return first
+
+
+def _on_side_stream(dy: Act, x: Act, fn) -> None:
+    side = _WG["stream"]
+    if side is None:
+        fn()
+        return
+    main = torch.cuda.current_stream()
+    side.wait_stream(main)                      # the operands' producers are queued on main up to here
+    with torch.cuda.stream(side):
+        fn()
+        ev = torch.cuda.Event()
+        ev.record(side)
+    _WG["busy"][dy.buf.data_ptr()] = ev
+    dy.buf.record_stream(side)
+    x.buf.record_stream(side)
+
+
 def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
+    """dw [cout, cin, ks, ks] (+)= correlation of dy with the lazily activated forward input x (on the side stream
+    inside ``wgrad_overlap``)."""
+    _on_side_stream(dy, x, lambda: _conv2d_wgrad(x, dy, dw, accumulate, arena))
+
+
+def _conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
     """dw [cout, cin, ks, ks] (+)= correlation of dy with the lazily activated forward input x."""
     cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
     assert x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
     flops = 2.0 * x.n * x.h * x.w * cout * cin * ks * ks
     if USE_BF16X3[0] and lib().query("san_conv_wgrad_bf16x3_eligible", x.n, x.h, x.w, cin, cout, ks):
-        conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena)
+        _conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena)
         return
     if ks == 1 and wgrad1x1_bf16x3_ok(x, dy):
-        conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena)
+        _conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena)
         return
     P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout, ks)
     partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
@@ -707,6 +803,10 @@ def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, ar
 
 
 def conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
+    _on_side_stream(dy, x, lambda: _conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena))
+
+
+def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
     """The 3x3 weight gradient on the bf16 matrix cores (three-way split operands, fp32-level accuracy;
     csrc/san_wgrad_bf16.hip).  conv2d_wgrad dispatches here where san_conv_wgrad_bf16x3_eligible says so."""
     cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
@@ -727,6 +827,11 @@ def wgrad1x1_bf16x3_ok(x: Act, dy: Act) -> bool:
 
 def conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
                            transposed: bool = False) -> None:
+    _on_side_stream(dy, x, lambda: _conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena, transposed))
+
+
+def _conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
+                            transposed: bool = False) -> None:
     """The 1x1 weight gradient on the bf16 matrix cores (csrc/san_wgrad_bf16.hip, wgrad1x1_bf16x3_kernel).
     transposed: dw is laid out [cin, cout(, ...)] -- a ConvTranspose2d weight [Cin, Cout, 2, 2] seen as [Cin, 4 Cout]."""
     cin, cout = x.c, dy.c

@@ -58,12 +58,12 @@ class ConvBlock(nn.Module):
         if g_in is given, writes dL/d(T(x)) (gradient wrt the lazily activated block input)."""
         n, h, w, dev = x.n, x.h, x.w, x.buf.device
         wa, wb = self.layers[0].weight, self.layers[3].weight
-        dyb = Act(ARENA.get("bwd.dy", (n, out.c, h, w), dev), 0, out.c)
+        dyb = Act(ops.wgrad_dy_buffer("bwd.dy", (n, out.c, h, w), dev, ARENA), 0, out.c)
         ops.act_bwd(g_out, out, dyb, instance_norm=True)
         ops.conv2d_wgrad(mid, dyb, _grad_of(wb), accumulate=True)
         g_mid = Act(ARENA.get("bwd.gmid", (n, mid.c, h, w), dev), 0, mid.c)
         ops.conv2d_dgrad(dyb, wb, g_mid)
-        dya = Act(ARENA.get("bwd.dy", (n, mid.c, h, w), dev), 0, mid.c)
+        dya = Act(ops.wgrad_dy_buffer("bwd.dy", (n, mid.c, h, w), dev, ARENA), 0, mid.c)
         ops.act_bwd(g_mid, mid, dya, instance_norm=True)
         ops.conv2d_wgrad(x, dya, _grad_of(wa), accumulate=True)
         if g_in is not None:
@@ -106,7 +106,7 @@ class TransposeConvBlock(nn.Module):
         n, h, w, dev = x.n, x.h, x.w, x.buf.device
         dyt = Act(ARENA.get("bwd.dyt", (n, cout, 2 * h, 2 * w), dev), 0, cout)
         ops.act_bwd(g_out, out, dyt, instance_norm=True)
-        dyp = Act(ARENA.get("bwd.dyp", (n, 4 * cout, h, w), dev), 0, 4 * cout)
+        dyp = Act(ops.wgrad_dy_buffer("bwd.dyp", (n, 4 * cout, h, w), dev, ARENA), 0, 4 * cout)
         ops.unshuffle2(dyt, dyp)
         wv = _view_cached(wt, (cin, 4 * cout, 1, 1))
         # dL/dx[ci] = sum_c' Wv[ci, c'] dy'[c']  == forward 1x1 conv with weight [cout'=Cin, cin'=4Cout]
@@ -116,7 +116,7 @@ class TransposeConvBlock(nn.Module):
             ops.conv2d_wgrad1x1_bf16x3(x, dyp, _grad_of(wt), accumulate=True, transposed=True)
         else:
             dwv = ARENA.get("bwd.dwv", (4 * cout, cin, 1, 1), dev)
-            ops.conv2d_wgrad(x, dyp, dwv, accumulate=False)
+            ops._conv2d_wgrad(x, dyp, dwv, accumulate=False)      # in line: its result is consumed right here
             _grad_of(wt).add_(dwv.view(4 * cout, cin).t().reshape(cin, cout, 2, 2))
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
@@ -347,7 +347,7 @@ class NormUnet(nn.Module):
         g_out = g_out.contiguous()
         isd = (1.0 / std).contiguous()
         part_b = ops.plane_dot_part(ops.full(g_out), Act(out_planar, 0, 2, isd, (-mean * isd).contiguous(), 1.0), "nu.b")
-        g_u = ARENA.get("bwd.g_u", (b, 2, h, w), dev)
+        g_u = ops.wgrad_dy_buffer("bwd.g_u", (b, 2, h, w), dev, ARENA)
         ops.apply(Act(g_out, 0, 2, std, ARENA.get("bwd.zero_sh", tuple(std.shape), dev, zero=True), 1.0), ops.full(g_u))
         g_xh = self.unet.run_bwd(g_u, key)                         # [B, 2 or 3, H, W]
         part_a = ops.plane_dot_part(Act(g_xh, 0, 2), xin.view(0, 2), "nu.a")
