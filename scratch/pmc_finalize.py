@@ -5,7 +5,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 raw = json.load(open(os.path.join(R, "gpurun_out", "r01_pmc_traffic_raw.json")))
 old = json.load(open(os.path.join(R, "profiles", "r01_pmc_traffic.json")))
 F16, F4, WF = old["fetch_factor"]["16B_or_8B_per_lane"], old["fetch_factor"]["4B_per_lane"], old["write_factor"]
-width = {"conv_mfma_3x3": "4B_per_lane", "conv_mfma_1x1": "4B_per_lane", "conv_bf16x3": "4B_per_lane"}
+width = {"conv_mfma_3x3": "4B_per_lane", "conv_mfma_1x1": "4B_per_lane", "conv_bf16x3": "4B_per_lane", "conv_bf16x3_1x1": "4B_per_lane"}
 kern = {}
 for k, v in raw.items():
     if k.startswith("cal_") or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:

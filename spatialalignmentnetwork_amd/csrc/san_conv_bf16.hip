@@ -13,15 +13,17 @@
 //   k = (tap, input channel), consumed in GROUPS of 8 consecutive channels of one tap: a lane's
 //   8 bf16 operand elements are 8 channels of one pixel, i.e. one 16-byte LDS read from a
 //   [pixel][channel] image of the staged input tile.
-// Used for the layers whose channel counts fit 16-wide tiles (cout >= 32): U-Net levels 2-4 and the
-// alignment network; 18/36-channel layers stay on the fp32 4x4x1 kernel (san_conv_mfma.hip).
+// Used for every 3x3 layer from 18 -> 18 channels upwards (san_conv_bf16x3_eligible) and, as KS = 1, for the 1x1
+// convolutions, the 2x2 stride-2 transposed convolutions (1x1 to 4 cout virtual channels + pixel shuffle in the
+// epilogue) and their data gradients; the 2-/3-/8-channel layers stay on the fp32 4x4x1 kernel (san_conv_mfma.hip).
 //
 // Workgroup = 4 waves, output tile 32 x 8 pixels, MB blocks of 16 output channels.  Wave w owns
 // rows 2w, 2w+1 = four 16-pixel blocks and all MB channel blocks: 4*MB accumulator tiles.  Input
 // channels are staged 24 at a time (three groups of 8): 3 parts x 340 halo pixels x 48 B in LDS
 // (pixel stride 48 B = 3 x 16 B: conflict-free b128 reads and writes), next to the chunk's packed
 // weights, which are stored in HBM exactly as the lanes read them.  A chunk = 27 (tap, group) pairs =
-// 7 K-steps of 4 groups (one zero group of padding).
+// 7 K-steps of 4 groups (one zero group of padding).  In the weights-direct form (WD, MB <= 4) the weights skip
+// LDS and are read by the K-steps straight from L2, which leaves room for three workgroups per CU.
 #include "san_common.h"
 
 #include <cstdint>
