@@ -62,6 +62,7 @@ struct BArgs {
     int y_ctot, y_coff, cout;
     int N, H, W;
     int tiles_x, tiles_y, cgs, chunks, nblkp;   // nblkp: channel blocks in the packed image (>= cgs * MB)
+    int tw, th, hp, npx;       // tile width / height (tw * th <= 256 pixels, taken in flattened order), halo pitch tw + 2, halo pixels
 };
 
 // round-to-nearest-even bf16 of f, returned as the fp32 it represents (upper 16 bits)
@@ -104,7 +105,9 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
 // KS = 1: the same kernel as a 1x1 convolution (the alignment net's 1x1 layers, the data gradient of the transposed
 // convolutions): one K-step per 24-channel chunk (three channel groups at the centre tap + the zero group), always WD;
 // only the tile's interior is staged.
-template <int MB, bool WD, int KS>
+// FLAT: run-time tile shape (narrow images: full-width rows, see tile_geom); otherwise the 32 x 8 tile with
+// compile-time offsets between a wave's blocks (immediate LDS offsets in the K-loop).
+template <int MB, bool WD, int KS, bool FLAT>
 __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     constexpr int kSteps = KS == 3 ? 7 : 1;            // (shadows the 3x3 constant)
     static_assert(KS == 3 || WD, "the 1x1 form reads its weights directly");
@@ -132,7 +135,8 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     const int tile = (lin / a.cgs) % ntile;
     const int n = lin / (a.cgs * ntile);
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
-    const int x0 = tx * kTW, y0 = ty * kTH;
+    const int tw = FLAT ? a.tw : kTW, th = FLAT ? a.th : kTH, hp = FLAT ? a.hp : kHW_, npx = FLAT ? a.npx : kNP;
+    const int x0 = tx * tw, y0 = ty * th;
 
     // ---- staging units (pixel p, channel group chg): slots 0..2 = pixel tid of group s (the group, hence the
     // lazy-affine entries, is wave-uniform there), slot 3 = the remaining 84 pixels x 3 groups
@@ -145,13 +149,15 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         if (s < 3) {
             p = tid;
             chg = s;
+            used = tid < npx;
         } else {
-            used = tid < 3 * (kNP - kT);
-            chg = used ? tid / (kNP - kT) : 0;
-            p = used ? kT + tid - chg * (kNP - kT) : 0;
+            const int rem = npx - kT;                   // halo pixels beyond the first 256 (<= 84)
+            used = rem > 0 && tid < 3 * rem;
+            chg = used ? tid / rem : 0;
+            p = used ? kT + tid - chg * rem : 0;
         }
-        const int pr = p / kHW_, pc = p - pr * kHW_;
-        if (KS == 1) used = used && pr >= 1 && pr <= kTH && pc >= 1 && pc <= kTW;       // no halo
+        const int pr = p / hp, pc = p - pr * hp;
+        if (KS == 1) used = used && pr >= 1 && pr <= th && pc >= 1 && pc <= tw;       // no halo
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
         s_in[s] = used && gy >= 0 && gy < H && gx >= 0 && gx < W;
         s_goff[s] = s_in[s] ? gy * W + gx : 0;
@@ -215,14 +221,26 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
             const int g = min(4 * s + kg, 26);
             const int tap = g / 3, chg = g - 3 * tap;
             const int ky = tap / 3, kx = tap - 3 * ky;
-            tapoff[s] = (ky * kHW_ + kx) * kPS + chg * 16;
+            tapoff[s] = (ky * hp + kx) * kPS + chg * 16;
         } else {
-            tapoff[s] = (kHW_ + 1) * kPS + min(kg, 2) * 16;        // centre tap; group 3 meets zero weights
+            tapoff[s] = (hp + 1) * kPS + min(kg, 2) * 16;          // centre tap; group 3 meets zero weights
         }
     }
-    int boff[4];                                        // block b: row 2 wave + (b >> 1), columns 16 (b & 1) ..
+    // block b of wave w = the 16 pixels 64 w + 16 b .. of the tile in flattened (row-major) order: any tile shape with
+    // tw * th <= 256 works, a block may wrap from one tile row into the next (32 x 8: rows 2w, 2w+1 as before)
+    int boff[4], trow[4], tcol[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) boff[b] = ((2 * wave + (b >> 1)) * kHW_ + 16 * (b & 1) + nn) * kPS;
+    for (int b = 0; b < 4; ++b) {
+        if constexpr (FLAT) {
+            const int q = min(64 * wave + 16 * b + nn, tw * th - 1);
+            trow[b] = q / tw;
+            tcol[b] = q - trow[b] * tw;
+        } else {
+            trow[b] = 2 * wave + (b >> 1);
+            tcol[b] = 16 * (b & 1) + nn;
+        }
+        boff[b] = (trow[b] * hp + tcol[b]) * kPS;
+    }
 
     fetch_aff(0);
     if (tid < 48) lds_aff[tid] = my_aff;              // chunk 0's table; visible after the loop's first barrier
@@ -305,15 +323,15 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     }
 
     // ------------------------------------------------------------ epilogue
-    // acc[m][b][r] = output channel co = (cg MB + m) 16 + 4 (lane >> 4) + r at pixel (row 2 wave + (b >> 1), column 16 (b & 1) + nn)
+    // acc[m][b][r] = output channel co = (cg MB + m) 16 + 4 (lane >> 4) + r at tile pixel (trow[b], tcol[b])
     const int cbase = cg * MB * 16 + 4 * kg;
     int oy[4], ox[4];
     bool valid[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        oy[b] = y0 + 2 * wave + (b >> 1);
-        ox[b] = x0 + 16 * (b & 1) + nn;
-        valid[b] = oy[b] < H && ox[b] < W;
+        oy[b] = y0 + trow[b];
+        ox[b] = x0 + tcol[b];
+        valid[b] = (!FLAT || 64 * wave + 16 * b + nn < tw * th) && oy[b] < H && ox[b] < W;
     }
     if (a.bias) {
 #pragma unroll
@@ -455,6 +473,39 @@ __global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
         pack_one(w, packed, idx, (int)j[2], (int)j[3], (int)j[4], (int)j[6], j[5] == 1 ? 1 : 3);
 }
 
+int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): force the weights-direct choice
+int g_b16_mb = -1;             // tuning hook (SAN_B16_MB=2..5): force the channel blocks per workgroup
+int g_b16_flat = 1;            // tuning hook (SAN_B16_FLAT=0): always 32 x 8 tiles
+struct B16Env {
+    B16Env() {
+        if (const char* e = getenv("SAN_B16_WD")) g_b16_wd = atoi(e);
+        if (const char* e = getenv("SAN_B16_MB")) g_b16_mb = atoi(e);
+        if (const char* e = getenv("SAN_B16_FLAT")) g_b16_flat = atoi(e);
+    }
+} g_b16_env;
+
+// Tile shape: 32 x 8 unless a narrow image fills more of the 256-pixel tile as full-width rows (W <= ~48: 20 x 12,
+// 40 x 6 ...; the halo must fit the 340-pixel LDS image).  Blocks are flattened 16-pixel runs, so any shape works.
+struct TileGeom {
+    int tw, th, tiles_x, tiles_y;
+};
+
+TileGeom tile_geom(int h, int w) {
+    TileGeom g{kTW, kTH, san_cdiv(w, kTW), san_cdiv(h, kTH)};
+    if (g_b16_flat == 0) return g;
+    long long best = (long long)g.tiles_x * g.tiles_y;             // workgroups per image: fewer = fuller tiles
+    int th = 256 / w;
+    if (th > h) th = h;
+    while (th > 1 && (w + 2) * (th + 2) > kNP) --th;
+    if (th >= 1 && w * th <= 256 && (w + 2) * (th + 2) <= kNP) {
+        // rows balanced over the image (20 rows: 10 + 10 rather than 12 + 8)
+        const int ty = san_cdiv(h, th);
+        const int thb = san_cdiv(h, ty);
+        if ((long long)ty < best) g = TileGeom{w, thb, 1, ty};
+    }
+    return g;
+}
+
 struct BPlan {
     int nblkp, chunks;
     size_t packed_elems;       // bf16 elements
@@ -487,12 +538,12 @@ int pick_mb(int cout, int tiles) {
     return best > 5 ? 5 : best;
 }
 
-template <int MB, bool WD, int KS = 3>
-int launch_b(const BArgs& a, hipStream_t s) {
+template <int MB, bool WD, int KS, bool FLAT>
+int launch_bf(const BArgs& a, hipStream_t s) {
     constexpr size_t lds = 3 * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -500,18 +551,16 @@ int launch_b(const BArgs& a, hipStream_t s) {
         configured = true;
     }
     const int total = a.tiles_x * a.tiles_y * a.cgs * a.N;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS>), dim3(total), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT>), dim3(total), dim3(kT), lds, s, a);
     return SAN_OK;
 }
 
-int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): force the weights-direct choice
-int g_b16_mb = -1;             // tuning hook (SAN_B16_MB=2..5): force the channel blocks per workgroup
-struct B16Env {
-    B16Env() {
-        if (const char* e = getenv("SAN_B16_WD")) g_b16_wd = atoi(e);
-        if (const char* e = getenv("SAN_B16_MB")) g_b16_mb = atoi(e);
-    }
-} g_b16_env;
+template <int MB, bool WD, int KS = 3>
+int launch_b(const BArgs& a, hipStream_t s) {
+    return (a.tw == kTW && a.th == kTH) ? launch_bf<MB, WD, KS, false>(a, s) : launch_bf<MB, WD, KS, true>(a, s);
+}
+
+
 
 }  // namespace
 
@@ -541,7 +590,8 @@ size_t san_conv_bf16x3_packed_bytes(int cout, int cin) { return san_conv_bf16x3_
 
 int san_conv_bf16x3_stat_tiles(int n, int h, int w) {
     (void)n;
-    return san_cdiv(w, kTW) * san_cdiv(h, kTH) * 4;
+    const TileGeom tg = tile_geom(h, w);
+    return tg.tiles_x * tg.tiles_y * 4;
 }
 
 int san_conv_bf16x3_pack_ks(const float* w, void* packed, int cout, int cin, int mode, int ks, void* stream) {
@@ -615,8 +665,13 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.N = n;
     a.H = h;
     a.W = w;
-    a.tiles_x = san_cdiv(w, kTW);
-    a.tiles_y = san_cdiv(h, kTH);
+    const TileGeom tg = tile_geom(h, w);
+    a.tiles_x = tg.tiles_x;
+    a.tiles_y = tg.tiles_y;
+    a.tw = tg.tw;
+    a.th = tg.th;
+    a.hp = tg.tw + 2;
+    a.npx = (tg.tw + 2) * (tg.th + 2);
     int mb = pick_mb(cout, a.tiles_x * a.tiles_y * n);
     if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
     a.cgs = san_cdiv(san_cdiv(cout, 16), mb);
