@@ -13,7 +13,7 @@ for tag, d in (('FETCH_SIZE', '/tmp/pmc_f'), ('WRITE_SIZE', '/tmp/pmc_w')):
             if r['Counter_Name'] != tag: continue
             k = r['Kernel_Name']
             key = ('cal_apply' if 'apply_kernel' in k else 'cal_rss' if 'rss_kernel' in k and 'bwd' not in k else
-                   'conv_bf16x3_1x1' if 'conv_bf16x3_kernel' in k and ', 1>(' in k else
+                   'conv_bf16x3_1x1' if 'conv_bf16x3_kernel' in k and (', true, 1, ' in k or ', false, 1, ' in k) else
                    'conv_bf16x3' if 'conv_bf16x3_kernel' in k else
                    'wgrad_bf16x3' if 'wgrad_bf16x3_direct_kernel' in k else
                    'wgrad1x1_bf16x3' if 'wgrad1x1_bf16x3_kernel' in k else
