@@ -430,13 +430,12 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 // data-gradient convolution and w is the forward weight of the layer being differentiated: value = w[ci][co][8 - tap].
 // ks = 1: one step per chunk, group kg < 3 -> channels chunk 24 + 8 kg + i of the single tap, kg = 3 zero;
 // mode 0: w[co][ci], mode 2: w[ci][co].
-__device__ __forceinline__ void pack_one(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t idx, int cout,
-                                         int cin, int nblkp, int mode, int ks) {
-    const int i = (int)(idx & 7);
-    const int lane = (int)((idx >> 3) & 63);
-    size_t r = idx >> 9;
-    const int part = (int)(r % 3);
-    r /= 3;
+// One thread per (chunk, step, blk, lane): its 8 values (consecutive input channels of one tap) are gathered once,
+// split three ways and written as three 16-byte vectors (one per part).
+__device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t u, int cout,
+                                          int cin, int nblkp, int mode, int ks) {
+    const int lane = (int)(u & 63);
+    size_t r = u >> 6;
     const int blk = (int)(r % nblkp);
     r /= nblkp;
     const int steps = ks == 1 ? 1 : kSteps;
@@ -445,22 +444,40 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, uint16_t* 
     const int co = blk * 16 + (lane & 15);
     const int g = 4 * step + (lane >> 4);
     const int tap = g / 3;
-    const int ci = chunk * kCKC + (g - 3 * tap) * 8 + i;
-    float v = 0.f;
-    if (ks == 1) {
-        if (tap == 0 && ci < cin && co < cout) v = mode == 2 ? w[(size_t)ci * cout + co] : w[(size_t)co * cin + ci];
-    } else if (tap < 9 && ci < cin && co < cout) {
-        v = mode == 2 ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
+    const int ci0 = chunk * kCKC + (g - 3 * tap) * 8;
+    const bool live = co < cout && (ks == 1 ? tap == 0 : tap < 9);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q[3];
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+        float v[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ci = ci0 + i + k;
+            v[k] = 0.f;
+            if (live && ci < cin) {
+                if (ks == 1) v[k] = mode == 2 ? w[(size_t)ci * cout + co] : w[(size_t)co * cin + ci];
+                else v[k] = mode == 2 ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
+            }
+        }
+        uint32_t a1, a2, a3, b1, b2, b3;
+        split3(v[0], a1, a2, a3);
+        split3(v[1], b1, b2, b3);
+        q[0][i >> 1] = (a1 & 0xffffu) | (b1 << 16);
+        q[1][i >> 1] = (a2 & 0xffffu) | (b2 << 16);
+        q[2][i >> 1] = (a3 & 0xffffu) | (b3 << 16);
     }
-    uint32_t p1, p2, p3;
-    split3(v, p1, p2, p3);
-    packed[idx] = (uint16_t)(part == 0 ? p1 : (part == 1 ? p2 : p3));
+    // packed[(((chunk steps + step) nblkp + blk) 3 + part) 64 + lane][8]
+    uint16_t* o = packed + ((u >> 6) * 3 * 64 + lane) * 8;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(o + (size_t)p * 64 * 8) = q[p];
 }
 
 __global__ void pack_bf16x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t total, int cout,
                                    int cin, int nblkp, int mode, int ks) {
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-        pack_one(w, packed, idx, cout, cin, nblkp, mode, ks);
+    const size_t units = total / 24;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x)
+        pack_unit(w, packed, u, cout, cin, nblkp, mode, ks);
 }
 
 // batched: 8 x int64 per job = {w, packed, cout, cin, nblkp, ks (0 = 3), mode, total}
@@ -468,9 +485,9 @@ __global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
     const long long* j = jobs + 8 * (size_t)blockIdx.y;
     const float* w = reinterpret_cast<const float*>(j[0]);
     uint16_t* packed = reinterpret_cast<uint16_t*>(j[1]);
-    const size_t total = (size_t)j[7];
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x)
-        pack_one(w, packed, idx, (int)j[2], (int)j[3], (int)j[4], (int)j[6], j[5] == 1 ? 1 : 3);
+    const size_t units = (size_t)j[7] / 24;
+    for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x)
+        pack_unit(w, packed, u, (int)j[2], (int)j[3], (int)j[4], (int)j[6], j[5] == 1 ? 1 : 3);
 }
 
 int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): force the weights-direct choice
