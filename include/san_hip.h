@@ -357,6 +357,18 @@ int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
                           float* y, int y_ctot, int y_coff, int cout, float* part_stats,
                           int n, int h, int w, void* stream);
 
+/* Split-K form for deep-K layers on small images (288 -> 288 @20^2: 64 tiles for 256 CUs and 12 serial
+ * chunks per tile): up to 4 workgroups share an output tile, each over a range of the input channels,
+ * and a second launch adds their partial outputs in a fixed order (deterministic), applies the bias,
+ * stores and takes the statistics.  ws: san_conv_bf16x3_ws_bytes(...) bytes (0 = this layer is not
+ * split; then the plain entry point does the same work). */
+size_t san_conv_bf16x3_ws_bytes(int n, int h, int w, int cin, int cout, int ks);
+int san_conv2d_bf16x3_fwd_ws(const float* x, int x_ctot, int x_coff, int cin,
+                             const float* in_scale, const float* in_shift, float in_slope,
+                             const void* w_packed, const float* bias,
+                             float* y, int y_ctot, int y_coff, int cout, float* part_stats,
+                             int n, int h, int w, void* ws, size_t ws_bytes, void* stream);
+
 /* The same kernel as a 1x1 convolution (the alignment net's 1x1 layers, unet.py:64-77; the data gradient of
  * the transposed convolutions): weights packed with the _ks entry points (ks = 1 or 3; the plain ones are
  * ks = 3), statistics tiles as san_conv_bf16x3_stat_tiles. */

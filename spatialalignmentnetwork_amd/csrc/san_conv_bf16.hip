@@ -62,6 +62,8 @@ struct BArgs {
     int y_ctot, y_coff, cout;
     int N, H, W;
     int tiles_x, tiles_y, cgs, chunks, nblkp;   // nblkp: channel blocks in the packed image (>= cgs * MB)
+    int S;                     // split-K: S workgroups share an output tile, each takes a contiguous range of the chunks
+    float* ws;                 // [S][N][cout][H][W] partial outputs (S > 1); splitk_reduce_kernel adds them up
     int tw, th, hp, npx;       // tile width / height (tw * th <= 256 pixels, taken in flattened order), halo pitch tw + 2, halo pixels
 };
 
@@ -131,9 +133,12 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         lin = xcd * (total >> 3) + min(xcd, total & 7) + slot;
     }
     const int ntile = a.tiles_x * a.tiles_y;
-    const int cg = lin % a.cgs;
-    const int tile = (lin / a.cgs) % ntile;
-    const int n = lin / (a.cgs * ntile);
+    const int sk = lin % a.S;                           // split-K part (fastest: the S parts of a tile share its input)
+    const int group = lin / a.S;                        // (n, tile, cg)
+    const int cg = group % a.cgs;
+    const int tile = (group / a.cgs) % ntile;
+    const int n = group / (a.cgs * ntile);
+    const int c0 = (a.chunks * sk) / a.S, c1 = (a.chunks * (sk + 1)) / a.S;     // this workgroup's chunks
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int tw = FLAT ? a.tw : kTW, th = FLAT ? a.th : kTH, hp = FLAT ? a.hp : kHW_, npx = FLAT ? a.npx : kNP;
     const int x0 = tx * tw, y0 = ty * th;
@@ -242,10 +247,10 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         boff[b] = (trow[b] * hp + tcol[b]) * kPS;
     }
 
-    fetch_aff(0);
-    if (tid < 48) lds_aff[tid] = my_aff;              // chunk 0's table; visible after the loop's first barrier
-    prefetch(0);
-    for (int chunk = 0; chunk < a.chunks; ++chunk) {
+    fetch_aff(c0);
+    if (tid < 48) lds_aff[(c0 & 1) * 48 + tid] = my_aff;       // the first chunk's table; visible after the loop's first barrier
+    prefetch(c0);
+    for (int chunk = c0; chunk < c1; ++chunk) {
         __syncthreads();
         Frag wa[2][MB][3], xa[2][4][3];
         const uint4* wsrc = a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane;      // (WD)
@@ -301,7 +306,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 for (int p = 0; p < 3; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
         };
         __syncthreads();
-        if (chunk + 1 < a.chunks) prefetch(chunk + 1);
+        if (chunk + 1 < c1) prefetch(chunk + 1);
         if constexpr (KS == 3) load_w(0, wa[0]);
         load_x(0, xa[0]);
 #pragma unroll
@@ -332,6 +337,23 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         oy[b] = y0 + trow[b];
         ox[b] = x0 + tcol[b];
         valid[b] = (!FLAT || 64 * wave + 16 * b + nn < tw * th) && oy[b] < H && ox[b] < W;
+    }
+    if (a.S > 1) {
+        // split-K: this workgroup covered only chunks [c0, c1): its partial sums go to slice sk of the scratch tensor;
+        // bias, statistics and the real store happen in splitk_reduce_kernel (next launch: no device-scope fences here)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = cbase + 16 * m + r;
+                if (co < a.cout) {
+                    float* dst = a.ws + ((size_t)(sk * a.N + n) * a.cout + co) * HWp;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (valid[b]) dst[oy[b] * W + ox[b]] = acc[m][b][r];
+                }
+            }
+        return;
     }
     if (a.bias) {
 #pragma unroll
@@ -422,6 +444,54 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         }
 }
 
+// ---------------------------------------------------------------- split-K second pass
+// y[n][c][p] = bias[c] + sum_k ws[k][n][c][p] (fixed order), plus the plane's (count, mean, M2) as statistics tile 0
+// (the other tiles of the caller's partials array get count 0).  One workgroup per (n, c) plane of at most 4096 pixels.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int y_ctot, int y_coff, float* __restrict__ part,
+                                                             int tiles, int N, int C, int HW) {
+    __shared__ float red[2][4];
+    const int nc = blockIdx.x, n = nc / C, c = nc - n * C;
+    const float bv = bias ? bias[c] : 0.f;
+    const size_t plane = (size_t)N * C * HW;
+    const float* src = ws + (size_t)nc * HW;
+    float* dst = y + ((size_t)n * y_ctot + y_coff + c) * HW;
+    float v[16];
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int p = threadIdx.x + 256 * i;
+        v[i] = 0.f;
+        if (p < HW) {
+            float t = src[p];
+            for (int k = 1; k < S; ++k) t += src[(size_t)k * plane + p];
+            v[i] = t + bv;
+            dst[p] = v[i];
+            s1 += v[i];
+        }
+    }
+    if (!part) return;
+    s1 = san_wave_sum(s1);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1;
+    __syncthreads();
+    const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)HW;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int p = threadIdx.x + 256 * i;
+        if (p < HW) s2 = fmaf(v[i] - mean, v[i] - mean, s2);
+    }
+    s2 = san_wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = s2;
+    __syncthreads();
+    float* o = part + (size_t)nc * tiles * 3;
+    for (int t = threadIdx.x; t < tiles; t += 256) {
+        o[3 * t] = t == 0 ? (float)HW : 0.f;
+        o[3 * t + 1] = t == 0 ? mean : 0.f;
+        o[3 * t + 2] = t == 0 ? (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]) : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------- packing
 // packed[chunk][step][blk][part][lane][i] (bf16), blk over nblkp = ceil(cout/16) + 4 blocks (zero padded so any
 // grouping of up to 5 blocks per workgroup stays inside): lane = (co16 = lane & 15, kg = lane >> 4);
@@ -493,13 +563,29 @@ __global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
 int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): force the weights-direct choice
 int g_b16_mb = -1;             // tuning hook (SAN_B16_MB=2..5): force the channel blocks per workgroup
 int g_b16_flat = 1;            // tuning hook (SAN_B16_FLAT=0): always 32 x 8 tiles
+int g_b16_splitk = 4;          // tuning hook (SAN_B16_SPLITK=1 disables split-K, 2 / 4 = most parts per tile)
 struct B16Env {
     B16Env() {
         if (const char* e = getenv("SAN_B16_WD")) g_b16_wd = atoi(e);
         if (const char* e = getenv("SAN_B16_MB")) g_b16_mb = atoi(e);
         if (const char* e = getenv("SAN_B16_FLAT")) g_b16_flat = atoi(e);
+        if (const char* e = getenv("SAN_B16_SPLITK")) g_b16_splitk = atoi(e);
     }
 } g_b16_env;
+
+// Split-K: for 3x3 layers whose (image, tile, channel group) count leaves CUs idle and whose K is a long serial chain of
+// chunks (288 -> 288 @20^2: 64 tiles, 12 chunks), up to 4 workgroups share a tile, each taking a contiguous range of
+// the chunks (at least 2) and writing a partial output; splitk_reduce_kernel then adds the partials in a fixed order,
+// applies the bias, stores and takes the statistics.  (An in-kernel last-arriver join was tried first: its device-scope
+// fences write back / invalidate the whole L2 of every XCD and made the layer 1.7x SLOWER.)
+int splitk_parts(int groups, int chunks, int ks, int hw) {
+    if (ks != 3 || hw > 4096) return 1;
+    int S = 1;
+    while (S * 2 <= g_b16_splitk && groups * S * 2 <= 512 && chunks / (S * 2) >= 2) S *= 2;
+    return S;
+}
+
+size_t splitk_bytes(int S, int n, int cout, int hw) { return (size_t)S * n * cout * hw * sizeof(float); }
 
 // Tile shape: 32 x 8 unless a narrow image fills more of the 256-pixel tile as full-width rows (W <= ~48: 20 x 12,
 // 40 x 6 ...; the halo must fit the 340-pixel LDS image).  Blocks are flattened 16-pixel runs, so any shape works.
@@ -567,7 +653,7 @@ int launch_bf(const BArgs& a, hipStream_t s) {
         }
         configured = true;
     }
-    const int total = a.tiles_x * a.tiles_y * a.cgs * a.N;
+    const int total = a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
     hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT>), dim3(total), dim3(kT), lds, s, a);
     return SAN_OK;
 }
@@ -656,7 +742,8 @@ int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* strea
 
 static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
                            float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
-                           float* part_stats, int n, int h, int w, int ks, void* stream, int shuffle = 0) {
+                           float* part_stats, int n, int h, int w, int ks, void* stream, int shuffle = 0,
+                           void* ws = nullptr, size_t ws_bytes = 0) {
     SAN_CHECK_ARG(x && w_packed && y, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + (shuffle ? cout / 4 : cout) <= y_ctot, "bad channel view");
@@ -694,6 +781,14 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.cgs = san_cdiv(san_cdiv(cout, 16), mb);
     a.chunks = p.chunks;
     a.nblkp = p.nblkp;
+    a.S = 1;
+    if (ws && !shuffle) {
+        const int S = splitk_parts(a.tiles_x * a.tiles_y * n * a.cgs, p.chunks, ks, h * w);
+        if (S > 1 && ws_bytes >= splitk_bytes(S, n, cout, h * w)) {
+            a.S = S;
+            a.ws = static_cast<float*>(ws);
+        }
+    }
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (ks == 1) {
@@ -718,6 +813,12 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
+    if (a.S > 1) {
+        const TileGeom tgs = tile_geom(h, w);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(n * cout), dim3(256), 0, s, a.ws, a.S, bias, y, y_ctot, y_coff, part_stats,
+                           tgs.tiles_x * tgs.tiles_y * 4, n, cout, h * w);
+        SAN_LAUNCH_CHECK();
+    }
     return SAN_OK;
 }
 
@@ -753,6 +854,27 @@ int san_tconv2x2_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin, con
                             float* part_stats, int n, int h, int w, void* stream) {
     return conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, nullptr, y, y_ctot, y_coff,
                            4 * cout, part_stats, n, h, w, 1, stream, 1);
+}
+
+// Split-K form of san_conv2d_bf16x3_fwd for deep-K layers on small images (288 -> 288 @20^2 ...): ws = device scratch of
+// san_conv_bf16x3_ws_bytes(...) bytes (0: the layer is not split; the plain entry point does the same work).  The partial
+// outputs are added in a fixed order by a second launch: deterministic.
+size_t san_conv_bf16x3_ws_bytes(int n, int h, int w, int cin, int cout, int ks) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ks != 3) return 0;
+    const BPlan p = bplan(cout, cin, ks);
+    const TileGeom tg = tile_geom(h, w);
+    int mb = pick_mb(cout, tg.tiles_x * tg.tiles_y * n);
+    if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
+    const int groups = tg.tiles_x * tg.tiles_y * n * san_cdiv(san_cdiv(cout, 16), mb);
+    const int S = splitk_parts(groups, p.chunks, ks, h * w);
+    return S > 1 ? splitk_bytes(S, n, cout, h * w) : 0;
+}
+
+int san_conv2d_bf16x3_fwd_ws(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                             float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff,
+                             int cout, float* part_stats, int n, int h, int w, void* ws, size_t ws_bytes, void* stream) {
+    return conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout,
+                           part_stats, n, h, w, 3, stream, 0, ws, ws_bytes);
 }
 
 }  // extern "C"

@@ -463,6 +463,20 @@ def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     return PACKS.get(w, 1 if transposed else 0)
 
 
+def _bf16x3_launch(ks: int, bargs, n: int, h: int, w: int, cin: int, cout: int, device, arena: "Arena") -> None:
+    """bargs = the arguments of san_conv2d_bf16x3_fwd (stream last).  3x3 layers that the library wants to split over K
+    (deep K, few tiles: san_conv_bf16x3_ws_bytes > 0) get the scratch for the partial outputs."""
+    if ks != 3:
+        lib().call("san_conv1x1_bf16x3_fwd", *bargs)
+        return
+    nbytes = lib().query("san_conv_bf16x3_ws_bytes", n, h, w, cin, cout, 3)
+    if nbytes == 0:
+        lib().call("san_conv2d_bf16x3_fwd", *bargs)
+        return
+    ws = arena.scratch("b16_splitk", nbytes, device)
+    lib().call("san_conv2d_bf16x3_fwd_ws", *bargs[:-1], _p(ws), nbytes, bargs[-1])
+
+
 def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: bool = False,
            out_scale: Optional[torch.Tensor] = None, out_shift: Optional[torch.Tensor] = None,
            arena: Arena = GLOBAL_ARENA, tag: str = "") -> Optional[torch.Tensor]:
@@ -480,9 +494,8 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
             part = arena.get("part" + tag, (n, cout, lib().query("san_conv_bf16x3_stat_tiles", n, h, w), 3), x.buf.device)
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
                  y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
-        fn = "san_conv2d_bf16x3_fwd" if ks == 3 else "san_conv1x1_bf16x3_fwd"
         _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
-               lambda: lib().call(fn, *bargs))
+               lambda: _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena))
         return part
     wp = packed_weight(weight)
     if stats:
@@ -691,9 +704,8 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
         wp = PACKS16.get(weight, 2)
         bargs = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
                  _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), dy.n, dy.h, dy.w, _stream())
-        fn = "san_conv2d_bf16x3_fwd" if ks == 3 else "san_conv1x1_bf16x3_fwd"
         _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
-               lambda: lib().call(fn, *bargs))
+               lambda: _bf16x3_launch(ks, bargs, dy.n, dy.h, dy.w, cout, cin, dy.buf.device, GLOBAL_ARENA))
         return
     wp = packed_weight_dgrad(weight)
     args = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
