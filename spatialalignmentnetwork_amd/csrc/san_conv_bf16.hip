@@ -564,24 +564,26 @@ int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): for
 int g_b16_mb = -1;             // tuning hook (SAN_B16_MB=2..5): force the channel blocks per workgroup
 int g_b16_flat = 1;            // tuning hook (SAN_B16_FLAT=0): always 32 x 8 tiles
 int g_b16_splitk = 4;          // tuning hook (SAN_B16_SPLITK=1 disables split-K, 2 / 4 = most parts per tile)
+int g_b16_splitcap = 1024;     // tuning hook (SAN_B16_SPLITCAP): most workgroups a split launch may have
 struct B16Env {
     B16Env() {
         if (const char* e = getenv("SAN_B16_WD")) g_b16_wd = atoi(e);
         if (const char* e = getenv("SAN_B16_MB")) g_b16_mb = atoi(e);
         if (const char* e = getenv("SAN_B16_FLAT")) g_b16_flat = atoi(e);
         if (const char* e = getenv("SAN_B16_SPLITK")) g_b16_splitk = atoi(e);
+        if (const char* e = getenv("SAN_B16_SPLITCAP")) g_b16_splitcap = atoi(e);
     }
 } g_b16_env;
 
 // Split-K: for 3x3 layers whose (image, tile, channel group) count leaves CUs idle and whose K is a long serial chain of
 // chunks (288 -> 288 @20^2: 64 tiles, 12 chunks), up to 4 workgroups share a tile, each taking a contiguous range of
-// the chunks (at least 2) and writing a partial output; splitk_reduce_kernel then adds the partials in a fixed order,
+// the chunks (at least 2, at most ~4 workgroups per CU in the launch) and writing a partial output; splitk_reduce_kernel then adds the partials in a fixed order,
 // applies the bias, stores and takes the statistics.  (An in-kernel last-arriver join was tried first: its device-scope
 // fences write back / invalidate the whole L2 of every XCD and made the layer 1.7x SLOWER.)
 int splitk_parts(int groups, int chunks, int ks, int hw) {
     if (ks != 3 || hw > 4096) return 1;
     int S = 1;
-    while (S * 2 <= g_b16_splitk && groups * S * 2 <= 512 && chunks / (S * 2) >= 2) S *= 2;
+    while (S * 2 <= g_b16_splitk && groups * S * 2 <= g_b16_splitcap && chunks / (S * 2) >= 2) S *= 2;
     return S;
 }
 
