@@ -1029,15 +1029,18 @@ __global__ void bn_update_running_kernel(float* __restrict__ rmean, float* __res
 }
 
 // bias gradient from san_plane_stats chunks (count, mean, m2): db[c] += sum_{n,t} count * mean
-__global__ void bias_grad_kernel(const float* __restrict__ part, float* __restrict__ db, int n, int c, int tiles) {
-    const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ch >= c) return;
+__global__ void __launch_bounds__(64) bias_grad_kernel(const float* __restrict__ part, float* __restrict__ db, int n, int c,
+                                                        int tiles) {
+    // one wave per channel, lanes stride over the (sample, chunk) records; fixed-order butterfly sum in double
+    const int ch = blockIdx.x, lane = threadIdx.x;
     double s = 0.0;
-    for (int i = 0; i < n; ++i) {
-        const float* p = part + ((size_t)i * c + ch) * tiles * 3;
-        for (int t = 0; t < tiles; ++t) s += (double)p[3 * t] * (double)p[3 * t + 1];
+    for (int e = lane; e < n * tiles; e += 64) {
+        const int i = e / tiles, t = e - i * tiles;
+        const float* p = part + (((size_t)i * c + ch) * tiles + t) * 3;
+        s += (double)p[0] * (double)p[1];
     }
-    db[ch] += (float)s;
+    s = san_wave_sum_d(s);
+    if (lane == 0) db[ch] += (float)s;
 }
 
 // NormUnet backward (varnet.py:246-332): with B = chunk sums of (g_out, g_out*U), A = chunk sums of (g_xh, g_xh*xh),
@@ -1357,7 +1360,7 @@ int san_bn_bwd_finalize(const float* part, const float* gamma, const float* beta
 int san_bias_grad_from_stats(const float* part, float* db, int n, int c, int tiles, void* stream) {
     SAN_CHECK_ARG(part && db, "null pointer");
     SAN_CHECK_ARG(n > 0 && c > 0 && tiles > 0, "bad dims");
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(san_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, part, db, n, c, tiles);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, part, db, n, c, tiles);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

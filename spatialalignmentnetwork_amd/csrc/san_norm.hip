@@ -9,40 +9,71 @@ namespace {
 constexpr int kThreads = 256;
 
 // -------------------------------------------------------------------------
-// one wave per output statistic; partials merged in double, fixed order
+// one workgroup of 256 threads per output statistic; partials merged in double, fixed order.  The (count, mean, M2)
+// records are read ONCE (up to 8 per thread stay in registers for the second, centred pass).
 // grid: (c, n_groups) ; n_groups = n (instance/group) or 1 (batch)
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 norm_finalize_kernel(const float* __restrict__ part, int n, int c, int tiles, int mode, float eps,
                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
                      float* __restrict__ shift, int sc_ctot, int sc_coff, float* __restrict__ aux_a,
                      float* __restrict__ aux_b) {
+    __shared__ double red[3][4];
     const int ch = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int n_lo = (mode == SAN_NORM_BATCH) ? 0 : blockIdx.y;
     const int n_hi = (mode == SAN_NORM_BATCH) ? n : blockIdx.y + 1;
+    const int total = (n_hi - n_lo) * tiles;            // records of this statistic, contiguous per sample
+    constexpr int kKeep = 8;
+    float kc[kKeep], km[kKeep], k2[kKeep];
     double cnt = 0.0, s = 0.0;
-    for (int b = n_lo; b < n_hi; ++b) {
-        const float* p = part + ((size_t)(b * c + ch) * tiles) * 3;
-        for (int t = lane; t < tiles; t += 64) {
-            const double k = p[t * 3 + 0];
-            cnt += k;
-            s += k * (double)p[t * 3 + 1];
+    auto rec = [&](int e) -> const float* {
+        const int b = n_lo + e / tiles, t = e - (e / tiles) * tiles;
+        return part + ((size_t)(b * c + ch) * tiles + t) * 3;
+    };
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i) {
+        const int e = tid + 256 * i;
+        kc[i] = km[i] = k2[i] = 0.f;
+        if (e < total) {
+            const float* p = rec(e);
+            kc[i] = p[0];
+            km[i] = p[1];
+            k2[i] = p[2];
+            cnt += (double)kc[i];
+            s += (double)kc[i] * (double)km[i];
         }
+    }
+    for (int e = tid + 256 * kKeep; e < total; e += 256) {
+        const float* p = rec(e);
+        cnt += (double)p[0];
+        s += (double)p[0] * (double)p[1];
     }
     cnt = san_wave_sum_d(cnt);
     s = san_wave_sum_d(s);
+    if (lane == 0) {
+        red[0][wv] = cnt;
+        red[1][wv] = s;
+    }
+    __syncthreads();
+    cnt = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double mean = cnt > 0.0 ? s / cnt : 0.0;
     double m2 = 0.0;
-    for (int b = n_lo; b < n_hi; ++b) {
-        const float* p = part + ((size_t)(b * c + ch) * tiles) * 3;
-        for (int t = lane; t < tiles; t += 64) {
-            const double k = p[t * 3 + 0];
-            const double d = (double)p[t * 3 + 1] - mean;
-            m2 += (double)p[t * 3 + 2] + k * d * d;
-        }
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i) {
+        const double d = (double)km[i] - mean;
+        m2 += (double)k2[i] + (double)kc[i] * d * d;
+    }
+    for (int e = tid + 256 * kKeep; e < total; e += 256) {
+        const float* p = rec(e);
+        const double d = (double)p[1] - mean;
+        m2 += (double)p[2] + (double)p[0] * d * d;
     }
     m2 = san_wave_sum_d(m2);
-    if (lane != 0) return;
+    if (lane == 0) red[2][wv] = m2;
+    __syncthreads();
+    m2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    if (tid != 0) return;
     const double var_b = cnt > 0.0 ? m2 / cnt : 0.0;
     const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : 0.0;
     if (mode == SAN_NORM_INSTANCE) {
@@ -267,7 +298,7 @@ int san_norm_finalize(const float* part, int n, int c, int tiles, int mode, floa
     SAN_CHECK_ARG(mode >= 0 && mode <= 2, "bad mode");
     SAN_CHECK_ARG(check_view(sc_ctot, sc_coff, c), "bad scale/shift view");
     dim3 grid(c, mode == SAN_NORM_BATCH ? 1 : n);
-    hipLaunchKernelGGL(norm_finalize_kernel, grid, dim3(64), 0, (hipStream_t)stream, part, n, c, tiles, mode, eps,
+    hipLaunchKernelGGL(norm_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, n, c, tiles, mode, eps,
                        gamma, beta, scale, shift, sc_ctot, sc_coff, aux_a, aux_b);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
