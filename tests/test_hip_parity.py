@@ -847,3 +847,37 @@ def test_full_rec_step_with_bf16x3_convs(S):
             den += (want ** 2).sum().item()
         print(pre, "relative L2 over all parameter gradients", (num / den) ** 0.5)
         assert (num / den) ** 0.5 < 5e-3
+
+
+@pytest.mark.gpu
+def test_training_steps_are_bit_reproducible_and_overlap_changes_nothing(S):
+    """Three 'Rec' optimisation steps (48 x 80, 3 coils) run twice from the same state give bit-identical parameters
+    (no float atomics anywhere: partial sums are added in fixed orders), and running the weight gradients on the side
+    stream (ops.wgrad_overlap, the default) gives bit-identical parameters to running them in line."""
+    from spatialalignmentnetwork_amd.basemodel import Config
+    from spatialalignmentnetwork_amd.model import CSModel
+    n, c, h, w = 2, 3, 48, 80
+
+    def run(overlap: bool):
+        S.ops.WGRAD_OVERLAP[0] = overlap
+        try:
+            cfg = Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                         weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=2, chans=4,
+                         sens_chans=2, pools=2, sens_pools=2)
+            net = CSModel(cfg)
+            net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+            net.net_T.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net.net_T.state_dict().items()], seed=41))
+            net.net_R.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in net.net_R.state_dict().items()], seed=42))
+            net.to(DEV).train()
+            img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+            for _ in range(3):
+                net.set_input(g(img_full), g(img_aux))
+                net.update()
+            torch.cuda.synchronize()
+            return [p.detach().cpu().clone() for m in (net.net_R, net.net_T) for p in m.parameters()]
+        finally:
+            S.ops.WGRAD_OVERLAP[0] = True
+
+    a, b, serial = run(True), run(True), run(False)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)), "two identical runs differ"
+    assert all(torch.equal(x, y) for x, y in zip(a, serial)), "side-stream weight gradients change the result"
