@@ -226,7 +226,7 @@ def main():
         out = {
             "metric": "slices/sec (320x320, 12-cascade VarNet+align)", "value": total_slices / dt, "unit": "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3x3 weight gradients and the convolutions of U-Net levels 2-4 / alignment net: bf16x3 split, fp32-equivalent)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (convolutions from 16-18 channels up and all weight gradients: bf16 matrix cores, operands split in three, six products per MAC, fp32-equivalent; FFT / DC / norms / losses fp32)", "data": "synthetic",
             "config": {"workload": ("train step (regime Rec: fwd + hand-written bwd + grad all-reduce + AdamW) " if args.mode == "train" else "inference pass ") + f"set_input+align+warp+VarNet{args.cascades}+SSIM, "
                                    f"{n} slices/GPU of {h}x{w} single-coil, 4x equispaced mask, random-init weights",
                        "slices_per_gpu": n, "global_batch": n * world, "cascades": args.cascades,
