@@ -287,6 +287,15 @@ int san_add_fwd(const float* a, int a_ctot, int a_coff, const float* a_sc, const
                 float* y, int y_ctot, int y_coff, int n, int c, int hw, void* stream);
 int san_apply_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
                   float* y, int y_ctot, int y_coff, int n, int c, int hw, void* stream);
+/* Copy between planes of different sizes: y[n, c, oy, ox] = T(x)[n, c, oy - off_y, ox - off_x] (T = x's lazy read).
+ * mode 0: zero where the source index falls outside x -- NormUnet.pad (zero-pad the NORMALISED image to multiples
+ *         of 16, varnet.py:275-289: off = the top / left pad) and NormUnet.unpad (varnet.py:291-299: negative off);
+ * mode 1: x plus one reflected row / column at the bottom / right (hy - hx, wy - wx in {0, 1}; F.pad(..., 'reflect')
+ *         of the U-Net's up path for odd sizes, varnet.py:107-114);
+ * mode 2: the adjoint of mode 1 (x = gradient of the padded plane, y = gradient of the unpadded one). */
+int san_window_copy_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
+                        int hx, int wx, float* y, int y_ctot, int y_coff, int hy, int wy, int off_y, int off_x,
+                        int mode, int n, int c, void* stream);
 
 /* -------------------------------------------------------- warp and losses */
 

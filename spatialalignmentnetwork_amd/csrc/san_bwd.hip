@@ -1068,7 +1068,8 @@ __global__ void normunet_bwd_coefs_kernel(const float* __restrict__ partB, const
         }
         const double s = (double)scale[bi * x_ctot + j], t = (double)shift[bi * x_ctot + j], sd = (double)stdv[bi * 2 + j];
         const double dmu = b1 - a1 * s, dsig = b2 - a2 * s;
-        const double cco = dsig / (s * (nel - 1.0) * sd);
+        // a constant plane has sd == 0: torch's std backward masks that case to 0 (and the forward divides by sd + 1e-6)
+        const double cco = sd > 0.0 ? dsig / (s * (nel - 1.0) * sd) : 0.0;
         asc = (float)s;
         ash = (float)(dmu / nel);
         msc = (float)(cco * s);

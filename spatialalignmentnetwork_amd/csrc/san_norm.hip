@@ -275,6 +275,50 @@ __global__ void __launch_bounds__(kThreads) apply_kernel(const EwArgs a) {
     }
 }
 
+
+// window copy between planes of different sizes (NormUnet.pad / unpad, the U-Net's reflect pad and its adjoint):
+// y[oy, ox] = T(x)[oy - off_y, ox - off_x], T = the lazy read of x.  mode 0: zero outside x; 1: one reflected row /
+// column at the bottom / right (F.pad 'reflect': the edge itself is not repeated); 2: adjoint of mode 1 (x is the
+// gradient of the padded plane: its extra row hy / column wy folds back onto row hy-2 / column wy-2 of y).
+struct WinArgs {
+    const float* x;
+    const float* sc;
+    const float* sh;
+    float slope;
+    int x_ctot, x_coff, hx, wx;
+    float* y;
+    int y_ctot, y_coff, hy, wy;
+    int off_y, off_x, mode;
+};
+
+__global__ void __launch_bounds__(kThreads) window_copy_kernel(const WinArgs a) {
+    const int ch = blockIdx.y, n = blockIdx.z;
+    float s, t;
+    load_affine(a.sc, a.sh, n * a.x_ctot + a.x_coff + ch, s, t);
+    const float* xp = a.x + ((size_t)(n * a.x_ctot + a.x_coff + ch)) * a.hx * a.wx;
+    float* yp = a.y + ((size_t)(n * a.y_ctot + a.y_coff + ch)) * a.hy * a.wy;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < a.hy * a.wy; i += gridDim.x * kThreads) {
+        const int oy = i / a.wy, ox = i - oy * a.wy;
+        int sy = oy - a.off_y, sx = ox - a.off_x;
+        float v = 0.f;
+        if (a.mode == 1) {
+            if (sy >= a.hx) sy = 2 * (a.hx - 1) - sy;
+            if (sx >= a.wx) sx = 2 * (a.wx - 1) - sx;
+            v = san_act(xp[(size_t)sy * a.wx + sx], s, t, a.slope);
+        } else if (a.mode == 2) {
+            // x = gradient of the reflect-padded plane (hx >= hy, wx >= wy); rows / columns beyond y fold back
+            const bool fy = a.hx > a.hy && oy == 2 * (a.hy - 1) - a.hy, fx = a.wx > a.wy && ox == 2 * (a.wy - 1) - a.wy;
+            v = san_act(xp[(size_t)oy * a.wx + ox], s, t, a.slope);
+            if (fy) v += san_act(xp[(size_t)a.hy * a.wx + ox], s, t, a.slope);
+            if (fx) v += san_act(xp[(size_t)oy * a.wx + a.wy], s, t, a.slope);
+            if (fy && fx) v += san_act(xp[(size_t)a.hy * a.wx + a.wy], s, t, a.slope);
+        } else if (sy >= 0 && sy < a.hx && sx >= 0 && sx < a.wx) {
+            v = san_act(xp[(size_t)sy * a.wx + sx], s, t, a.slope);
+        }
+        yp[i] = v;
+    }
+}
+
 dim3 ew_grid(int elems_per_plane, int c, int n) {
     int bx = san_cdiv(elems_per_plane, kThreads * 4);
     if (bx < 1) bx = 1;
@@ -398,6 +442,26 @@ int san_apply_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const
     a.x = x; a.sc = sc; a.sh = sh; a.slope = slope; a.x_ctot = x_ctot; a.x_coff = x_coff;
     a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff; a.n = n; a.c = c; a.h = hw; a.w = 1;
     hipLaunchKernelGGL(apply_kernel, ew_grid(hw, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_window_copy_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope, int hx,
+                        int wx, float* y, int y_ctot, int y_coff, int hy, int wy, int off_y, int off_x, int mode, int n,
+                        int c, void* stream) {
+    SAN_CHECK_ARG(x && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && hx > 0 && wx > 0 && hy > 0 && wy > 0, "bad dims");
+    SAN_CHECK_ARG(check_view(x_ctot, x_coff, c) && check_view(y_ctot, y_coff, c), "bad channel view");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    SAN_CHECK_ARG(mode >= 0 && mode <= 2, "bad mode");
+    if (mode == 1) SAN_CHECK_ARG(off_y == 0 && off_x == 0 && hy - hx >= 0 && hy - hx <= 1 && wy - wx >= 0 && wy - wx <= 1 &&
+                                 hx >= 2 && wx >= 2, "reflect: pads one row / column at the bottom / right");
+    if (mode == 2) SAN_CHECK_ARG(off_y == 0 && off_x == 0 && hx - hy >= 0 && hx - hy <= 1 && wx - wy >= 0 && wx - wy <= 1 &&
+                                 hy >= 2 && wy >= 2, "reflect adjoint: x is the padded plane");
+    WinArgs a{};
+    a.x = x; a.sc = sc; a.sh = sh; a.slope = slope; a.x_ctot = x_ctot; a.x_coff = x_coff; a.hx = hx; a.wx = wx;
+    a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff; a.hy = hy; a.wy = wy; a.off_y = off_y; a.off_x = off_x; a.mode = mode;
+    hipLaunchKernelGGL(window_copy_kernel, ew_grid(hy * wy, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -23,11 +23,12 @@ def env_rank_world() -> Tuple[int, int, int]:
 BACKEND = None   # the backend actually in use (bench.py reports it)
 
 
-def init(backend: str, device=None):
+def init(backend: str, device=None, allow_fallback: bool = False):
     """Initialise torch.distributed if WORLD_SIZE > 1; returns the module or None.
-    backend "nccl" is RCCL on ROCm.  The slice-sharded inference path exchanges only scalars, so
-    if RCCL cannot come up (e.g. IPC disabled on the host) the scalars go over gloo instead of
-    losing the whole multi-GPU run; the choice is recorded in ``BACKEND``."""
+    backend "nccl" is RCCL on ROCm.  RCCL is probed with one all-reduce so that a broken transport fails HERE and not
+    inside a timed region.  A failure raises: a multi-GPU number whose gradients went through the host over gloo would
+    be meaningless.  Only ``allow_fallback=True`` (debugging on a box without working IPC) degrades to gloo, with the
+    gradients staged through the host; ``BACKEND`` records what is in use."""
     global BACKEND
     _, _, world = env_rank_world()
     if world <= 1:
@@ -45,7 +46,10 @@ def init(backend: str, device=None):
             BACKEND = "nccl"
             return dist
         except Exception as e:                     # pragma: no cover (needs a multi-GPU box)
-            print(f"[dist] RCCL unavailable ({type(e).__name__}: {e}); scalars fall back to gloo", flush=True)
+            if not allow_fallback:
+                raise RuntimeError(f"RCCL could not initialise ({type(e).__name__}: {e}); refusing to fall back to gloo "
+                                   "(pass allow_fallback=True to stage gradients through the host)") from e
+            print(f"[dist] RCCL unavailable ({type(e).__name__}: {e}); falling back to gloo", flush=True)
             try:
                 dist.destroy_process_group()
             except Exception:
@@ -90,6 +94,26 @@ def gather_metric_mean(local_sum: float, local_count: int, dist, device="cpu") -
     s = sum_over_ranks(local_sum, dist, device)
     c = sum_over_ranks(float(local_count), dist, device)
     return s / max(c, 1.0)
+
+
+def broadcast0(t: torch.Tensor, dist) -> None:
+    """In-place broadcast of rank 0's tensor (bool buffers travel as uint8; CUDA tensors are staged through the host
+    when only gloo is up)."""
+    if dist is None:
+        return
+    src = t
+    if t.dtype == torch.bool:
+        src = t.to(torch.uint8)
+    if src.is_cuda and BACKEND == "gloo":
+        host = src.cpu()
+        dist.broadcast(host, src=0)
+        src = host.to(t.device)
+    else:
+        if not src.is_contiguous():
+            src = src.contiguous()
+        dist.broadcast(src, src=0)
+    if src is not t:
+        t.copy_(src.to(t.dtype))
 
 
 class GradBucket:

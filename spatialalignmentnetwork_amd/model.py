@@ -39,7 +39,7 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
 class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs"}
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -47,6 +47,9 @@ class CSModel(BaseModel):
         shape, sparsity, coils = cfg.shape, cfg.sparsity, cfg.coils
         get = lambda k, d: cfg[k] if k in cfg else d
         mask = cfg.mask
+        if mask not in masks:
+            raise NotImplementedError(f"mask {mask!r}: only {sorted(masks)} are built (the learned LOUPE / Taylor masks "
+                                      "of masks.py:71-84,127-166 are outside this path)")
         self.net_mask = masks[mask](shape) if mask == "mask" else masks[mask](sparsity, shape)
         self.net_T = SpatialTransformer(channels=coils)
         self.net_R = VarNet(num_cascades=get("num_cascades", 8), sens_chans=get("sens_chans", 8),
@@ -137,6 +140,8 @@ class CSModel(BaseModel):
             self.backward(train_T)
         dist = _active_dist()
         scale = 1.0
+        if dist is not None and not getattr(self, "_replicas_synced", False):
+            self.sync_replicas(dist)            # first data-parallel step: every rank starts from rank 0's state
         if dist is not None:                    # data parallel: one in-place RCCL all-reduce per network;
             for o in opts:                      # the 1/world factor rides in the optimiser kernel
                 o.bucket().allreduce_sum(dist)
@@ -144,6 +149,29 @@ class CSModel(BaseModel):
         for o in opts:
             o.step(grad_scale=scale)
         del self.loss_all
+
+    def sync_replicas(self, dist=None) -> None:
+        """Broadcast rank 0's parameters, AdamW moments, BatchNorm buffers and column mask to every rank (what DDP does
+        at construction).  Without it replicas built from per-process RNG streams would average gradients of DIFFERENT
+        models.  update() calls it before the first data-parallel step; call it again after load()."""
+        dist = dist or _active_dist()
+        if dist is None:
+            return
+        from . import dist as sdist
+        for o in (self.optim_R, self.optim_T):
+            b = o.bucket()
+            for t in (b.flat_p, b.exp_avg, b.exp_avg_sq):
+                sdist.broadcast0(t, dist)
+            steps = torch.tensor([b.steps], dtype=torch.int64, device=b.flat_p.device)
+            sdist.broadcast0(steps, dist)
+            b.steps = int(steps.item())
+        for mod in (self.net_T, self.net_R, self.net_mask):
+            for buf in mod.buffers():
+                sdist.broadcast0(buf, dist)
+        sdist.broadcast0(self.net_mask.weight.data, dist)
+        ops.bump_weight_epoch()                 # packed weight images are stale
+        _KEEP_CACHE.clear()
+        self._replicas_synced = True
 
     def _grad_buckets(self):
         """Flat per-network buffers (p.data / p.grad are views, see dist.ParamBucket)."""
@@ -172,7 +200,9 @@ class CSModel(BaseModel):
         if content in (None, "scalars"):
             vis["scalars"] = {}
             for k, v in self.__dict__.items():
-                if k.startswith("loss_") and v is not None and k != "loss_all":
+                if k.startswith("loss_") and v is not None:
+                    # incl. loss_all, which test() leaves behind (= loss_sim * weight_sim, model.py:270-272,296-300);
+                    # update() deletes it (model.py:262)
                     vis["scalars"][k] = v.detach().item()
                 elif k.startswith("metric_") and v is not None:
                     vis["scalars"][k] = v

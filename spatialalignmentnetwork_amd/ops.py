@@ -579,6 +579,15 @@ def apply(x: Act, y: Act) -> None:
                _p(y.buf), y.ctot, y.coff, x.n, x.c, x.h * x.w, _stream())
 
 
+def window_copy(x: Act, y: Act, off_y: int = 0, off_x: int = 0, mode: int = 0) -> None:
+    """y[.., oy, ox] = T(x)[.., oy - off_y, ox - off_x] between planes of different sizes (san_window_copy_fwd).
+    mode 0: zeros outside x (zero pad with off >= 0, crop with off <= 0); 1: reflect one row / column at the bottom /
+    right; 2: the adjoint of mode 1."""
+    assert x.c == y.c and x.n == y.n
+    lib().call("san_window_copy_fwd", _p(x.buf), x.ctot, x.coff, _p(x.scale), _p(x.shift), float(x.slope), x.h, x.w,
+               _p(y.buf), y.ctot, y.coff, y.h, y.w, int(off_y), int(off_x), int(mode), x.n, x.c, _stream())
+
+
 # ---------------------------------------------------------------------------
 # warp and losses
 # ---------------------------------------------------------------------------

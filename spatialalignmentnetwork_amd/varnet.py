@@ -17,7 +17,6 @@ epilogue.
 """
 from __future__ import annotations
 
-import math
 from typing import Optional
 
 import torch
@@ -92,9 +91,13 @@ class TransposeConvBlock(nn.Module):
             nn.LeakyReLU(negative_slope=0.2, inplace=True),
         )
 
-    def run(self, x: Act, out: Act, tag: str) -> Act:
+    def run(self, x: Act, out: Act, tag: str, also: Optional[Act] = None) -> Act:
+        """``also``: a second view whose (scale, shift) receive the same InstanceNorm affine (the reflect-padded copy
+        of ``out`` inside the concatenation buffer, Unet.run)."""
         part = ops.tconv2x2(x, self.layers[0].weight, out, stats=True, tag=tag)
         ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
+        if also is not None:
+            ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, also.scale, also.shift, also.coff)
         return out
 
     def run_bwd(self, g_out: Act, x: Act, out: Act, g_in: Act) -> None:
@@ -195,10 +198,8 @@ class Unet(nn.Module):
         P = self.num_pool_layers
         n, h, w, dev = x.n, x.h, x.w, x.buf.device
         tape = {"x": x, "blocks": [], "pooled": [], "ups": []}
-        if (h % (1 << P)) or (w % (1 << P)):
-            raise NotImplementedError(
-                f"U-Net input {h}x{w} not divisible by 2^{P}: the reflect-pad path (varnet.py:107-114) "
-                "is not built; NormUnet pads to multiples of 16")
+        if (h >> P) < 1 or (w >> P) < 1:
+            raise ValueError(f"U-Net input {h}x{w} is too small for {P} pooling levels")
         tagp = f"{key}.c{self.chans}"
         cur = x
         cats = []
@@ -211,7 +212,13 @@ class Unet(nn.Module):
             tape["blocks"].append((cur, mid, cat.view(ch, ch)))
             cats.append(cat)
             pooled = Act(ARENA.get(f"{tagp}.pool{i}", (n, ch, hh // 2, ww // 2), dev), 0, ch)
-            ops.avgpool2(cat.view(ch, ch), pooled)
+            if (hh | ww) & 1:
+                # F.avg_pool2d drops the odd last row / column (varnet.py:99): activate + crop, then pool
+                even = Act(ARENA.get(f"{tagp}.even{i}", (n, ch, hh & ~1, ww & ~1), dev), 0, ch)
+                ops.window_copy(cat.view(ch, ch), even)
+                ops.avgpool2(even, pooled)
+            else:
+                ops.avgpool2(cat.view(ch, ch), pooled)
             tape["pooled"].append(pooled)
             cur = pooled
             hh, ww, ch = hh // 2, ww // 2, ch * 2
@@ -221,14 +228,23 @@ class Unet(nn.Module):
         cur = self.conv.run(cur, mid, bot, tagp)
         for i in range(P):
             ch //= 2
-            hh, ww = hh * 2, ww * 2
             lvl = P - 1 - i
             cat = cats[lvl]
-            self.up_transpose_conv[i].run(cur, cat.view(0, ch), tagp)
+            hh, ww = cat.h, cat.w
+            tmp = None
+            if (2 * cur.h, 2 * cur.w) != (hh, ww):
+                # odd size at this level: the transposed conv's output is one row / column short and the reference
+                # reflect-pads it on the bottom / right AFTER its InstanceNorm + LeakyReLU (varnet.py:107-114).  Both
+                # are per-channel maps, so the RAW values are reflected and the affine is shared.
+                tmp = _arena_act(f"{tagp}.tpad{lvl}", n, ch, 2 * cur.h, 2 * cur.w, dev, 0.2)
+                self.up_transpose_conv[i].run(cur, tmp, tagp, also=cat.view(0, ch))
+                ops.window_copy(Act(tmp.buf, 0, ch), Act(cat.buf, 0, ch), mode=1)
+            else:
+                self.up_transpose_conv[i].run(cur, cat.view(0, ch), tagp)
             mid = _arena_act(f"{tagp}.umid{lvl}", n, ch, hh, ww, dev, 0.2)
             up = _arena_act(f"{tagp}.up{lvl}", n, ch, hh, ww, dev, 0.2)
             block = self.up_conv[i] if i < P - 1 else self.up_conv[i][0]
-            tape["ups"].append((cur, cat, mid, up))      # cur = the transposed conv's input
+            tape["ups"].append((cur, cat, mid, up, tmp))      # cur = the transposed conv's input
             cur = block.run(cat, mid, up, tagp)
         last = self.up_conv[P - 1][1]
         ops.conv2d(cur, last.weight, last.bias, out, stats=False, out_scale=out_scale, out_shift=out_shift)
@@ -250,21 +266,26 @@ class Unet(nn.Module):
         # final 1x1 conv (+bias): bias gradient = plane sums of g
         ops.bias_grad_acc(ops.plane_stats(gc, tag="bgrad"), _grad_of(last.bias))
         ops.conv2d_wgrad(cur, gc, _grad_of(last.weight), accumulate=True)
-        g = Act(ARENA.get(f"bwd.g.{cur.c}.{cur.h}", (n, cur.c, cur.h, cur.w), dev), 0, cur.c)
+        g = Act(ARENA.get(f"bwd.g.{cur.c}.{cur.h}.{cur.w}", (n, cur.c, cur.h, cur.w), dev), 0, cur.c)
         ops.conv2d_dgrad(gc, last.weight, g)
         skip_g = [None] * P
         for i in reversed(range(P)):
-            tin, cat, mid, up = tape["ups"][i]
+            tin, cat, mid, up, tmp = tape["ups"][i]
             lvl = P - 1 - i
             ch = up.c
             block = self.up_conv[i] if i < P - 1 else self.up_conv[i][0]
             g_cat = Act(ARENA.get(f"bwd.gcat{lvl}", (n, 2 * ch, cat.h, cat.w), dev), 0, 2 * ch)
             block.run_bwd(g, cat, mid, up, g_cat)
             skip_g[lvl] = g_cat.view(ch, ch)
-            g = Act(ARENA.get(f"bwd.g.{tin.c}.{tin.h}", (n, tin.c, tin.h, tin.w), dev), 0, tin.c)
-            self.up_transpose_conv[i].run_bwd(g_cat.view(0, ch), tin, cat.view(0, ch), g)
+            g = Act(ARENA.get(f"bwd.g.{tin.c}.{tin.h}.{tin.w}", (n, tin.c, tin.h, tin.w), dev), 0, tin.c)
+            if tmp is None:
+                self.up_transpose_conv[i].run_bwd(g_cat.view(0, ch), tin, cat.view(0, ch), g)
+            else:                                            # adjoint of the reflect pad, then the unpadded block
+                g_tmp = Act(ARENA.get(f"bwd.gtpad{lvl}", (n, ch, tmp.h, tmp.w), dev), 0, ch)
+                ops.window_copy(g_cat.view(0, ch), g_tmp, mode=2)
+                self.up_transpose_conv[i].run_bwd(g_tmp, tin, tmp, g)
         bx, bmid, bot = tape["bott"]
-        g_pool = Act(ARENA.get(f"bwd.gp.{bx.c}.{bx.h}", (n, bx.c, bx.h, bx.w), dev), 0, bx.c)
+        g_pool = Act(ARENA.get(f"bwd.gp.{bx.c}.{bx.h}.{bx.w}", (n, bx.c, bx.h, bx.w), dev), 0, bx.c)
         self.conv.run_bwd(g, bx, bmid, bot, g_pool)
         for i in reversed(range(P)):
             bin_, bmid_, bout = tape["blocks"][i]
@@ -272,9 +293,14 @@ class Unet(nn.Module):
             # avg-pool backward (x0.25, nearest up-sampling) + the skip connection's gradient
             sc, sh = _const_affine("bwd.quarter", n, ch, 0.25, dev)
             up = Act(ARENA.get(f"bwd.pup{i}", (n, ch, bout.h, bout.w), dev), 0, ch)
-            ops.upsample2(Act(g_pool.buf, 0, ch, sc, sh, 1.0), up)
+            if (bout.h | bout.w) & 1:                         # the pooled-away odd row / column gets no gradient
+                upe = Act(ARENA.get(f"bwd.pupe{i}", (n, ch, bout.h & ~1, bout.w & ~1), dev), 0, ch)
+                ops.upsample2(Act(g_pool.buf, 0, ch, sc, sh, 1.0), upe)
+                ops.window_copy(upe, up)
+            else:
+                ops.upsample2(Act(g_pool.buf, 0, ch, sc, sh, 1.0), up)
             ops.add(up, skip_g[i], up)
-            g_pool = Act(ARENA.get(f"bwd.gp.{bin_.c}.{bin_.h}", (n, bin_.c, bin_.h, bin_.w), dev), 0, bin_.c)
+            g_pool = Act(ARENA.get(f"bwd.gp.{bin_.c}.{bin_.h}.{bin_.w}", (n, bin_.c, bin_.h, bin_.w), dev), 0, bin_.c)
             self.down_sample_layers[i].run_bwd(up, bin_, bmid_, bout, g_pool)
         return g_pool.buf
 
@@ -315,19 +341,32 @@ class NormUnet(nn.Module):
         part = ops.plane_stats(xin.view(2, 1), tag="ref")
         ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, xin.scale, xin.shift, 2)
 
+    @staticmethod
+    def pad_sizes(h: int, w: int):
+        """(top, left, padded h, padded w): zero padding to multiples of 16, the smaller half first (varnet.py:275-289)."""
+        hp, wp = ((h - 1) | 15) + 1, ((w - 1) | 15) + 1
+        return (hp - h) // 2, (wp - w) // 2, hp, wp
+
     def run(self, xin: Act, out_planar: torch.Tensor, key: str) -> torch.Tensor:
         """xin channels 0,1 hold the planar complex image (raw).  Writes the
         un-normalised planar output [B,2,H,W]."""
         b, h, w = xin.n, xin.h, xin.w
-        if (h % 16) or (w % 16):
-            raise NotImplementedError("NormUnet zero-padding to multiples of 16 (varnet.py:275-289) is not built; "
-                                      f"got {h}x{w}")
         dev = xin.buf.device
         std = ARENA.get(f"{key}.gn_std", (b, 2), dev)
         mean = ARENA.get(f"{key}.gn_mean", (b, 2), dev)
         part = ops.plane_stats(xin.view(0, 2), tag="gn")
         ops.norm_finalize(part, ops.NORM_GROUP, 1e-6, xin.scale, xin.shift, 0, aux_a=std, aux_b=mean)
-        self.unet.run(xin, ops.full(out_planar), out_scale=std, out_shift=mean, key=key)
+        top, left, hp, wp = self.pad_sizes(h, w)
+        if (hp, wp) == (h, w):
+            self.unet.run(xin, ops.full(out_planar), out_scale=std, out_shift=mean, key=key)
+        else:
+            # NormUnet.pad (varnet.py:275-289, 311-319): the NORMALISED image and the normalised reference are zero-padded,
+            # the U-Net runs on the padded planes, the result is cropped (unpad, :291-299) and then un-normalised
+            xpad = Act(ARENA.get(f"{key}.nu_pad", (b, xin.c, hp, wp), dev), 0, xin.c)
+            ops.window_copy(xin, xpad, top, left)
+            upad = ARENA.get(f"{key}.nu_upad", (b, 2, hp, wp), dev)
+            self.unet.run(xpad, ops.full(upad), key=key)
+            ops.window_copy(Act(upad, 0, 2, std, mean, 1.0), ops.full(out_planar), -top, -left)
         self._tapes[key] = (xin, out_planar, std, mean)
         return out_planar
 
@@ -345,11 +384,22 @@ class NormUnet(nn.Module):
         b, h, w, dev = xin.n, xin.h, xin.w, xin.buf.device
         nel = h * w
         g_out = g_out.contiguous()
-        isd = (1.0 / std).contiguous()
+        # a constant plane (e.g. an all-zero slice) has std == 0: U cannot be recovered from U*0 + mean, and torch's
+        # std backward gives that plane no d sigma term at all (san_normunet_bwd_coefs does the same)
+        isd = torch.where(std > 0, 1.0 / std, torch.zeros_like(std)).contiguous()
         part_b = ops.plane_dot_part(ops.full(g_out), Act(out_planar, 0, 2, isd, (-mean * isd).contiguous(), 1.0), "nu.b")
-        g_u = ops.wgrad_dy_buffer("bwd.g_u", (b, 2, h, w), dev, ARENA)
-        ops.apply(Act(g_out, 0, 2, std, ARENA.get("bwd.zero_sh", tuple(std.shape), dev, zero=True), 1.0), ops.full(g_u))
-        g_xh = self.unet.run_bwd(g_u, key)                         # [B, 2 or 3, H, W]
+        zero_sh = ARENA.get("bwd.zero_sh", tuple(std.shape), dev, zero=True)
+        top, left, hp, wp = self.pad_sizes(h, w)
+        if (hp, wp) == (h, w):
+            g_u = ops.wgrad_dy_buffer("bwd.g_u", (b, 2, h, w), dev, ARENA)
+            ops.apply(Act(g_out, 0, 2, std, zero_sh, 1.0), ops.full(g_u))
+            g_xh = self.unet.run_bwd(g_u, key)                     # [B, 2 or 3, H, W]
+        else:
+            g_u = ops.wgrad_dy_buffer("bwd.g_u", (b, 2, hp, wp), dev, ARENA)
+            ops.window_copy(Act(g_out, 0, 2, std, zero_sh, 1.0), ops.full(g_u), top, left)     # adjoint of the crop
+            g_pad = self.unet.run_bwd(g_u, key)
+            g_xh = ARENA.get("bwd.g_xh_crop", (b, xin.c, h, w), dev)
+            ops.window_copy(ops.full(g_pad), ops.full(g_xh), -top, -left)                      # adjoint of the zero pad
         part_a = ops.plane_dot_part(Act(g_xh, 0, 2), xin.view(0, 2), "nu.a")
         a_sc, a_sh, m_sc, m_sh = ops.normunet_bwd_coefs(part_b, part_a, xin, std, nel, g_xh.shape[1])
         g_m = torch.empty((b, 2, h, w), device=dev)
@@ -430,8 +480,22 @@ class VarNetBlock(nn.Module):
         self.dc_weight = nn.Parameter(torch.ones(1))
 
     def sens_expand(self, image: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
-        from .signal_utils import fft2
-        return fft2(_cmul_bcast(image, sens_maps))
+        """fft2(image * sens_maps): image complex [N,1,H,W], sens_maps complex [N,C,H,W] (varnet.py:508-509).  Runs on
+        the fused expand + DC kernel with k = k0 = 0, which yields -fft2(r * S): fed with r = -image (negation is
+        exact) it returns the reference's value."""
+        n, c, h, w = sens_maps.shape
+        assert image.shape == (n, 1, h, w) and torch.is_complex(image)
+        dev = image.device
+        planar = torch.view_as_real(image.contiguous()).permute(0, 1, 4, 2, 3).reshape(n, 2, h, w).contiguous()
+        neg_sc, neg_sh = _const_affine("bwd.neg", n, 2, -1.0, dev)
+        r = torch.empty_like(planar)
+        ops.apply(Act(planar, 0, 2, neg_sc, neg_sh, 1.0), ops.full(r))
+        zeros = ARENA.get("bwd.zero_k", (n, c, h, w), dev, dtype=torch.complex64, zero=True)
+        out = torch.empty((n, c, h, w), device=dev, dtype=torch.complex64)
+        ones = ARENA.get("expand.ones", (w,), dev)
+        ones.fill_(1.0)
+        ops.sens_expand_dc(r, sens_maps.contiguous(), zeros, zeros, ones, self.dc_weight.detach(), out)
+        return out
 
     def sens_reduce(self, kspace: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
         n, c, h, w = kspace.shape
@@ -492,10 +556,6 @@ class VarNetBlock(nn.Module):
         k_out = torch.empty_like(current_kspace)
         return self.run(current_kspace.contiguous(), ref_kspace.contiguous(), mask_f, sens_maps.contiguous(), xin,
                         k_out, "cas")
-
-
-def _cmul_bcast(image: torch.Tensor, sens: torch.Tensor) -> torch.Tensor:
-    raise NotImplementedError("stand-alone sens_expand is exposed through ops.sens_expand_dc (fused with the DC step)")
 
 
 class VarNet(nn.Module):
@@ -570,6 +630,3 @@ class VarNet(nn.Module):
             return None
         return ops.rss_bwd(ref, ref1, g_ref1)            # through ref = rss(ref)
 
-
-def _unused(*_):  # keep math imported for API parity with the reference module
-    return math.pi
