@@ -5,29 +5,35 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic input already
-resident in HBM: CSModel.set_input (fft2 -> column mask -> ifft2 -> rss),
-forwardT (alignment U-Net + bilinear warp + smoothness loss) and forwardR
-(VarNet: sensitivity net + 12 cascades of [ifft2.conj(S).sum -> NormUnet -> fft2
-+ soft DC] + rss, then the SSIM loss), BASELINE.json configs[1]: batch 8 of
-320x320 single-coil slices per GPU, 12 cascades, chans 18, sens_chans 8.
-Slices are independent, so N GPUs run N shards with no data-path collective
-(weak scaling); only the timing is reduced across ranks.
+``python bench.py --gpus N`` with N > 1 and no torch.distributed.run environment re-launches itself under
+``torch.distributed.run`` (one process per GPU, 127.0.0.1 rendezvous); both invocations print the same line.
 
-Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max
-rank time) that also carries
-  roofline      : the dominant kernel (by GPU time inside the timed region),
-                  algorithmic work / HIP-event time of its launches (every 29th
-                  launch of a kernel family is bracketed, run alone on the GPU:
-                  an event pair around each of ~1,700 launches per step costs
-                  ~6 % of the step and would serialise the two streams);
-  roofline_fft_dc: the fused FFT + data-consistency kernels against HBM;
-  cpu_baseline  : the CPU oracle (PyTorch CPU restatement of the reference) timed
-                  on this box's host cores on a bounded sample (rank 0, N=1 only).
+One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+CSModel.set_input (fft2 -> column mask -> ifft2 -> rss) + CSModel.update() = forwardT (alignment U-Net + bilinear warp
++ smoothness loss), forwardR (VarNet: sensitivity net + 12 cascades of [ifft2.conj(S).sum -> NormUnet -> fft2 + soft
+DC] + rss, SSIM loss), the hand-written backward, the RCCL all-reduce of the flat gradient buffers when N > 1, and
+fused AdamW -- BASELINE.json configs[1]: batch 8 of 320x320 single-coil slices per GPU, 12 cascades, chans 18,
+sens_chans 8.  Slices are independent, so N GPUs run N shards (weak scaling); the only data-path collective is the
+gradient all-reduce.  ``--coils 15 --height 640 --width 368 --sparsity 0.125 --batch 1`` names configs[3].
+
+Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max rank time) that also carries
+  roofline       : the dominant kernel family by GPU time inside the timed region.  achieved = ALGORITHMIC work of its
+                   launches (FLOPs the layer needs: 2 N H W Cout Cin k^2; or SURVEY 8(d) bytes) / HIP-event time of
+                   those launches on their stream; peak = the roof of the unit the kernel runs on (dense bf16 MFMA
+                   2.5 PFLOP/s for the bf16x3 kernels, fp32 MFMA 157.3 TFLOP/s, HBM 8 TB/s); frac = achieved / peak.
+                   The bf16x3 kernels execute 6 bf16 products per fp32 MAC: `executed_tflops` and
+                   `frac_of_bf16x3_ceiling` (ceiling = 2500 / 6 = 416.7 TFLOP/s fp32-equivalent) are extras.
+                   Every 29th launch of a family is bracketed and run alone (an event pair around each of ~1,700
+                   launches per step costs ~6 % of the step and would serialise the two streams).
+  roofline_*     : the same for the fused FFT + data-consistency kernels (HBM) and the other conv families.
+  cpu_baseline   : the CPU oracle (PyTorch CPU restatement of the reference, same ATen kernels) timed on this box's
+                   host cores: the same step incl. torch.optim.AdamW, N = 1 and N = 8, all usable cores and 1 thread.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,17 +44,58 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
-BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak; the bf16x3 convolution executes 6 bf16 products per fp32 MAC
+BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak
+BF16X3_PRODUCTS = 6.0        # bf16 products the bf16x3 kernels execute per fp32 MAC
 
 
-def build_model(n_per_gpu, h, w, num_cascades, dev, seed=0):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="slices per GPU")
+    ap.add_argument("--size", type=int, default=320, help="height = width (overridden by --height / --width)")
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--coils", type=int, default=1)
+    ap.add_argument("--sparsity", type=float, default=0.25, help="0.25 = 4x, 0.125 = 8x equispaced mask")
+    ap.add_argument("--cascades", type=int, default=12)
+    ap.add_argument("--mode", choices=["infer", "train"], default="train",
+                    help="train (default): the full optimisation step incl. the gradient all-reduce; infer: forward only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step into a hipGraph and time replays (no per-kernel timer in that mode)")
+    ap.add_argument("--launch-test", action="store_true",
+                    help="(CPU) exercise only the launcher: rendezvous over gloo, barrier, max-over-ranks, one JSON line")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: re-exec under it, one process per GPU."""
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
+
+
+def build_model(n_per_gpu, h, w, num_cascades, dev, seed=0, coils=1, sparsity=0.25):
     from spatialalignmentnetwork_amd import synth
     from spatialalignmentnetwork_amd.basemodel import Config
     from spatialalignmentnetwork_amd.model import CSModel
-    cfg = Config(sparsity=0.25, lr=1e-4, shape=w, coils=1, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+    cfg = Config(sparsity=sparsity, lr=1e-4, shape=w, coils=coils, reg="Rec", mask="equispaced", weight_smooth=1000.0,
                  weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=num_cascades)
     net = CSModel(cfg)
-    net.net_mask.pruned = synth.equispaced_pruned(w, 0.25, 0)
+    net.net_mask.pruned = synth.equispaced_pruned(w, sparsity, 0)
     # random-init weights of the reference's architecture (no checkpoints offline), deterministic per name
     for sub, sd in (("net_T", 1), ("net_R", 2)):
         m = getattr(net, sub)
@@ -86,81 +133,151 @@ def usable_cores(cap=32):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(num_cascades, h, w, mode="infer", budget_s=15.0):
-    """The oracle on host cores: same arithmetic as the reference's CPU path
-    (same ATen kernels), N=1 slices one at a time until ~budget_s is spent.
-    mode 'train' times forward + autograd backward of the 'Rec' objective (no optimiser step)."""
+def cpu_baseline(num_cascades, h, w, mode="train", coils=1, sparsity=0.25, batch=8, budget_s=24.0):
+    """The oracle on host cores: the same arithmetic as the reference's CPU path (same ATen
+    kernels).  Train mode = forward + autograd backward + torch.optim.AdamW step for both networks (model.py:206-216),
+    i.e. the same work as the GPU leg.  Legs: N = 1 on all usable cores, N = `batch` on all usable cores, N = 1 on one
+    thread; each leg runs whole steps until its share of ~budget_s is spent (at least one)."""
     from oracle import cpu_ref as O
     from spatialalignmentnetwork_amd import synth
     from spatialalignmentnetwork_amd.cross import SpatialTransformer
     from spatialalignmentnetwork_amd.varnet import VarNet
     cores = usable_cores()
-    torch.set_num_threads(cores)
-    t_shapes = [(k, tuple(v.shape)) for k, v in SpatialTransformer(1).state_dict().items()]
+    t_shapes = [(k, tuple(v.shape)) for k, v in SpatialTransformer(coils).state_dict().items()]
     r_shapes = [(k, tuple(v.shape)) for k, v in VarNet(num_cascades=num_cascades, use_ref=True).state_dict().items()]
     pT, pR = synth.fill_params(t_shapes, seed=1), synth.fill_params(r_shapes, seed=2)
-    img_full, img_aux = synth.phantom_pair(1, 1, h, w, seed=1234)
-    pruned = synth.equispaced_pruned(w, 0.25, 0)
+    pruned = synth.equispaced_pruned(w, sparsity, 0)
     train = mode == "train"
+    opts = []
     if train:
         for d in (pT, pR):
+            leaves = []
             for k, v in d.items():
                 if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
                     v.requires_grad_(True)
+                    leaves.append(v)
+            opts.append(torch.optim.AdamW(leaves, lr=1e-4, weight_decay=0))
+    data = {n: synth.phantom_pair(n, coils, h, w, seed=1234) for n in sorted({1, batch})}
 
-    def run():
-        o = O.recon_align_forward(pT, pR, img_full, img_aux, pruned, shape=w, sparsity=0.25,
-                                  num_cascades=num_cascades, training=train)
+    def run(n):
+        img_full, img_aux = data[n]
+        o = O.recon_align_forward(pT, pR, img_full, img_aux, pruned, shape=w, sparsity=sparsity,
+                                  num_cascades=num_cascades, training=train, state=O.BNState() if train else None)
         if train:
+            for op in opts:
+                op.zero_grad()
             o["loss_all"].backward()
+            for op in opts:
+                op.step()
 
-    warm = lambda: O.recon_align_forward(pT, pR, img_full, img_aux, pruned, shape=w, sparsity=0.25, num_cascades=1)
+    legs = []
     with torch.set_grad_enabled(train):
-        warm()                      # warm-up on a 1-cascade pass (thread pools, oneDNN primitives)
-        t0 = time.perf_counter()
-        done = 0
-        while True:
-            run()
-            done += 1
-            if time.perf_counter() - t0 > budget_s or done >= 256:
-                break
-        dt = time.perf_counter() - t0
-    what = "forward + autograd backward (no optimiser step)" if train else "forward"
-    return {"value": done / dt, "unit": "slices/s", "cores": cores, "kind": "port",
-            "sample": f"{done} slice(s) of the same workload ({what}), one at a time (N=1), 1 warm-up, "
-                      f"{dt:.1f} s of CPU work"}
+        torch.set_num_threads(cores)
+        run(1)                                           # one full warm-up step (thread pool, oneDNN primitives)
+        for n, threads, share in ((1, cores, 0.25), (batch, cores, 0.40), (1, 1, 0.35)):
+            if (n, threads) in [(lg["n"], lg["threads"]) for lg in legs]:
+                continue
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            done = 0
+            while True:
+                run(n)
+                done += 1
+                if time.perf_counter() - t0 > budget_s * share or done >= 64:
+                    break
+            dt = time.perf_counter() - t0
+            legs.append({"n": n, "threads": threads, "steps": done, "seconds": round(dt, 2), "slices_per_s": n * done / dt})
+        torch.set_num_threads(cores)
+    best = max((lg for lg in legs if lg["threads"] == cores), key=lambda lg: lg["slices_per_s"])
+    one = [lg for lg in legs if lg["threads"] == 1]
+    what = "forward + autograd backward + torch.optim.AdamW step" if train else "forward"
+    return {"value": best["slices_per_s"], "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"whole steps of the same workload ({what}; {num_cascades} cascades, {coils} coil(s), {h}x{w}) after one "
+                      f"full warm-up step: " + "; ".join(f"N={lg['n']} on {lg['threads']} thread(s): {lg['steps']} step(s) in "
+                                                          f"{lg['seconds']} s" for lg in legs) + f"; value = the best all-core leg (N={best['n']})",
+            "legs": legs, "single_thread": one[0]["slices_per_s"] if one else None}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="slices per GPU")
-    ap.add_argument("--size", type=int, default=320)
-    ap.add_argument("--cascades", type=int, default=12)
-    ap.add_argument("--mode", choices=["infer", "train"], default="train",
-                    help="train (default): the full optimisation step incl. the gradient all-reduce; infer: forward only")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture the step into a hipGraph and time replays (no per-kernel timer in that mode)")
-    args = ap.parse_args()
+def launch_test(args):
+    """CPU check of the launcher contract: env rendezvous, barrier, max-over-ranks, rank 0 prints one line."""
+    from spatialalignmentnetwork_amd import dist as sdist
+    rank, local_rank, world = sdist.env_rank_world()
+    dist = sdist.init("gloo")
+    lo, hi = sdist.shard_bounds(args.batch * world, rank, world)
+    t = sdist.max_over_ranks(1.0 + rank, dist)
+    tot = sdist.sum_over_ranks(float(hi - lo), dist)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_test": True, "n_gpus": world, "backend": sdist.BACKEND, "max_over_ranks": t,
+                          "global_batch": tot}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def roofline_entry(key, d, dt, steps, pmc, match_profile):
+    """One roofline object from a KernelTimer family record (see the module docstring for the definitions)."""
+    sec = d["ms"] * 1e-3                       # rate over the bracketed launches, applied to all launches
+    extra = {}
+    per_launch = d["work"] / d["launches"]
+    if d["unit"] == "FLOP":
+        ach = d["work"] / sec / 1e12           # ALGORITHMIC TFLOP/s
+        if key.endswith("_bf16x3"):
+            peak = BF16_PEAK_TFLOPS
+            extra = {"dtype": "bf16 matrix cores, operands split in three (6 bf16 products per fp32 MAC)",
+                     "executed_tflops": BF16X3_PRODUCTS * ach, "executed_frac": BF16X3_PRODUCTS * ach / peak,
+                     "bf16x3_ceiling_tflops": peak / BF16X3_PRODUCTS,
+                     "frac_of_bf16x3_ceiling": ach / (peak / BF16X3_PRODUCTS)}
+        else:
+            peak = FP32_PEAK_TFLOPS
+            extra = {"dtype": "fp32 MFMA"}
+        unit, bound = "TFLOP/s", "mfma"
+        extra["algorithmic_flops_per_launch"] = per_launch
+    else:
+        ach, peak, unit, bound = d["work"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+    p = (pmc.get(key) or {}) if match_profile else {}
+    out = {"kernel": key, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+           "traffic": p.get("hbm_bytes_per_launch"),
+           "traffic_source": p.get("source"),
+           "algorithmic_bytes": p.get("algorithmic_bytes_per_launch") if d["unit"] == "FLOP" else per_launch,
+           "mfma_busy": p.get("mfma_busy"),
+           "launches": d["launches"], "timed_launches": d["sampled_launches"],
+           "avg_launch_us": 1e3 * d["sampled_ms"] / d["sampled_launches"],
+           "share_of_step": d["ms"] / (1e3 * dt), **extra}
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
 
     from spatialalignmentnetwork_amd import dist as sdist
     rank, local_rank, world = sdist.env_rank_world()
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} processes (WORLD_SIZE={world})")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
+    if args.launch_test:
+        return launch_test(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = sdist.init("nccl", dev)      # RCCL; None when world == 1
+    dist = sdist.init("nccl", dev)      # RCCL; None when world == 1; raises (rc != 0) if RCCL cannot come up
+    nccl_ranks = None
+    if dist is not None:
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        nccl_ranks = int(ones.item())
+        assert nccl_ranks == world, (nccl_ranks, world)
 
     from spatialalignmentnetwork_amd import ops, synth
-    n, h, w = args.batch, args.size, args.size
-    net = build_model(n, h, w, args.cascades, dev)
-    img_full, img_aux = synth.phantom_pair(n, 1, h, w, seed=1234 + rank)
+    n = args.batch
+    h = args.height or args.size
+    w = args.width or args.size
+    c = args.coils
+    net = build_model(n, h, w, args.cascades, dev, coils=c, sparsity=args.sparsity)
+    img_full, img_aux = synth.phantom_pair(n, c, h, w, seed=1234 + rank)
     img_full, img_aux = img_full.to(dev), img_aux.to(dev)
 
     def barrier():
@@ -223,62 +340,52 @@ def main():
         infer = {"value": n * world * args.steps / dti, "unit": "slices/s", "ms_per_step": 1e3 * dti / args.steps}
     if rank == 0:
         total_slices = n * world * args.steps
+        acc = int(round(1.0 / args.sparsity))
+        coil_txt = "single-coil" if c == 1 else f"{c}-coil (sensitivity-map VarNet)"
         out = {
             "metric": "slices/sec (320x320, 12-cascade VarNet+align)", "value": total_slices / dt, "unit": "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (convolutions from 16-18 channels up and all weight gradients: bf16 matrix cores, operands split in three, six products per MAC, fp32-equivalent; FFT / DC / norms / losses fp32)", "data": "synthetic",
-            "config": {"workload": ("train step (regime Rec: fwd + hand-written bwd + grad all-reduce + AdamW) " if args.mode == "train" else "inference pass ") + f"set_input+align+warp+VarNet{args.cascades}+SSIM, "
-                                   f"{n} slices/GPU of {h}x{w} single-coil, 4x equispaced mask, random-init weights",
-                       "slices_per_gpu": n, "global_batch": n * world, "cascades": args.cascades,
-                       "parallelism": f"dp{world} (independent slice shards, no data-path collective)",
-                       "scalar_backend": sdist.BACKEND},
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (convolutions from 16-18 channels up and all weight gradients: bf16 matrix cores, operands split "
+                     "in three, six products per MAC, fp32-equivalent; FFT / DC / norms / losses fp32)",
+            "data": "synthetic",
+            "config": {"workload": ("train step (regime Rec: fwd + hand-written bwd + grad all-reduce + AdamW) " if args.mode == "train"
+                                    else "inference pass ") + f"set_input+align+warp+VarNet{args.cascades}+SSIM, "
+                                   f"{n} slices/GPU of {h}x{w} {coil_txt}, {acc}x equispaced mask, random-init weights",
+                       "slices_per_gpu": n, "global_batch": n * world, "cascades": args.cascades, "coils": c,
+                       "height": h, "width": w, "acceleration": acc,
+                       "parallelism": f"dp{world} (independent slice shards; one RCCL all-reduce of the flat gradient "
+                                      f"buffers per step)" if args.mode == "train" else
+                                      f"dp{world} (independent slice shards, no data-path collective)",
+                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks},
         }
         if infer is not None:
             out["inference"] = infer
         if timer is not None:
             tot = timer.totals()
             dom = max(tot, key=lambda k: tot[k]["ms"])
-            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE / WRITE_SIZE collected in two
-            # separate rocprofv3 runs of this workload and corrected as profiles/r01_pmc_traffic.json states);
-            # bench.py itself cannot run the profiler, so this is the profile's figure, not a live one
-            pmc = {}
-            try:
-                pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
-                                                  "r01_pmc_traffic.json")))["kernels"]
-            except (OSError, KeyError, ValueError):
-                pass
+            # HBM bytes per launch, algorithmic bytes and MFMA-busy fractions from the committed PMC passes of THIS workload
+            # (separate rocprofv3 --pmc runs, corrected as the file states); bench.py itself cannot run the profiler
+            pmc, pmc_file = {}, None
+            for cand in ("r02_pmc.json", "r01_pmc_traffic.json"):
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
+                    pmc_file = cand
+                    break
+                except (OSError, KeyError, ValueError):
+                    continue
+            for v in pmc.values():
+                v.setdefault("source", f"profiles/{pmc_file}")
+            match = args.mode == "train" and (n, h, w, c, args.cascades) == (8, 320, 320, 1, 12)
             for key, field in ((dom, "roofline"), ("fft_dc", "roofline_fft_dc"), ("conv3x3", "roofline_conv_fp32"),
                                ("conv3x3_bf16x3", "roofline_conv_bf16x3"), ("wgrad3x3_bf16x3", "roofline_wgrad_bf16x3"),
                                ("wgrad3x3", "roofline_wgrad_fp32")):
-                if key not in tot or (field != "roofline" and key == dom):
+                if key not in tot or (field != "roofline" and key == dom) or tot[key]["sampled_launches"] == 0:
                     continue
-                d = tot[key]
-                if d["sampled_launches"] == 0:
-                    continue
-                # rate over the bracketed launches (every 29th of the family); "ms" is that rate applied to all launches
-                sec = d["ms"] * 1e-3
-                extra = {}
-                if key in ("conv3x3_bf16x3", "wgrad3x3_bf16x3"):
-                    # algorithmic (fp32) FLOPs are what the layer needs; the kernel issues six bf16 products per MAC,
-                    # so against the bf16 roof the matrix pipe sees 6x that
-                    ach, peak, unit, bound = 6.0 * d["work"] / sec / 1e12, BF16_PEAK_TFLOPS, "TFLOP/s", "mfma"
-                    extra = {"dtype": "bf16 (3-way split operands, 6 products per fp32 MAC)",
-                             "algorithmic_tflops": d["work"] / sec / 1e12}
-                elif d["unit"] == "FLOP":
-                    ach, peak, unit, bound = d["work"] / sec / 1e12, FP32_PEAK_TFLOPS, "TFLOP/s", "mfma"
-                else:
-                    ach, peak, unit, bound = d["work"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
-                out[field] = {"kernel": key, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                              "frac": ach / peak,
-                              "traffic": (pmc.get(key) or {}).get("hbm_bytes_per_launch") if args.mode == "train" and
-                              (n, h, args.cascades) == (8, 320, 12) else None,
-                              "traffic_source": "profiles/r01_pmc_traffic.json" if key in pmc else None,
-                              "launches": d["launches"], "timed_launches": d["sampled_launches"],
-                              "avg_launch_us": 1e3 * d["sampled_ms"] / d["sampled_launches"],
-                              "share_of_step": d["ms"] / (1e3 * dt), **extra}
+                out[field] = roofline_entry(key, tot[key], dt, args.steps, pmc, match)
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode)
+            out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -72,9 +72,9 @@ def npy(t):
     return t.numpy()
 
 
-def load_into(module, seed):
+def load_into(module, seed, damp=1.0):
     sd = module.state_dict()
-    vals = synth.fill_params([(k, tuple(v.shape)) for k, v in sd.items()], seed=seed)
+    vals = synth.fill_params([(k, tuple(v.shape)) for k, v in sd.items()], seed=seed, damp=damp)
     module.load_state_dict(vals)
     return vals
 
@@ -327,8 +327,300 @@ def make_ckpt():
     print("wrote", folder, sorted(os.listdir(folder)), sum(os.path.getsize(os.path.join(folder, f)) for f in os.listdir(folder)) // 1024, "KiB")
 
 
+# ---------------------------------------------------------------------------
+# round 2 additions
+# ---------------------------------------------------------------------------
+def probe_idx(name, numel, k=16):
+    """The flat indices at which a tensor is sampled for the compact gradient fixtures (tests regenerate them)."""
+    return synth._rng("probe." + name, 0).integers(0, numel, k)
+
+
+def grad_digest(named_grads):
+    """{name: grad} -> (names, l2 [T], probes [T, 16], numel [T]) -- per-tensor L2 norm and 16 probe values."""
+    names, l2, pr, ne = [], [], [], []
+    for nm, g in named_grads:
+        g = g.detach().double().reshape(-1)
+        names.append(nm)
+        l2.append(g.norm().item())
+        pr.append(g[torch.from_numpy(probe_idx(nm, g.numel()))].numpy())
+        ne.append(g.numel())
+    return np.array(names), np.asarray(l2), np.stack(pr), np.asarray(ne)
+
+
+def make_layers():
+    """One VarNetBlock step (varnet.py:514-530), the alignment backbone's Conv2d / Up / Down factories (unet.py:119-140)
+    in eval and train mode, StandardMask for seeded draws (masks.py:48-69)."""
+    import unet as R_unet
+    out = {}
+    # one VarNetBlock step with a real regulariser
+    blk = R_varnet.VarNetBlock(R_varnet.NormUnet(4, 2, use_ref=True))
+    load_into(blk, 21)
+    k = cplx("vb.k", (2, 3, 32, 48))
+    k0 = cplx("vb.k0", (2, 3, 32, 48))
+    sens = cplx("vb.s", (2, 3, 32, 48))
+    sens = sens / (R_sig.rss(sens) + 1e-6)
+    ref = philox("vb.ref", (2, 1, 32, 48), lo=0.0, hi=1.0)
+    mask = torch.zeros(1, 1, 1, 48, dtype=torch.bool)
+    mask[..., ::3] = True
+    mask[..., :4] = True
+    with torch.no_grad():
+        out["varnetblock"] = npy(blk(k, k0, mask, sens, ref))
+    out["varnetblock.mask"] = mask.reshape(-1).numpy()
+    # alignment-network building blocks
+    for tag, fac, cin, cout, shp in (("conv2d", R_unet.Conv2d, 6, 16, (2, 6, 24, 40)), ("up", R_unet.Up, 16, 24, (2, 16, 12, 20)),
+                                     ("down", R_unet.Down, 24, 16, (2, 24, 24, 40))):
+        m = fac(cin, cout)
+        load_into(m, 31)
+        x = philox("stl." + tag, shp)
+        m.eval()
+        with torch.no_grad():
+            out[f"st.{tag}.eval"] = npy(m(x))
+        m.train()
+        with torch.no_grad():
+            out[f"st.{tag}.train"] = npy(m(x))
+        bn = [mm for mm in m if isinstance(mm, torch.nn.BatchNorm2d)][0]
+        out[f"st.{tag}.running_mean"], out[f"st.{tag}.running_var"] = npy(bn.running_mean), npy(bn.running_var)
+    # StandardMask: torch.manual_seed makes the draw reproducible (same torch build in tests)
+    for w, sp, seed in ((320, 0.25, 1), (320, 0.125, 2), (368, 0.125, 3)):
+        torch.manual_seed(seed)
+        out[f"standard_{w}_{int(1 / sp)}_seed{seed}"] = R_masks.StandardMask(sp, w).pruned.numpy()
+    save("layers_small.npz", **out)
+
+
+def make_pad():
+    """Shapes that are NOT multiples of 16: NormUnet.pad / unpad (varnet.py:275-299) and the U-Net's reflect pad for
+    odd sizes (varnet.py:107-114), forward and gradients."""
+    out = {}
+    # (a) NormUnet with ref at 50 x 70 (zero pad to 64 x 80), gradients wrt parameters, input and reference
+    nu = R_varnet.NormUnet(4, 2, use_ref=True)
+    load_into(nu, 51)
+    x = cplx("pad.x", (2, 1, 50, 70)).requires_grad_(True)
+    ref = philox("pad.ref", (2, 1, 50, 70), lo=0.0, hi=1.0).requires_grad_(True)
+    y = nu(x, ref)
+    wgt = cplx("pad.w", (2, 1, 50, 70))
+    (y * wgt.conj()).real.sum().backward()
+    out["nu.y"], out["nu.gx"], out["nu.gref"] = npy(y), npy(x.grad), npy(ref.grad)
+    for nm, prm in nu.named_parameters():
+        out["nu.grad." + nm] = prm.grad.numpy()
+    # (b) bare U-Net at 25 x 35, 2 pooling levels: 25 -> 12 -> 6, up 12 -> 24 (+1 reflected) at both axes, 35 -> 17 -> 8
+    un = R_varnet.Unet(3, 2, chans=4, num_pool_layers=2)
+    load_into(un, 52)
+    xi = philox("pad.u", (2, 3, 25, 35)).requires_grad_(True)
+    yo = un(xi)
+    (yo * philox("pad.uw", (2, 2, 25, 35))).sum().backward()
+    out["un.y"], out["un.gx"] = npy(yo), npy(xi.grad)
+    for nm, prm in un.named_parameters():
+        out["un.grad." + nm] = prm.grad.numpy()
+    # (c) VarNet (2 cascades, 2 coils) at 50 x 70 through the sensitivity net, eval
+    vn = R_varnet.VarNet(num_cascades=2, sens_chans=2, sens_pools=2, chans=4, pools=2, use_ref=True)
+    load_into(vn, 53)
+    vn.eval()
+    img, _ = synth.phantom_pair(2, 2, 50, 70, seed=54)
+    pruned = synth.equispaced_pruned(70, 0.25, 0)
+    ks = R_sig.fft2(img) * (1 - pruned.float())
+    refv = philox("pad.vref", (2, 2, 50, 70), lo=0.0, hi=1.0)
+    with torch.no_grad():
+        out["vn.rec"] = npy(vn(ks, torch.logical_not(pruned), refv, int(70 * 0.25 * 0.32)))
+    save("pad_small.npz", **out)
+
+
+def _skimage_standin():
+    """skimage is absent from this image.  For the CSModel scalar fixture ONLY, its two functions the reference calls
+    (metrics.py:35-44) are stood in by their published definitions: peak_signal_noise_ratio = 10 log10(R^2 / mse) over
+    the whole array; structural_similarity = Wang et al. with a 7x7 uniform filter, K1 = 0.01, K2 = 0.03, sample
+    covariance, borders of 3 cropped.  metric_PSNR / metric_SSIM in the fixture are therefore definition-pinned, not
+    skimage-pinned; every other scalar is the reference's own arithmetic."""
+    import types
+    from scipy.ndimage import uniform_filter
+
+    def psnr(gt, pred, data_range=None):
+        err = np.mean((np.asarray(gt, dtype=np.float64) - np.asarray(pred, dtype=np.float64)) ** 2)
+        return 10 * np.log10((data_range ** 2) / err)
+
+    def ssim(im1, im2, data_range=None):
+        win, K1, K2 = 7, 0.01, 0.03
+        im1, im2 = im1.astype(np.float64), im2.astype(np.float64)
+        NP = win ** 2
+        cov_norm = NP / (NP - 1)
+        ux, uy = uniform_filter(im1, size=win), uniform_filter(im2, size=win)
+        uxx, uyy, uxy = uniform_filter(im1 * im1, size=win), uniform_filter(im2 * im2, size=win), uniform_filter(im1 * im2, size=win)
+        vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+        C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+        S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+        pad = (win - 1) // 2
+        return S[pad:-pad, pad:-pad].mean()
+
+    skm = sys.modules["skimage.metrics"]
+    skm.peak_signal_noise_ratio, skm.structural_similarity = psnr, ssim
+    import metrics as R_met
+    R_met.compare_psnr, R_met.compare_ssim = psnr, ssim
+
+
+def make_scalars():
+    """CSModel.set_input -> test() -> get_vis('scalars') of the REFERENCE's CSModel (model.py:265-306) on CPU, N = 2,
+    64 x 64, its hard-coded 8-cascade VarNet; plus the images eval.py reads (eval.py:69-70)."""
+    _skimage_standin()
+    import basemodel as R_base
+    shape = 64
+    cfg = R_base.Config(sparsity=0.25, lr=1e-4, shape=shape, coils=1, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                        weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = R_model.CSModel(cfg)
+    net.net_mask.pruned = synth.equispaced_pruned(shape, 0.25, 0)
+    load_into(net.net_T, 61)
+    load_into(net.net_R, 62)
+    net.eval()
+    img_full, img_aux = synth.phantom_pair(2, 1, shape, shape, seed=63)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net.set_input(img_full, img_aux)
+        ret = net.test()
+        vis = net.get_vis("scalars")["scalars"]
+    out = {"scalar." + k: np.float64(v) for k, v in vis.items()}
+    out["return"] = np.float64(ret)
+    for k in ("img_full_rss", "img_sampled_rss", "img_aux_rss", "img_warped_rss", "img_rec", "img_offset", "img_mask"):
+        out[k] = npy(getattr(net, k))
+    print("reference scalars:", vis)
+    save("csmodel_scalars.npz", **out)
+
+
+def _rec_step(n, c, h, w, sparsity, num_cascades, seed, dtype=torch.float32, damp=1.0):
+    """Train-mode 'Rec' step of the reference's modules (model.py:206-216) at the full network width."""
+    img_full, img_aux = synth.phantom_pair(n, c, h, w, seed=seed)
+    pruned = synth.equispaced_pruned(w, sparsity, start=0)
+    net_T = R_cross.SpatialTransformer(channels=c)
+    net_R = R_varnet.VarNet(num_cascades=num_cascades, sens_chans=8, sens_pools=4, chans=18, pools=4, use_ref=True)
+    load_into(net_T, seed + 1)
+    load_into(net_R, seed + 2, damp=damp)
+    cd = torch.complex64
+    if dtype == torch.float64:
+        net_T, net_R, cd = net_T.double(), net_R.double(), torch.complex128
+        img_full, img_aux = img_full.to(cd), img_aux.to(cd)
+    net_T.train()
+    net_R.train()
+    k_samp = R_sig.fft2(img_full) * (1 - pruned.to(dtype))
+    samp = R_sig.ifft2(k_samp)
+    offset, grid = net_T(moving=img_aux.abs(), fixed=samp.abs())
+    if dtype == torch.float64:      # SpatialTransformer.warp force-casts to fp32 (cross.py:33-34): bypass for the arbiter
+        warped = torch.nn.functional.grid_sample(img_aux.abs(), grid, align_corners=False)
+    else:
+        warped = net_T.warp(img_aux.abs(), grid)
+    loss_smooth = R_gradient_loss(offset)
+    rec = net_R(masked_kspace=k_samp, mask=torch.logical_not(pruned), ref=warped, num_low_frequencies=int(w * sparsity * 0.32))
+    loss_sim = R_ssim.ssimloss(R_sig.rss(img_full), rec)
+    loss = loss_smooth * 1000.0 + loss_sim * 1.0
+    loss.backward()
+    return net_T, net_R, dict(img_warped=warped, img_rec=rec, img_offset=offset, loss_smooth=loss_smooth, loss_sim=loss_sim,
+                              loss_all=loss)
+
+
+def _digest_step(out, pre, net_T, net_R, res):
+    for k_ in ("loss_smooth", "loss_sim", "loss_all"):
+        out[pre + k_] = np.float64(res[k_].item())
+    for tag, net in (("T", net_T), ("R", net_R)):
+        names, l2, pr, ne = grad_digest([(nm, p_.grad) for nm, p_ in net.named_parameters()])
+        out[f"{pre}grad.{tag}.names"], out[f"{pre}grad.{tag}.l2"], out[f"{pre}grad.{tag}.probes"] = names, l2, pr
+        out[f"{pre}grad.{tag}.numel"] = ne
+
+
+def make_train_full(with_f64=True):
+    """Config-2 shape train step: N = 2, 320 x 320, 12 cascades, chans 18 (model.py:206-216), fp32 as the reference
+    runs it, and the same step in fp64 as arbiter.  Gradients are stored as per-tensor L2 norms + 16 probes.
+    Two weight sets: 'raw' (the default random weights: O(1) cascade maps, rounding noise amplified ~1e3-1e4x, the
+    reference's own fp32 / fp64 gradients differ by 16 %) and 'damped' (cascade output convolutions x 0.1: each cascade
+    is a small correction as in a trained network, so fp32 noise stays near 1e-6 and the bars can be tight)."""
+    import time
+    out = {}
+    for tag, damp in (("raw", 1.0), ("damped", 0.1)):
+        t0 = time.time()
+        net_T, net_R, res = _rec_step(2, 1, 320, 320, 0.25, 12, seed=2234, damp=damp)
+        print(f"[{tag}] fp32 reference step: {time.time() - t0:.0f} s")
+        _digest_step(out, f"{tag}.f32.", net_T, net_R, res)
+        out[f"{tag}.f32.img_rec"] = npy(res["img_rec"]).astype(np.float32)
+        if tag == "raw":
+            out["f32.img_warped"] = npy(res["img_warped"]).astype(np.float32)
+            for nm, buf in net_T.named_buffers():
+                if nm.endswith(("running_mean", "running_var")):
+                    out["f32.bn_after.T." + nm] = buf.numpy()
+        if not with_f64:
+            continue
+        t0 = time.time()
+        net_T64, net_R64, res64 = _rec_step(2, 1, 320, 320, 0.25, 12, seed=2234, dtype=torch.float64, damp=damp)
+        print(f"[{tag}] fp64 reference step: {time.time() - t0:.0f} s")
+        _digest_step(out, f"{tag}.f64.", net_T64, net_R64, res64)
+        out[f"{tag}.f64.img_rec"] = npy(res64["img_rec"]).astype(np.float64)
+        for nt, a, b in (("T", net_T, net_T64), ("R", net_R, net_R64)):
+            num = sum(((p.grad.double() - q.grad) ** 2).sum().item() for p, q in zip(a.parameters(), b.parameters()))
+            den = sum((q.grad ** 2).sum().item() for q in b.parameters())
+            print(f"[{tag}] reference fp32 vs fp64 gradients, net_{nt}: relative L2 {(num / den) ** 0.5:.3e}")
+            out[f"{tag}.ref32_vs_ref64.grad.{nt}"] = np.float64((num / den) ** 0.5)
+        r32, r64 = res["img_rec"].detach().double(), res64["img_rec"].detach()
+        out[f"{tag}.ref32_vs_ref64.img_rec"] = np.float64(((r32 - r64).norm() / r64.norm()).item())
+        print(f"[{tag}] reference fp32 vs fp64 rec:", out[f"{tag}.ref32_vs_ref64.img_rec"])
+    save("train_full_320.npz", **out)
+
+
+def make_multicoil():
+    """Config 4: one 640 x 368 slice with 15 coils, 8x equispaced mask (46 kept columns, nlf = 14), sensitivity-map
+    VarNet with 12 cascades + the 30-channel alignment net.  (a) eval forward with fp64 arbiter; (b) a 2-cascade train
+    step with gradients as per-tensor digests."""
+    import time
+    n, c, h, w, sp = 1, 15, 640, 368, 0.125
+    out = {}
+    t0 = time.time()
+    net_T, net_R, img_full, img_aux, pruned, res = run_pair_full(n, c, h, w, sp, 12, seed=3234, training=False)
+    print(f"multi-coil fp32 forward: {time.time() - t0:.0f} s")
+    out["pruned"] = pruned.numpy()
+    out["img_rec"] = npy(res["img_rec"])
+    out["img_warped_rss"] = npy(R_sig.rss(res["img_warped"]))
+    out["img_offset_s4"] = npy(res["img_offset"][:, ::4, ::4].contiguous())
+    out["loss_sim"], out["loss_smooth"] = npy(res["loss_sim"]), npy(res["loss_smooth"])
+    sens_sums, cas_sums = [], []
+    hk = [net_R.sens_net.register_forward_hook(lambda m, i, o: sens_sums.append(
+        np.stack([o.real.double().sum((0, 2, 3)).numpy(), o.imag.double().sum((0, 2, 3)).numpy(),
+                  o.abs().double().pow(2).sum((0, 2, 3)).sqrt().numpy()], 1)))]
+    hk += [cas.register_forward_hook(lambda m, i, o: cas_sums.append(
+        [o.real.double().sum().item(), o.imag.double().sum().item(), o.abs().double().pow(2).sum().sqrt().item()]))
+        for cas in net_R.cascades]
+    with torch.no_grad():
+        net_R(masked_kspace=res["img_k_sampled"], mask=torch.logical_not(pruned), ref=res["img_warped"],
+              num_low_frequencies=int(w * sp * 0.32))
+    for x in hk:
+        x.remove()
+    out["sens_checksums"] = sens_sums[0]            # [coil, (sum re, sum im, L2)]
+    out["cascade_checksums"] = np.asarray(cas_sums)
+    t0 = time.time()
+    with torch.no_grad():
+        T64, R64 = net_T.double(), net_R.double()
+        f64, a64 = img_full.to(torch.complex128), img_aux.to(torch.complex128)
+        k_samp = R_sig.fft2(f64) * (1 - pruned.double())
+        samp = R_sig.ifft2(k_samp)
+        off64, grid64 = T64(moving=a64.abs(), fixed=samp.abs())
+        warped64 = torch.nn.functional.grid_sample(a64.abs(), grid64, align_corners=False)
+        rec64 = R64(masked_kspace=k_samp, mask=torch.logical_not(pruned), ref=warped64, num_low_frequencies=int(w * sp * 0.32))
+    print(f"multi-coil fp64 forward: {time.time() - t0:.0f} s")
+    out["img_rec_f64"] = rec64.numpy()
+    r32 = res["img_rec"].detach().double()
+    print("reference fp32 vs fp64 rel-L2 (rec):", ((r32 - rec64).norm() / rec64.norm()).item())
+    # (b) reduced train step: 2 cascades
+    t0 = time.time()
+    net_T, net_R, res = _rec_step(n, c, h, w, sp, 2, seed=3334)
+    print(f"multi-coil 2-cascade train step: {time.time() - t0:.0f} s")
+    _digest_step(out, "train2.", net_T, net_R, res)
+    out["train2.img_rec"] = npy(res["img_rec"])
+    save("multicoil_640x368.npz", **out)
+
+
+def run_pair_full(n, c, h, w, sparsity, num_cascades, seed, training):
+    """run_pair at the full network width (chans 18, sens_chans 8, 4 pooling levels)."""
+    return run_pair(n, c, h, w, sparsity, num_cascades, 18, 8, 4, seed=seed, training=training)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["ops", "small", "full", "augment", "metrics", "ckpt"]
+    which = sys.argv[1:] or ["ops", "small", "full", "augment", "metrics", "ckpt", "layers", "pad", "scalars", "train_full",
+                             "multicoil"]
     with torch.no_grad():
         if "ops" in which:
             make_ops()
@@ -343,3 +635,13 @@ if __name__ == "__main__":
         make_metrics()
     if "ckpt" in which:
         make_ckpt()
+    if "layers" in which:
+        make_layers()
+    if "pad" in which:
+        make_pad()
+    if "scalars" in which:
+        make_scalars()
+    if "train_full" in which:
+        make_train_full()
+    if "multicoil" in which:
+        make_multicoil()

@@ -132,3 +132,65 @@ def test_param_bucket_data_parallel_step_world2():
     g1, p1 = out[1]
     assert torch.equal(g0, g1) and torch.equal(p0, p1)     # replicas stay bit-identical after the exchange
     assert float(g0[0]) == 3.0                              # sum over ranks of (rank + 1) * 1
+
+
+def test_bench_self_launches_under_torch_distributed_run():
+    """`python bench.py --gpus 2` outside torch.distributed.run re-launches itself with one process per GPU
+    (127.0.0.1 rendezvous) and rank 0 prints ONE JSON line; --launch-test keeps it on the CPU (gloo)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-test", "--batch", "8"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"launch_test": True, "n_gpus": 2, "backend": "gloo", "max_over_ranks": 2.0, "global_batch": 16.0}
+    # the driver's own form (torch.distributed.run around bench.py) gives the same line
+    port = _free_port()
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-test",
+                         "--batch", "8"], env=env, capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert [json.loads(ln) for ln in r2.stdout.splitlines() if ln.startswith("{")] == [out]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-test"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stdout + r.stderr)
+
+
+def _bcast_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = sdist.init("gloo")
+    torch.manual_seed(rank)
+    t = torch.randn(5, 3)
+    b = torch.tensor([rank == 0, True, rank == 1])
+    nc = torch.randn(4, 6).t()                      # non-contiguous view
+    sdist.broadcast0(t, d)
+    sdist.broadcast0(b, d)
+    sdist.broadcast0(nc, d)
+    out[rank] = (t.clone(), b.clone(), nc.clone())
+    d.destroy_process_group()
+
+
+def test_broadcast0_world2():
+    """sync_replicas' primitive: float, bool and non-contiguous tensors end up equal to rank 0's on every rank."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_bcast_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    torch.manual_seed(0)
+    want_t = torch.randn(5, 3)
+    want_nc = torch.randn(4, 6).t()
+    for r in range(2):
+        t, b, nc = out[r]
+        assert torch.equal(t, want_t) and torch.equal(b, torch.tensor([True, True, False])) and torch.equal(nc, want_nc)

@@ -471,7 +471,7 @@ def test_varnet_backward_vs_golden_grads(S, tag, shape):
         if err > worst:
             worst, worst_name = err, name
     print("worst relative gradient error", worst, worst_name)
-    assert worst < 5e-3, (worst, worst_name)
+    assert worst < 2e-4, (worst, worst_name)           # measured 2e-5 (bf16x3 kernels: layers here have < 16 channels)
 
 
 def test_warp_and_smoothness_backward(S):
@@ -547,7 +547,10 @@ def test_full_rec_step_gradients_vs_golden(S, fp32_convs, tag, shape):
             if err > worst:
                 worst, worst_name = err, name
         print(pre, "worst relative gradient error", worst, worst_name)
-        assert worst < 1e-2, (pre, worst, worst_name)
+        # measured (fp32 conv kernels): 2e-5 on both networks at 32 x 32; at 48 x 80 / 3 coils 2e-5 on net_R and 8e-4 on
+        # one BatchNorm bias of net_T (a 3 x 5 pixel layer next to a LeakyReLU kink).  Bars = 10x measured.
+        bar = 8e-3 if (tag == "48x80c3" and pre == "grad.T.") else 2e-4
+        assert worst < bar, (pre, worst, worst_name)
     for k in gold.files:
         if k.startswith("bn_after.T."):
             got = dict(net.net_T.named_buffers())[k[len("bn_after.T."):]]
@@ -846,7 +849,8 @@ def test_full_rec_step_with_bf16x3_convs(S):
             num += ((got - want) ** 2).sum().item()
             den += (want ** 2).sum().item()
         print(pre, "relative L2 over all parameter gradients", (num / den) ** 0.5)
-        assert (num / den) ** 0.5 < 5e-3
+        # measured 8.6e-6 (net_R) / 6.2e-4 (net_T: the BatchNorm layers at 3 x 5 pixels); bars = 10x measured
+        assert (num / den) ** 0.5 < (1e-4 if pre == "grad.R." else 6e-3)
 
 
 @pytest.mark.gpu
