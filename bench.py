@@ -239,7 +239,7 @@ def roofline_entry(key, d, dt, steps, pmc, match_profile):
     out = {"kernel": key, "bound": bound, "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
            "traffic": p.get("hbm_bytes_per_launch"),
            "traffic_source": p.get("source"),
-           "algorithmic_bytes": p.get("algorithmic_bytes_per_launch") if d["unit"] == "FLOP" else per_launch,
+           "algorithmic_bytes": (d.get("abytes", 0.0) / d["launches"] or None) if d["unit"] == "FLOP" else per_launch,
            "mfma_busy": p.get("mfma_busy"),
            "launches": d["launches"], "timed_launches": d["sampled_launches"],
            "avg_launch_us": 1e3 * d["sampled_ms"] / d["sampled_launches"],

@@ -1,0 +1,59 @@
+"""gpurun_out/<tag>_pmc_raw.json (scratch/prof_r02.sh) -> profiles/<tag>_pmc.json.
+
+HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are reported in KiB of 64-byte fabric requests; on gfx950 a wide coalesced
+read is tallied at half its bytes (MI355X_MICROARCH.md, HBM section), other widths are uncalibrated -> the factors are
+calibrated in the same run on kernels of known traffic far beyond the 256 MiB Infinity Cache (scratch/pmc_traffic.py:
+apply_kernel 512 MiB in / out at 16 B and 4 B per lane, rss_kernel 512 MiB in at 8 B per lane).
+MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) per kernel family (the gfx94x MfmaUtil formula
+rocprofv3 falls back to on gfx950), next to SQ_BUSY_CYCLES and SQ_WAVE_CYCLES."""
+import json
+import os
+import sys
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+raw = json.load(open(os.path.join(R, "gpurun_out", f"{tag}_pmc_raw.json")))
+MiB = 1024.0 * 1024.0
+cal = {}
+ap = raw.get("cal_apply", {})
+rs = raw.get("cal_rss", {})
+# the two largest apply launches are the 16 B/lane shape (512 MiB), the next two the 4 B/lane shape (511.998 MiB)
+f_list, w_list = ap.get("FETCH_SIZE_list", []), ap.get("WRITE_SIZE_list", [])
+cal["raw_KiB"] = {"apply_FETCH": f_list, "apply_WRITE": w_list, "rss_FETCH": rs.get("FETCH_SIZE_list", [])}
+f16 = 512 * MiB / (max(f_list) * 1024) if f_list else 2.0
+f4 = 511.998 * MiB / (sorted(f_list)[0] * 1024) if len(f_list) >= 3 else f16
+f8 = 512 * MiB / (max(rs["FETCH_SIZE_list"]) * 1024) if rs.get("FETCH_SIZE_list") else f16
+wf = 512 * MiB / (max(w_list) * 1024) if w_list else 1.0
+width = {"conv_mfma_3x3": f4, "conv_mfma_1x1": f4, "conv_bf16x3": f4, "conv_bf16x3_1x1": f4}
+kern = {}
+for k, v in raw.items():
+    if k.startswith("cal_"):
+        continue
+    e = {}
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        f = v["FETCH_SIZE"]["avg"] * 1024 * width.get(k, f16)
+        w = v["WRITE_SIZE"]["avg"] * 1024 * wf
+        e.update(launches=v["FETCH_SIZE"]["launches"], fetch_bytes_per_launch=int(f), write_bytes_per_launch=int(w),
+                 hbm_bytes_per_launch=int(f + w), read_factor=round(width.get(k, f16), 3))
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+        busy, gui = v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"], v["GRBM_GUI_ACTIVE"]["sum"]
+        e["mfma_busy"] = busy / (gui * 1024.0) if gui else None
+        e["mfma_counters_avg_per_launch"] = {c: v[c]["avg"] for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
+                                                                      "GRBM_GUI_ACTIVE") if c in v}
+    kern[k] = e
+alias = {"conv3x3": "conv_mfma_3x3", "conv3x3_bf16x3": "conv_bf16x3", "wgrad3x3_bf16x3": "wgrad_bf16x3", "wgrad3x3": "wgrad_vec_3x3"}
+for a, b in alias.items():
+    if b in kern:
+        kern[a] = dict(kern[b])
+if "fft320_rows" in kern and "fft320_cols" in kern and "hbm_bytes_per_launch" in kern["fft320_rows"]:
+    r, c = kern["fft320_rows"], kern["fft320_cols"]
+    n = r["launches"] + c["launches"]
+    kern["fft_dc"] = {"launches": n, "hbm_bytes_per_launch": int((r["hbm_bytes_per_launch"] * r["launches"] + c["hbm_bytes_per_launch"] * c["launches"]) / n),
+                      "note": "launch-weighted average over the rows and (fused) columns kernels"}
+out = {"note": "rocprofv3 --pmc passes of scratch/pmc_traffic.py (calibration kernels + 3 train steps at N = 8, 320 x 320, 12 cascades), "
+               "each counter set in its own run with --kernel-trace only (scratch/prof_r02.sh); corrected by scratch/pmc_r02_finalize.py",
+       "calibration": cal, "fetch_factor": {"16B_per_lane": f16, "8B_per_lane": f8, "4B_per_lane": f4}, "write_factor": wf,
+       "mfma_busy_definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs), summed over the family's launches",
+       "kernels": kern}
+json.dump(out, open(os.path.join(R, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
+print(json.dumps({k: {"hbm": v.get("hbm_bytes_per_launch"), "mfma_busy": v.get("mfma_busy")} for k, v in kern.items()}, indent=1))

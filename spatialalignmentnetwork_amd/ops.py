@@ -35,10 +35,11 @@ class KernelTimer:
         self.recs = []
         self.seen = {}
 
-    def bracket(self, name, work, unit, fn):
-        d = self.seen.setdefault(name, {"launches": 0, "work": 0.0, "unit": unit})
+    def bracket(self, name, work, unit, fn, abytes=0.0):
+        d = self.seen.setdefault(name, {"launches": 0, "work": 0.0, "unit": unit, "abytes": 0.0})
         d["launches"] += 1
         d["work"] += work
+        d["abytes"] += abytes
         if (d["launches"] - 1) % self.stride:
             fn()
             return
@@ -78,11 +79,18 @@ TIMER: Optional[KernelTimer] = None
 TIMED_KERNELS = ("conv3x3", "conv3x3_bf16x3", "wgrad3x3", "wgrad3x3_bf16x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
 
 
-def _timed(name, work, unit, fn):
+def _timed(name, work, unit, fn, abytes=0.0):
+    """abytes: the launch's ALGORITHMIC bytes (operands read once + results written once), reported next to the PMC
+    traffic so that a waste ratio can be formed."""
     if TIMER is None or name not in TIMED_KERNELS:
         fn()
     else:
-        TIMER.bracket(name, work, unit, fn)
+        TIMER.bracket(name, work, unit, fn, abytes)
+
+
+def _conv_abytes(n, h, w, cin, cout, ks):
+    """fp32 input planes + fp32 output planes + fp32 weights, each once."""
+    return 4.0 * (n * h * w * (cin + cout) + cout * cin * ks * ks)
 
 
 def _stream() -> ctypes.c_void_p:
@@ -495,7 +503,7 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
                  y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
         _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
-               lambda: _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena))
+               lambda: _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena), _conv_abytes(n, h, w, cin, cout, ks))
         return part
     wp = packed_weight(weight)
     if stats:
@@ -504,7 +512,7 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
             y.ctot, y.coff, cout, _p(out_scale), _p(out_shift), _p(part), n, h, w, ks, _stream())
     _timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
-           lambda: lib().call("san_conv2d_fwd", *args))
+           lambda: lib().call("san_conv2d_fwd", *args), _conv_abytes(n, h, w, cin, cout, ks))
     return part
 
 
@@ -714,14 +722,15 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
         bargs = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
                  _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), dy.n, dy.h, dy.w, _stream())
         _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
-               lambda: _bf16x3_launch(ks, bargs, dy.n, dy.h, dy.w, cout, cin, dy.buf.device, GLOBAL_ARENA))
+               lambda: _bf16x3_launch(ks, bargs, dy.n, dy.h, dy.w, cout, cin, dy.buf.device, GLOBAL_ARENA),
+               _conv_abytes(dy.n, dy.h, dy.w, cin, cout, ks))
         return
     wp = packed_weight_dgrad(weight)
     args = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
             _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), _p(None), _p(None), dy.n, dy.h, dy.w, ks, _stream())
     # the data gradient runs on the forward conv kernel: same roofline class
     _timed("conv3x3" if ks == 3 else "conv1x1", 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
-           lambda: lib().call("san_conv2d_fwd", *args))
+           lambda: lib().call("san_conv2d_fwd", *args), _conv_abytes(dy.n, dy.h, dy.w, cin, cout, ks))
 
 
 # ---------------------------------------------------------------------------
@@ -820,7 +829,8 @@ def _conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, a
     partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff, cout,
             _p(_chk(dw, name="dw")), int(accumulate), _p(partial), x.n, x.h, x.w, ks, _stream())
-    _timed("wgrad3x3" if ks == 3 else "wgrad1x1", flops, "FLOP", lambda: lib().call("san_conv2d_wgrad", *args))
+    _timed("wgrad3x3" if ks == 3 else "wgrad1x1", flops, "FLOP", lambda: lib().call("san_conv2d_wgrad", *args),
+           _conv_abytes(x.n, x.h, x.w, cin, cout, ks))
 
 
 def conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
@@ -838,7 +848,8 @@ def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = F
     scratch = arena.scratch("wgrad_bf16x3", nbytes, x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
             cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
-    _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args))
+    _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args),
+           _conv_abytes(x.n, x.h, x.w, cin, cout, 3))
 
 
 def wgrad1x1_bf16x3_ok(x: Act, dy: Act) -> bool:
