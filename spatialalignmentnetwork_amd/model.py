@@ -125,6 +125,8 @@ class CSModel(BaseModel):
         if reg not in ("None", "Rec"):
             raise NotImplementedError(f"regime {reg!r}: the GAN branch (Mixed / GAN-Only) is out of scope")
         train_T = reg == "Rec"
+        if _active_dist() is not None and not getattr(self, "_replicas_synced", False):
+            self.sync_replicas()                # first data-parallel step: every rank starts from rank 0's state
         self.loss_all = 0
         if train_T:
             self.forwardT()
@@ -140,8 +142,6 @@ class CSModel(BaseModel):
             self.backward(train_T)
         dist = _active_dist()
         scale = 1.0
-        if dist is not None and not getattr(self, "_replicas_synced", False):
-            self.sync_replicas(dist)            # first data-parallel step: every rank starts from rank 0's state
         if dist is not None:                    # data parallel: one in-place RCCL all-reduce per network;
             for o in opts:                      # the 1/world factor rides in the optimiser kernel
                 o.bucket().allreduce_sum(dist)
