@@ -186,6 +186,11 @@ int san_dc_weight_grad(const float* g, const float* k, const float* k0, const fl
                        int planes, int h, int w, void* stream);
 int san_sens_grad_acc(float* gs, const float* r_planar, const float* t1, const float* x, const float* gm_planar,
                       float sign1, int n, int c, int hw, void* stream);
+/* Image-domain cascade backward (san_dc_rows, backward form): the accumulation of san_sens_grad_acc (skipped when gs is
+ * NULL) and, in the same pass, gd[n,c] += gm[n] * sens[n,c]: the gradient that reaches the cascade's input through
+ * m = sum_c conj(S_c) x_c joins the one through the data-consistency path. */
+int san_sens_grad_prop(float* gs, const float* r_planar, const float* t1, const float* x, const float* gm_planar,
+                       float sign1, float* gd, const float* sens, int n, int c, int hw, void* stream);
 int san_sens_normalize_bwd(const float* est_planar, const float* gs, float* gest_planar, int n, int c, int hw,
                            void* stream);
 int san_rss_bwd(const float* x, const float* y, const float* g, float* gx, int n, int c, int hw, int is_complex,
@@ -296,6 +301,28 @@ int san_apply_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const
 int san_window_copy_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
                         int hx, int wx, float* y, int y_ctot, int y_coff, int hy, int wy, int off_y, int off_x,
                         int mode, int n, int c, void* stream);
+
+/* ------------------------------------------- image-domain cascade boundary */
+
+/* out = (i)fft along H only (ortho: scale 1/sqrt(h)) of interleaved complex [planes, h, w].  k0x = ifft_y(k0) is the
+ * data term of san_dc_rows; x0 = ifft_x(k0x) = ifft2(k0). */
+int san_fft_cols(const float* in, float* out, int planes, int h, int w, int inverse, void* stream);
+
+/* One cascade boundary in the IMAGE domain.  The soft data consistency's mask depends on kx only, so with x = ifft2(k)
+ * the reference's  k' = k - dc_w * where(mask, k - k0, 0) - fft2(r * S)  followed by  m' = sum_c ifft2(k')_c conj(S_c)
+ * (varnet.py:508-530 and :511-512 of the next cascade) is row-local:
+ *     D  = ifft_x( mask (fft_x(x) - k0x) )        x_out = x - dc_w D - r S        m_out = sum_c conj(S_c) x_out_c
+ * x, sens, k0x, x_out, dk_*: interleaved complex [n, c, h, w]; r_planar [n, 2, h, w]; m_out planar into channels 0, 1
+ * of [n, m_ctot, h, w]; mask fp32 [w]; dc_w one device float.  x_out may alias x.  k0x / r_planar / x_out / m_out may
+ * be NULL (term absent / result not wanted).  dk_out (optional): mask (fft_x(x) - k0x), kept for the backward pass.
+ * backward != 0 (the DC term is self-adjoint; k0x, r_planar, dk_out must be NULL):
+ *     x_out = g - dc_w ifft_x(mask fft_x(g)),   m_out = - sum_c conj(S_c) g_c   (gradient wrt the regulariser output),
+ *     dcw_part[san_dc_rows_partials(n, h, w)] = per-workgroup partials of Re sum conj(fft_x(g)) dk_in, whose total is
+ *     -dL/d(dc_w). */
+int san_dc_rows_partials(int n, int h, int w);
+int san_dc_rows(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
+                const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, const float* dk_in,
+                float* dcw_part, int backward, int n, int c, int h, int w, void* stream);
 
 /* -------------------------------------------------------- warp and losses */
 

@@ -771,6 +771,40 @@ sens_grad_acc_kernel(float2* __restrict__ gS, const float* __restrict__ r, const
     }
 }
 
+// image-domain cascade backward (see san_dc_rows): the same sensitivity-map accumulation, and in the same pass the
+// regulariser-input gradient joins the state gradient:  gd[n,c] += gm[n] * S[n,c]   (m = sum_c conj(S_c) x_c).  gS may be null.
+__global__ void __launch_bounds__(kThreads)
+sens_grad_prop_kernel(float2* __restrict__ gS, const float* __restrict__ r, const float2* __restrict__ t1,
+                      const float2* __restrict__ x, const float* __restrict__ gm, float sign1, float2* __restrict__ gd,
+                      const float2* __restrict__ S, int C, int HW) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < HW; i += gridDim.x * kThreads) {
+        const float gr = gm[(size_t)n * 2 * HW + i], gi = gm[(size_t)n * 2 * HW + HW + i];
+        float rr = 0.f, ri = 0.f;
+        if (gS) {
+            rr = r[(size_t)n * 2 * HW + i];
+            ri = r[(size_t)n * 2 * HW + HW + i];
+        }
+        for (int c = 0; c < C; ++c) {
+            const size_t e = ((size_t)n * C + c) * HW + i;
+            if (gS) {
+                const float2 t = t1[e], xv = x[e];
+                float2 acc = gS[e];
+                acc.x += sign1 * (rr * t.x + ri * t.y);
+                acc.y += sign1 * (rr * t.y - ri * t.x);
+                acc.x += xv.x * gr + xv.y * gi;
+                acc.y += xv.y * gr - xv.x * gi;
+                gS[e] = acc;
+            }
+            const float2 sv = S[e];
+            float2 g = gd[e];
+            g.x += gr * sv.x - gi * sv.y;
+            g.y += gr * sv.y + gi * sv.x;
+            gd[e] = g;
+        }
+    }
+}
+
 // S_c = e_c / d, d = sqrt(sum |e_c|^2) + eps:  g_e_c = G_c/d - T * e_c / rss,  T = Re(sum conj(G_c) e_c) / d^2
 __global__ void __launch_bounds__(kThreads)
 sens_normalize_bwd_kernel(const float* __restrict__ est, const float2* __restrict__ gS, float* __restrict__ gest, int C,
@@ -1256,6 +1290,19 @@ int san_sens_grad_acc(float* gs, const float* r_planar, const float* t1, const f
     if (bx > 256) bx = 256;
     hipLaunchKernelGGL(sens_grad_acc_kernel, dim3(bx, n), dim3(kThreads), 0, (hipStream_t)stream, (float2*)gs, r_planar,
                        (const float2*)t1, (const float2*)x, gm_planar, sign1, c, hw);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_sens_grad_prop(float* gs, const float* r_planar, const float* t1, const float* x, const float* gm_planar,
+                       float sign1, float* gd, const float* sens, int n, int c, int hw, void* stream) {
+    SAN_CHECK_ARG(gm_planar && gd && sens, "null pointer");
+    SAN_CHECK_ARG(!gs || (r_planar && t1 && x), "the sensitivity-map accumulation needs r, t1 and x");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    int bx = san_cdiv(hw, kThreads);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL(sens_grad_prop_kernel, dim3(bx, n), dim3(kThreads), 0, (hipStream_t)stream, (float2*)gs, r_planar,
+                       (const float2*)t1, (const float2*)x, gm_planar, sign1, (float2*)gd, (const float2*)sens, c, hw);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -58,6 +58,11 @@ struct FftArgs {
     float scale;
     float sgn;               // +1 forward, -1 inverse
     int pro, epi;
+    // image-domain cascade boundary (dc_rows kernels)
+    float2* dk_out;          // forward: mask * (fft_x(x) - k0x), kept for the dc_weight gradient (or null)
+    const float2* dk_in;     // backward: that tensor of the forward pass
+    float* dcw_part;         // backward: one partial of Re sum conj(fft_x(g)) dk_in per workgroup
+    float m_scale;           // factor on the coil-combined planar output (-1 in the backward form)
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -147,7 +152,7 @@ __device__ __forceinline__ void stockham_pass_any(float2* __restrict__ src, floa
 
 // Runs all passes; returns the buffer that holds the result.
 __device__ __forceinline__ float2* run_fft(const FftArgs& a, float2* bufA, float2* bufB, const float2* tw,
-                                           int seq, int lane, int tps, bool active) {
+                                           int seq, int lane, int tps, bool active, float sgn) {
     float2* src = bufA;
     float2* dst = bufB;
     int Ns = 1;
@@ -157,10 +162,10 @@ __device__ __forceinline__ float2* run_fft(const FftArgs& a, float2* bufA, float
             float2* s = src + seq * a.pitch;
             float2* d = dst + seq * a.pitch;
             switch (R) {
-                case 2: stockham_pass_reg<2>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, a.sgn); break;
-                case 3: stockham_pass_reg<3>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, a.sgn); break;
-                case 4: stockham_pass_reg<4>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, a.sgn); break;
-                case 5: stockham_pass_reg<5>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, a.sgn); break;
+                case 2: stockham_pass_reg<2>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, sgn); break;
+                case 3: stockham_pass_reg<3>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, sgn); break;
+                case 4: stockham_pass_reg<4>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, sgn); break;
+                case 5: stockham_pass_reg<5>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, sgn); break;
                 default: stockham_pass_any(s, d, tw, a.len, R, Ns, a.ns_shift[p], lane, tps); break;
             }
         }
@@ -239,7 +244,7 @@ __global__ void __launch_bounds__(kThreads) fft_rows_kernel(const FftArgs a) {
             }
         }
         __syncthreads();
-        float2* res = run_fft(a, bufA, bufB, tw, seq, lane, tps, seq < rows);
+        float2* res = run_fft(a, bufA, bufB, tw, seq, lane, tps, seq < rows, a.sgn);
         // ---- epilogue
         if (a.epi == RE_STORE) {
             int wi = tid % W;
@@ -339,7 +344,7 @@ __global__ void __launch_bounds__(kThreads) fft_cols_kernel(const FftArgs a) {
         bufA[j * a.pitch + h] = v;
     }
     __syncthreads();
-    float2* res = run_fft(a, bufA, bufB, tw, seq, lane, tps, seq < cols);
+    float2* res = run_fft(a, bufA, bufB, tw, seq, lane, tps, seq < cols, a.sgn);
     if (a.epi == CE_STORE) {
         for (int e = tid; e < H * B; e += kThreads) {
             const int h = e >> a.logB;
@@ -739,6 +744,249 @@ __global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
 #pragma unroll
             for (int r = 0; r < 5; ++r) a.out2[base + (size_t)(j + 64 * r) * W] = out[t][r];
         }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Image-domain cascade boundary.  The column mask M of the soft data consistency depends on kx only, so with
+// x = ifft2(k) the k-space update  k' = k - w M (k - k0) - fft2(r S)  (varnet.py:514-530) is ROW-LOCAL in the image domain:
+//     D(x) = ifft_x( M (fft_x(x) - k0x) ),  k0x = ifft_y(k0)        x' = x - w D(x) - r S        m' = sum_c conj(S_c) x'_c
+// (the y transforms cancel: F_y^H (F_y X F_x diag(M)) F_x^H = X F_x diag(M) F_x^H).  One launch per cascade does the
+// forward row transform, the masked combine, the inverse row transform, the regulariser term and the coil combination
+// for the NEXT cascade, touching HBM once: read x, S, k0x (C planes each) and r (1), write x' (C) and m' (1) =
+// (4C + 2) planes instead of the (6C + 2) of the two 2-D transforms, and no column passes at all.
+// MODE 0 (forward): as above; optionally stores dk = M (fft_x(x) - k0x) for the dc_weight gradient.
+// MODE 1 (backward: the DC term is self-adjoint): g' = g - w ifft_x(M fft_x(g)), h = m_scale sum_c conj(S_c) g_c (the
+//        INPUT g: gradient wrt the regulariser output), and one partial of Re sum conj(fft_x(g)) dk per workgroup.
+template <int MODE>
+__global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
+    __shared__ float2 lds[kL320 * kP320];
+    __shared__ float2 tws[kN320];
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < 5; ++r) tws[lane + 64 * r] = a.tw[lane + 64 * r];
+    const int W = kN320, H = a.H;
+    const int h0 = blockIdx.x * kL320;
+    const int n = blockIdx.y;
+    const float dcw = a.dcw[0];
+    float mk[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) mk[r] = a.mask[lane + 64 * r];
+    float2 macc[4][5];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) macc[t][r] = make_float2(0.f, 0.f);
+    float wsum = 0.f;
+    int lineA[5], jA[5];
+#pragma unroll
+    for (int t = 0; t < 5; ++t) Map320<0>::r4(lane, t, lineA[t], jA[t]);
+
+    for (int c = 0; c < a.C; ++c) {
+        const size_t pbase = (size_t)(n * a.C + c) * H * W;
+        float2 in[5][4], out[4][5];
+        if (c > 0) __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            const int e = min(h0 + lineA[t], H - 1) * W + jA[t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) in[t][r] = a.in[pbase + e + 80 * r];
+        }
+        // the k_x-domain operand is requested before the transform so that its latency hides under it
+        float2 kq[4][5];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const size_t e = pbase + (size_t)min(h0 + t, H - 1) * W + lane;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                if (MODE == 0) kq[t][r] = a.k0 ? a.k0[e + 64 * r] : make_float2(0.f, 0.f);
+                else kq[t][r] = a.dk_in ? a.dk_in[e + 64 * r] : make_float2(0.f, 0.f);
+            }
+        }
+        fft320_core<0>(in, out, lds, tws, 1.f, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const float2 X = make_float2(out[t][r].x * a.scale, out[t][r].y * a.scale);
+                float2 d;
+                if (MODE == 0) {
+                    d = make_float2(mk[r] * (X.x - kq[t][r].x), mk[r] * (X.y - kq[t][r].y));
+                    if (a.dk_out && h0 + t < H) a.dk_out[pbase + (size_t)(h0 + t) * W + lane + 64 * r] = d;
+                } else {
+                    d = make_float2(mk[r] * X.x, mk[r] * X.y);
+                    if (h0 + t < H) wsum += X.x * kq[t][r].x + X.y * kq[t][r].y;
+                }
+                out[t][r] = d;
+            }
+        }
+        // one LDS exchange converts the radix-5 output layout (element lane + 64 r) into the pass-A input layout
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 5; ++r) lds[t * kP320 + lane + 64 * r] = out[t][r];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) in[t][r] = lds[lineA[t] * kP320 + jA[t] + 80 * r];
+        __syncthreads();
+        // epilogue operands, requested before the inverse transform
+        float2 xo[4][5], sv[4][5];
+        float rre[4][5], rim[4][5];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int row = min(h0 + t, H - 1);
+            const size_t e = pbase + (size_t)row * W + lane;
+            const size_t pe = ((size_t)n * 2 * H + row) * W + lane;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                xo[t][r] = a.in[e + 64 * r];
+                sv[t][r] = a.sens[e + 64 * r];
+                if (MODE == 0 && a.in_planar) {
+                    rre[t][r] = a.in_planar[pe + 64 * r];
+                    rim[t][r] = a.in_planar[pe + 64 * r + (size_t)H * W];
+                } else {
+                    rre[t][r] = rim[t][r] = 0.f;
+                }
+            }
+        }
+        fft320_core<0>(in, out, lds, tws, -1.f, lane);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (h0 + t >= H) continue;
+            const size_t e = pbase + (size_t)(h0 + t) * W + lane;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const float2 s = sv[t][r];
+                float2 v = make_float2(xo[t][r].x - dcw * (out[t][r].x * a.scale), xo[t][r].y - dcw * (out[t][r].y * a.scale));
+                if (MODE == 0) {
+                    v.x -= rre[t][r] * s.x - rim[t][r] * s.y;
+                    v.y -= rre[t][r] * s.y + rim[t][r] * s.x;
+                }
+                if (a.out) a.out[e + 64 * r] = v;
+                const float2 q = MODE == 0 ? v : xo[t][r];          // coil combination: conj(S) * q
+                macc[t][r].x += q.x * s.x + q.y * s.y;
+                macc[t][r].y += q.y * s.x - q.x * s.y;
+            }
+        }
+    }
+    if (a.out_real) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (h0 + t >= H) continue;
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const size_t pe = ((size_t)n * a.out_ctot * H + h0 + t) * W + lane + 64 * r;
+                a.out_real[pe] = macc[t][r].x * a.m_scale;
+                a.out_real[pe + (size_t)H * W] = macc[t][r].y * a.m_scale;
+            }
+        }
+    }
+    if (MODE == 1 && a.dcw_part) {
+        wsum = san_wave_total(wsum);
+        if (lane == 0) a.dcw_part[blockIdx.y * gridDim.x + blockIdx.x] = wsum;
+    }
+}
+
+// Any row length: B rows per workgroup staged in LDS, both transforms with the mixed-radix Stockham passes.
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) dc_rows_kernel(const FftArgs a) {
+    float2* twf = reinterpret_cast<float2*>(smem_raw);
+    float2* twi = twf + a.len;
+    float2* bufA = twi + a.len;
+    float2* bufB = bufA + a.B * a.pitch;
+    const int tid = threadIdx.x;
+    const int W = a.W, H = a.H;
+    const int h0 = blockIdx.x * a.B;
+    const int rows = min(a.B, H - h0);
+    const int cnt = rows * W;
+    const int tps = kThreads >> a.logB;
+    const int seq = tid / tps;
+    const int lane = tid - seq * tps;
+    const int n = blockIdx.y;
+    for (int i = tid; i < a.len; i += kThreads) {
+        const float2 t = a.tw[i];
+        twf[i] = t;
+        twi[i] = make_float2(t.x, -t.y);
+    }
+    const float dcw = a.dcw[0];
+    constexpr int kMaxAcc = 24;
+    float2 acc[kMaxAcc];
+#pragma unroll
+    for (int i = 0; i < kMaxAcc; ++i) acc[i] = make_float2(0.f, 0.f);
+    float wsum = 0.f;
+    for (int c = 0; c < a.C; ++c) {
+        const size_t base = ((size_t)(n * a.C + c) * H + h0) * W;
+        __syncthreads();
+        for (int e = tid; e < a.B * W; e += kThreads) bufA[e] = e < cnt ? a.in[base + e] : make_float2(0.f, 0.f);
+        __syncthreads();
+        float2* res = run_fft(a, bufA, bufB, twf, seq, lane, tps, seq < rows, 1.f);
+        {
+            int wi = tid % W;
+            for (int e = tid; e < cnt; e += kThreads) {
+                const float2 X = make_float2(res[e].x * a.scale, res[e].y * a.scale);
+                const float m = a.mask[wi];
+                float2 d;
+                if (MODE == 0) {
+                    const float2 k0 = a.k0 ? a.k0[base + e] : make_float2(0.f, 0.f);
+                    d = make_float2(m * (X.x - k0.x), m * (X.y - k0.y));
+                    if (a.dk_out) a.dk_out[base + e] = d;
+                } else {
+                    d = make_float2(m * X.x, m * X.y);
+                    if (a.dk_in) {
+                        const float2 q = a.dk_in[base + e];
+                        wsum += X.x * q.x + X.y * q.y;
+                    }
+                }
+                res[e] = d;
+                wi += kThreads % W;
+                if (wi >= W) wi -= W;
+            }
+        }
+        __syncthreads();
+        float2* other = res == bufA ? bufB : bufA;
+        float2* res2 = run_fft(a, res, other, twi, seq, lane, tps, seq < rows, -1.f);
+        const size_t rbase = ((size_t)n * 2 * H + h0) * W;
+#pragma unroll
+        for (int it = 0; it < kMaxAcc; ++it) {
+            const int e = tid + it * kThreads;
+            if (e < cnt) {
+                const float2 xo = a.in[base + e];
+                const float2 s = a.sens[base + e];
+                float2 v = make_float2(xo.x - dcw * (res2[e].x * a.scale), xo.y - dcw * (res2[e].y * a.scale));
+                if (MODE == 0 && a.in_planar) {
+                    const float rr = a.in_planar[rbase + e], ri = a.in_planar[rbase + e + (size_t)H * W];
+                    v.x -= rr * s.x - ri * s.y;
+                    v.y -= rr * s.y + ri * s.x;
+                }
+                if (a.out) a.out[base + e] = v;
+                const float2 q = MODE == 0 ? v : xo;
+                acc[it].x += q.x * s.x + q.y * s.y;
+                acc[it].y += q.y * s.x - q.x * s.y;
+            }
+        }
+    }
+    if (a.out_real) {
+        const size_t rb = ((size_t)n * a.out_ctot * H + h0) * W;
+#pragma unroll
+        for (int it = 0; it < kMaxAcc; ++it) {
+            const int e = tid + it * kThreads;
+            if (e < cnt) {
+                a.out_real[rb + e] = acc[it].x * a.m_scale;
+                a.out_real[rb + e + (size_t)H * W] = acc[it].y * a.m_scale;
+            }
+        }
+    }
+    if (MODE == 1 && a.dcw_part) {
+        wsum = san_wave_total(wsum);
+        __syncthreads();                                   // the transforms are done: the twiddle area is free
+        float* red = reinterpret_cast<float*>(twf);         // (one __shared__ object only: the dynamic one may then be the full 160 KB)
+        if ((tid & 63) == 0) red[tid >> 6] = wsum;
+        __syncthreads();
+        if (tid == 0) a.dcw_part[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -1166,6 +1414,107 @@ int san_ifft2_rss(const float* k, float* out, int n, int c, int h, int w, void* 
 int san_ifft2_rss_from_cols(const float* k_cols, float* out, int n, int c, int h, int w, void* ws, size_t ws_bytes,
                             void* stream) {
     return ifft2_rss_impl(k_cols, out, n, c, h, w, ws, ws_bytes, 1, stream);
+}
+
+// rows per workgroup and grid of the image-domain cascade kernels (also sizes the dc_weight partials)
+static void dc_rows_geom(int h, int w, int* B, int* gx) {
+    if (w == kN320) {
+        *B = kL320;
+    } else {
+        int b = 8;
+        while (b > 1 && (size_t)b * w * sizeof(float2) * 2 > 60 * 1024) b >>= 1;
+        while (b > 1 && b * w > 24 * kThreads) b >>= 1;
+        *B = b;
+    }
+    *gx = san_cdiv(h, *B);
+}
+
+int san_dc_rows_partials(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return 0;
+    int B, gx;
+    dc_rows_geom(h, w, &B, &gx);
+    return gx * n;
+}
+
+int san_fft_cols(const float* in, float* out, int planes, int h, int w, int inverse, void* stream) {
+    SAN_CHECK_ARG(in && out, "null pointer");
+    SAN_CHECK_ARG(planes > 0 && h > 0 && w > 0, "bad dims");
+    int r = ensure_big_lds();
+    if (r) return r;
+    Plan ph;
+    if ((r = get_plan(h, &ph))) return r;
+    FftArgs c = base_args(1, h, w);
+    fill_pass(c, ph);
+    c.in = (const float2*)in;
+    c.out = (float2*)out;
+    c.sgn = inverse ? -1.f : 1.f;
+    c.scale = (float)(1.0 / std::sqrt((double)h));
+    c.epi = CE_STORE;
+    return launch_cols(c, planes, (hipStream_t)stream);
+}
+
+int san_dc_rows(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
+                const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, const float* dk_in,
+                float* dcw_part, int backward, int n, int c, int h, int w, void* stream) {
+    SAN_CHECK_ARG(x && sens && mask && dc_w, "null input");
+    SAN_CHECK_ARG(n > 0 && c > 0 && h > 0 && w > 0, "bad dims");
+    SAN_CHECK_ARG(!m_out || m_ctot >= 2, "m_ctot must be >= 2");
+    SAN_CHECK_ARG(backward ? (!k0x && !r_planar && !dk_out) : (!dk_in && !dcw_part), "operand not used in this direction");
+    int r = ensure_big_lds();
+    if (r) return r;
+    Plan pw;
+    if ((r = get_plan(w, &pw))) return r;
+    FftArgs a = base_args(c, h, w);
+    fill_pass(a, pw);
+    a.in = (const float2*)x;
+    a.sens = (const float2*)sens;
+    a.k0 = (const float2*)k0x;
+    a.mask = mask;
+    a.dcw = dc_w;
+    a.in_planar = r_planar;
+    a.out = (float2*)x_out;
+    a.out_real = m_out;
+    a.out_ctot = m_out ? m_ctot : 2;
+    a.dk_out = (float2*)dk_out;
+    a.dk_in = (const float2*)dk_in;
+    a.dcw_part = dcw_part;
+    a.m_scale = backward ? -1.f : 1.f;
+    a.scale = (float)(1.0 / std::sqrt((double)w));
+    hipStream_t s = (hipStream_t)stream;
+    int B, gx;
+    dc_rows_geom(h, w, &B, &gx);
+    if (w == kN320) {
+        const dim3 grid(gx, n);
+        if (backward) hipLaunchKernelGGL((dc_rows320_kernel<1>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((dc_rows320_kernel<0>), grid, dim3(64), 0, s, a);
+        SAN_LAUNCH_CHECK();
+        return SAN_OK;
+    }
+    a.B = B;
+    if (a.B * a.W > 24 * kThreads) {
+        san_set_error("row length %d too long for the image-domain cascade kernel", w);
+        return SAN_E_UNSUPPORTED;
+    }
+    a.logB = ilog2(a.B);
+    a.pitch = a.len;
+    const size_t lds = sizeof(float2) * (2 * (size_t)a.len + 2 * (size_t)a.B * a.pitch);
+    if (lds > 160 * 1024) {
+        san_set_error("fft row of %d does not fit LDS", a.len);
+        return SAN_E_UNSUPPORTED;
+    }
+    static std::once_flag once;
+    static hipError_t err = hipSuccess;
+    std::call_once(once, [] {
+        err = hipFuncSetAttribute(reinterpret_cast<const void*>(dc_rows_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (err == hipSuccess)
+            err = hipFuncSetAttribute(reinterpret_cast<const void*>(dc_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (err != hipSuccess) return (int)err;
+    const dim3 grid(gx, n);
+    if (backward) hipLaunchKernelGGL((dc_rows_kernel<1>), grid, dim3(kThreads), lds, s, a);
+    else hipLaunchKernelGGL((dc_rows_kernel<0>), grid, dim3(kThreads), lds, s, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
 }
 
 }  // extern "C"

@@ -269,6 +269,53 @@ def sens_expand_dc(r_planar: torch.Tensor, sens: torch.Tensor, k: torch.Tensor, 
     return k_out
 
 
+def fft_cols(x: torch.Tensor, inverse: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Ortho (i)fft along H only of complex [N, C, H, W] (k0x = ifft_y(k0): the data term of dc_rows)."""
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    lib().call("san_fft_cols", _p(_creal(x, "x")), _p(_creal(out, "out")), n * c, h, w, int(inverse), _stream())
+    return out
+
+
+def dc_rows(x: torch.Tensor, sens: torch.Tensor, k0x: Optional[torch.Tensor], mask: torch.Tensor, dc_w: torch.Tensor,
+            r_planar: Optional[torch.Tensor], x_out: Optional[torch.Tensor], m_out: Optional[torch.Tensor],
+            dk_out: Optional[torch.Tensor] = None) -> None:
+    """One cascade boundary in the image domain (san_dc_rows): x_out = x - dc_w ifft_x(mask (fft_x(x) - k0x)) - r S and
+    m_out[:, 0:2] = sum_c conj(S_c) x_out_c (planar, into a [N, ctot, H, W] buffer)."""
+    n, c, h, w = x.shape
+    args = (_p(_creal(x, "x")), _p(_creal(sens, "sens")), _p(None if k0x is None else _creal(k0x, "k0x")),
+            _p(_chk(mask, name="mask")), _p(_chk(dc_w, name="dc_w")), _p(None if r_planar is None else _chk(r_planar, name="r")),
+            _p(None if x_out is None else _creal(x_out, "x_out")), _p(None if m_out is None else _chk(m_out, name="m_out")),
+            int(m_out.shape[1]) if m_out is not None else 2, _p(None if dk_out is None else _creal(dk_out, "dk_out")),
+            _p(None), _p(None), 0, n, c, h, w, _stream())
+    # SURVEY 8(d) bytes of one cascade's FFT + DC work: (6C + 2) planes of H*W*8 B per slice; this kernel itself moves
+    # (4C + 2) (+ C for dk_out): the column passes of the two 2-D transforms are gone
+    _timed("fft_dc", float((6 * c + 2) * n * h * w * 8), "B", lambda: lib().call("san_dc_rows", *args),
+           float((4 * c + 2 + (c if dk_out is not None else 0)) * n * h * w * 8))
+
+
+def dc_rows_bwd(g: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, dc_w: torch.Tensor, g_out: torch.Tensor,
+                h_out: torch.Tensor, dk: torch.Tensor) -> torch.Tensor:
+    """Backward form: g_out = g - dc_w ifft_x(mask fft_x(g)); h_out = -sum_c conj(S_c) g_c (planar: the gradient wrt the
+    regulariser output); returns dL/d(dc_w) as a 0-d tensor (fixed-order sum of the per-workgroup partials)."""
+    n, c, h, w = g.shape
+    part = GLOBAL_ARENA.get("dcw_part", (lib().query("san_dc_rows_partials", n, h, w),), g.device)
+    lib().call("san_dc_rows", _p(_creal(g, "g")), _p(_creal(sens, "sens")), _p(None), _p(_chk(mask, name="mask")),
+               _p(_chk(dc_w, name="dc_w")), _p(None), _p(_creal(g_out, "g_out")), _p(_chk(h_out, name="h_out")),
+               int(h_out.shape[1]), _p(None), _p(_creal(dk, "dk")), _p(part), 1, n, c, h, w, _stream())
+    return -(part.double().sum()).float()
+
+
+def sens_grad_prop(gS: Optional[torch.Tensor], r_planar: torch.Tensor, t1: torch.Tensor, x: torch.Tensor, gm_planar: torch.Tensor,
+                   gd: torch.Tensor, sens: torch.Tensor) -> None:
+    """gd += gm * S (in place) and, if gS is given, the sensitivity-map gradient of one cascade (san_sens_grad_prop)."""
+    n, c, h, w = gd.shape
+    lib().call("san_sens_grad_prop", _p(None if gS is None else _creal(gS, "gS")), _p(_chk(r_planar, name="r")),
+               _p(_creal(t1, "t1")), _p(_creal(x, "x")), _p(_chk(gm_planar, name="gm")), -1.0, _p(_creal(gd, "gd")),
+               _p(_creal(sens, "sens")), n, c, h * w, _stream())
+
+
 def ifft2_rss(k: torch.Tensor, out: Optional[torch.Tensor] = None, cols: Optional[torch.Tensor] = None) -> torch.Tensor:
     n, c, h, w = k.shape
     if out is None:

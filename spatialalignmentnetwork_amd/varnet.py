@@ -545,6 +545,35 @@ class VarNetBlock(nn.Module):
         ops.sens_expand_dc(neg_gm, sens, g_kout, zeros, mask_f, self.dc_weight.detach(), g_k)
         return g_k, g_ref
 
+    # -- image-domain form (what VarNet.forward runs) --------------------------------------------
+    def run_img(self, x: torch.Tensor, k0x: torch.Tensor, mask_f: torch.Tensor, sens: torch.Tensor, xin: Act,
+                x_out: torch.Tensor, key: str, m_next: Optional[torch.Tensor], dk_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The same cascade on the state x = ifft2(k): the mask depends on kx only, so the soft data consistency is
+        row-local there (ops.dc_rows).  xin channels 0, 1 already hold m = sum_c conj(S_c) x_c (written by the previous
+        cascade's launch); this one writes x_out = x - w D(x) - r S and the next cascade's m into ``m_next``."""
+        n, c, h, w = x.shape
+        r = ARENA.get(f"{key}.r", (n, 2, h, w), x.device)
+        self.model.run(xin, r, key)
+        ops.dc_rows(x, sens, k0x, mask_f, self.dc_weight.detach(), r, x_out, m_next, dk_out)
+        self._tape = (x, None, mask_f, sens, r, key)
+        self._dk = dk_out
+        return x_out
+
+    def run_bwd_img(self, g_xout: torch.Tensor, g_sens: Optional[torch.Tensor], want_ref_grad: bool):
+        """Backward of the last run_img().  g_xout = dL/dx' (complex; the caller may not reuse it).  Returns
+        (dL/dx, dL/d ref or None).  With D_lin = ifft_x M fft_x (Hermitian):
+            dL/dr = -sum_c conj(S_c) g_c          dL/dw = -Re sum conj(fft_x g) M (fft_x x - k0x)
+            dL/dx = g - w D_lin(g) + g_m S        (g_m = NormUnet backward of dL/dr, through m = sum_c conj(S_c) x_c)"""
+        x, _, mask_f, sens, r, key = self._tape
+        n, c, h, w = x.shape
+        dev = x.device
+        g_r = ARENA.get("bwd.g_r", (n, 2, h, w), dev)
+        g_d = torch.empty_like(g_xout)
+        _grad_of(self.dc_weight).add_(ops.dc_rows_bwd(g_xout, sens, mask_f, self.dc_weight.detach(), g_d, g_r, self._dk))
+        g_m, g_ref = self.model.run_bwd(g_r, key, want_ref_grad)
+        ops.sens_grad_prop(g_sens, r, g_xout, x, g_m, g_d, sens)
+        return g_d, g_ref
+
     def forward(self, current_kspace: torch.Tensor, ref_kspace: torch.Tensor, mask: torch.Tensor,
                 sens_maps: torch.Tensor, ref_image: Optional[torch.Tensor]) -> torch.Tensor:
         n, c, h, w = current_kspace.shape
@@ -581,50 +610,60 @@ class VarNet(nn.Module):
         if self.use_ref:
             ref = ref.contiguous()
             ref1 = ops.rss(ref)                          # varnet.py:475-476
-        k = masked_kspace                                # cascade 0 reads k0 itself: no clone (varnet.py:473)
+        # The cascades run on the IMAGE-domain state x_j = ifft2(k_j) (VarNetBlock.run_img): k0x = ifft_y(k0) is the data
+        # term, x_0 = ifft2(k0), m_0 = sum_c conj(S_c) x_0; every cascade is then ONE row-local launch besides its U-Net,
+        # and the output rss(ifft2(k_T)) (varnet.py:484-486) is rss(x_T).
+        k0x = ARENA.get("cas.k0x", (n, c, h, w), dev, dtype=torch.complex64)
+        ops.fft_cols(masked_kspace, True, out=k0x)
+        T = len(self.cascades)
         if not retain:
-            xin = self.cascades[0].model.input_buffer(n, h, w, dev, "cas")
-            if self.use_ref:
-                self.cascades[0].model.set_ref(xin, ref1)
-            k_buf = ARENA.get("cas.k", (n, c, h, w), dev, dtype=torch.complex64)
-            # each cascade's DC kernel also leaves the inverse column transform of its result: the next
-            # cascade (and the final ifft2 + rss) start from it -> 3 FFT launches per cascade instead of 4
-            cols = ARENA.get("cas.cols", (n, c, h, w), dev, dtype=torch.complex64)
-            have = None
-            for cascade in self.cascades:
-                k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_buf, "cas", k_cols=have, next_cols=cols)
-                have = cols
-            return ops.ifft2_rss(k, cols=have)
-        # training: every cascade keeps its own activations and its own k-space buffers
+            xin = self.cascades[0].model.input_buffer(n, h, w, dev, "cas") if T else None
+            x = ARENA.get("cas.x", (n, c, h, w), dev, dtype=torch.complex64)
+            ops.fft2c(masked_kspace, inverse=True, out=x)
+            if T:
+                if self.use_ref:
+                    self.cascades[0].model.set_ref(xin, ref1)
+                ops.sens_reduce(masked_kspace, sens, xin.buf)
+            for j, cascade in enumerate(self.cascades):
+                cascade.run_img(x, k0x, mask_f, sens, xin, x, "cas", xin.buf if j + 1 < T else None)
+            return ops.rss(x)
+        # training: every cascade keeps its own activations, state and data-consistency residual
+        x = ARENA.get("cas.x0", (n, c, h, w), dev, dtype=torch.complex64)
+        ops.fft2c(masked_kspace, inverse=True, out=x)
+        xins = []
         for j, cascade in enumerate(self.cascades):
-            key = f"cas{j}"
-            xin = cascade.model.input_buffer(n, h, w, dev, key)
+            xin = cascade.model.input_buffer(n, h, w, dev, f"cas{j}")
             if self.use_ref:
                 cascade.model.set_ref(xin, ref1)
-            k_out = ARENA.get(f"{key}.kout", (n, c, h, w), dev, dtype=torch.complex64)
-            cols = ARENA.get("cas.cols", (n, c, h, w), dev, dtype=torch.complex64)
-            k = cascade.run(k, masked_kspace, mask_f, sens, xin, k_out, key, k_cols=cols if j else None, next_cols=cols)
-        out = ops.ifft2_rss(k, cols=cols if len(self.cascades) else None)
-        self._train_state = (k, out, ref, ref1)
+            xins.append(xin)
+        if T:
+            ops.sens_reduce(masked_kspace, sens, xins[0].buf)
+        for j, cascade in enumerate(self.cascades):
+            key = f"cas{j}"
+            x_out = ARENA.get(f"{key}.xout", (n, c, h, w), dev, dtype=torch.complex64)
+            dk = ARENA.get(f"{key}.dk", (n, c, h, w), dev, dtype=torch.complex64)
+            x = cascade.run_img(x, k0x, mask_f, sens, xins[j], x_out, key, xins[j + 1].buf if j + 1 < T else None, dk)
+        out = ops.rss(x)
+        self._train_state = (x, out, ref, ref1)
         return out
 
     def backward(self, g_img: torch.Tensor, want_ref_grad: bool = False) -> Optional[torch.Tensor]:
         """Backward of the last training-mode forward().  g_img = dL/d(output image) [N,1,H,W].
         Accumulates every parameter gradient (cascades, dc weights, sensitivity net) and returns
         dL/d(ref) (the `ref` argument of forward) when asked."""
-        k_last, out, ref, ref1 = self._train_state
-        x = ops.fft2c(k_last, inverse=True)
-        g_x = ops.rss_bwd(x, out, g_img.contiguous())
-        g_k = ops.fft2c(g_x)                             # adjoint of the ortho ifft2
-        g_sens = torch.zeros_like(k_last)
+        x_last, out, ref, ref1 = self._train_state
+        g_x = ops.rss_bwd(x_last, out, g_img.contiguous())          # dL/dx_T: the state is already in the image domain
+        g_sens = torch.zeros_like(x_last)
         g_ref1 = None
         for cascade in reversed(self.cascades):
-            g_k, g_ref = cascade.run_bwd(g_k, g_sens, want_ref_grad and self.use_ref)
+            g_x, g_ref = cascade.run_bwd_img(g_x, g_sens, want_ref_grad and self.use_ref)
             if g_ref is not None:
                 if g_ref1 is None:
                     g_ref1 = g_ref
                 else:
                     ops.add(ops.full(g_ref1), ops.full(g_ref), ops.full(g_ref1))
+        # x_0 = ifft2(k0) and m_0 depend on the sensitivity maps only through m_0 = sum_c conj(S_c) x_0, which
+        # run_bwd_img of cascade 0 has already accounted for; k0 itself needs no gradient
         self.sens_net.backward(g_sens)
         if g_ref1 is None:
             return None

@@ -177,6 +177,63 @@ def test_normunet_backward_with_constant_plane(S):
         assert (prm.grad.cpu() - wantp).abs().max().item() <= 1e-3 * max(wantp.abs().max().item(), 1e-12), name
 
 
+# ------------------------------------------------------------------ image-domain cascade boundary
+@pytest.mark.parametrize("n,c,h,w", [(2, 1, 320, 320), (1, 3, 320, 320), (2, 3, 48, 80), (1, 2, 46, 368), (2, 1, 30, 45), (1, 1, 6, 320)])
+def test_dc_rows_vs_kspace_formula(S, n, c, h, w):
+    """san_dc_rows (one row-local launch per cascade on x = ifft2(k)) against the reference's k-space update
+    k' = k - w where(M, k - k0, 0) - fft2(r S), m' = sum_c ifft2(k')_c conj(S_c) (varnet.py:508-530) evaluated in
+    float64 on the CPU; backward form against autograd of the same expression; row lengths 320 (register kernel),
+    80 / 45 (radix 2-5) and 368 (radix 23)."""
+    F = torch.fft
+    x = cplx("dcr.x", (n, c, h, w))
+    sens = cplx("dcr.s", (n, c, h, w))
+    sens = sens / (S.O.rss(sens) + 1e-6)
+    k0 = cplx("dcr.k0", (n, c, h, w))
+    r = cplx("dcr.r", (n, 1, h, w))
+    mask = (philox("dcr.m", (w,)) > 0.3).float()
+    mask[:3] = 1
+    dcw = torch.tensor([0.8])
+    k0 = k0 * mask                                                     # a masked acquisition
+    x64 = x.to(torch.complex128).requires_grad_(True)
+    s64, r64 = sens.to(torch.complex128).requires_grad_(True), r.to(torch.complex128).requires_grad_(True)
+    w64 = dcw.double().requires_grad_(True)
+    k = F.fft2(x64, norm="ortho")
+    k1 = k - w64 * torch.where(mask.bool(), k - k0.to(torch.complex128), torch.zeros((), dtype=torch.complex128)) - F.fft2(r64 * s64, norm="ortho")
+    x1 = F.ifft2(k1, norm="ortho")
+    m1 = (x1 * s64.conj()).sum(1, keepdim=True)
+    # forward through the library
+    k0x = S.ops.fft_cols(g(k0), True)
+    assert rel_err(k0x.cpu(), F.ifft(k0.to(torch.complex128), dim=-2, norm="ortho")) < 3e-6
+    r_planar = g(torch.cat([r.real, r.imag], 1))
+    x_out = torch.empty((n, c, h, w), device=DEV, dtype=torch.complex64)
+    m_out = torch.zeros((n, 3, h, w), device=DEV)
+    dk = torch.empty_like(x_out)
+    S.ops.dc_rows(g(x), g(sens), k0x, g(mask), g(dcw), r_planar, x_out, m_out, dk)
+    assert rel_err(x_out.cpu(), x1.detach()) < 3e-6
+    assert rel_err(torch.complex(m_out[:, 0:1], m_out[:, 1:2]).cpu(), m1.detach()) < 3e-6
+    assert m_out[:, 2].abs().sum().item() == 0                       # channel 2 (the reference image) untouched
+    xa = g(x).clone()
+    S.ops.dc_rows(xa, g(sens), k0x, g(mask), g(dcw), r_planar, xa, None)     # in place, no coil combination
+    assert torch.equal(xa, x_out)
+    # backward: L = Re sum conj(gw) x'  ->  dL/dx, dL/dr, dL/dw, and the propagation / sensitivity-map pass
+    gw = cplx("dcr.g", (n, c, h, w))
+    (x1 * gw.to(torch.complex128).conj()).real.sum().backward()
+    g_d = torch.empty_like(x_out)
+    g_r = torch.empty((n, 2, h, w), device=DEV)
+    d_w = S.ops.dc_rows_bwd(g(gw), g(sens), g(mask), g(dcw), g_d, g_r, dk)
+    assert rel_err(g_d.cpu(), x64.grad) < 3e-6                        # (no path through m here: gd only)
+    assert rel_err(torch.complex(g_r[:, 0:1], g_r[:, 1:2]).cpu(), r64.grad) < 3e-6
+    assert abs(d_w.item() - w64.grad.item()) < 3e-5 * max(1.0, abs(w64.grad.item()))
+    # dL/dS of x' (only the -r S term depends on S) and gd += gm S
+    gm = cplx("dcr.gm", (n, 1, h, w))
+    gS = torch.zeros_like(x_out)
+    g_d2 = g_d.clone()
+    S.ops.sens_grad_prop(gS, r_planar, g(gw), g(x), g(torch.cat([gm.real, gm.imag], 1)), g_d2, g(sens))
+    assert rel_err(g_d2.cpu(), x64.grad + gm.to(torch.complex128) * sens.to(torch.complex128)) < 3e-6
+    want_gs = s64.grad + gm.to(torch.complex128).conj() * x.to(torch.complex128)      # + the m = sum conj(S) x term
+    assert rel_err(gS.cpu(), want_gs) < 3e-6
+
+
 # ------------------------------------------------------------------ single layers
 def test_varnetblock_step_and_sens_expand_golden(S, ops_golden):
     """One cascade with a real regulariser through VarNetBlock.forward, and the stand-alone sens_expand
@@ -387,7 +444,9 @@ def test_cascade_checksums_full_320(S):
     net_R(k_samp, (~pruned).to(DEV), g(as_t(gold["img_warped"])), int(w * 0.25 * 0.32))
     want = gold["cascade_checksums"]
     for j in range(12):
-        k = S.ops.GLOBAL_ARENA.get(f"cas{j}.kout", (1, 1, w, w), torch.device(DEV), dtype=torch.complex64).cpu()
+        # the cascades keep the image-domain state x_j = ifft2(k_j): transform it back for the k-space checksums
+        xj = S.ops.GLOBAL_ARENA.get(f"cas{j}.xout", (1, 1, w, w), torch.device(DEV), dtype=torch.complex64)
+        k = S.ops.fft2c(xj).cpu()
         got = np.array([k.real.double().sum().item(), k.imag.double().sum().item(), k.abs().double().pow(2).sum().sqrt().item()])
         l2 = want[j, 2]
         # sums of 102,400 values of magnitude ~L2/320 carry ~1e-5 of relative noise through 12 cascades; L2 itself ~1e-5
@@ -442,8 +501,9 @@ def test_e2e_multicoil_640x368_golden(S):
     assert np.all(np.abs(got[:, :2] - want[:, :2]) < 2e-3 * want[:, 2:3])
     cs = gold["cascade_checksums"]
     for j in range(12):
-        k = S.ops.GLOBAL_ARENA.get(f"cas{j}.kout", (n, c, h, w), torch.device(DEV), dtype=torch.complex64).cpu()
-        assert abs(k.abs().double().pow(2).sum().sqrt().item() - cs[j, 2]) < 1e-4 * cs[j, 2], j
+        xj = S.ops.GLOBAL_ARENA.get(f"cas{j}.xout", (n, c, h, w), torch.device(DEV), dtype=torch.complex64).cpu()
+        # ortho transforms: the k-space L2 norm is the image-domain L2 norm
+        assert abs(xj.abs().double().pow(2).sum().sqrt().item() - cs[j, 2]) < 1e-4 * cs[j, 2], j
 
 
 def test_multicoil_two_cascade_train_step_golden(S):
