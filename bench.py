@@ -45,7 +45,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
 BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak
-BF16X3_PRODUCTS = 6.0        # bf16 products the bf16x3 kernels execute per fp32 MAC
+BF16X3_PRODUCTS = 6.0        # bf16 products the bf16x3 kernels execute per fp32 MAC (3 with --dtype bf16x2, 1 with bf16)
 
 
 def parse_args(argv=None):
@@ -62,6 +62,10 @@ def parse_args(argv=None):
     ap.add_argument("--cascades", type=int, default=12)
     ap.add_argument("--mode", choices=["infer", "train"], default="train",
                     help="train (default): the full optimisation step incl. the gradient all-reduce; infer: forward only")
+    ap.add_argument("--dtype", choices=["fp32", "bf16x2", "bf16"], default="fp32",
+                    help="arithmetic of the matrix-core convolutions / weight gradients: fp32 = operands split in three bf16 "
+                         "parts, six products per MAC (fp32-equivalent: the parity-checked default); bf16x2 = two parts, three "
+                         "products; bf16 = plain bf16 (BASELINE configs[1] as written).  FFT / DC / norms / losses are fp32 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -215,7 +219,7 @@ def launch_test(args):
         dist.destroy_process_group()
 
 
-def roofline_entry(key, d, dt, steps, pmc, match_profile):
+def roofline_entry(key, d, dt, steps, pmc, match_profile, products=BF16X3_PRODUCTS):
     """One roofline object from a KernelTimer family record (see the module docstring for the definitions)."""
     sec = d["ms"] * 1e-3                       # rate over the bracketed launches, applied to all launches
     extra = {}
@@ -224,10 +228,10 @@ def roofline_entry(key, d, dt, steps, pmc, match_profile):
         ach = d["work"] / sec / 1e12           # ALGORITHMIC TFLOP/s
         if key.endswith("_bf16x3"):
             peak = BF16_PEAK_TFLOPS
-            extra = {"dtype": "bf16 matrix cores, operands split in three (6 bf16 products per fp32 MAC)",
-                     "executed_tflops": BF16X3_PRODUCTS * ach, "executed_frac": BF16X3_PRODUCTS * ach / peak,
-                     "bf16x3_ceiling_tflops": peak / BF16X3_PRODUCTS,
-                     "frac_of_bf16x3_ceiling": ach / (peak / BF16X3_PRODUCTS)}
+            extra = {"dtype": f"bf16 matrix cores, {int(products)} bf16 product(s) per MAC",
+                     "executed_tflops": products * ach, "executed_frac": products * ach / peak,
+                     "bf16x3_ceiling_tflops": peak / products,
+                     "frac_of_bf16x3_ceiling": ach / (peak / products)}
         else:
             peak = FP32_PEAK_TFLOPS
             extra = {"dtype": "fp32 MFMA"}
@@ -272,11 +276,13 @@ def main(argv=None):
         assert nccl_ranks == world, (nccl_ranks, world)
 
     from spatialalignmentnetwork_amd import ops, synth
+    ops.set_conv_precision(args.dtype)
     n = args.batch
     h = args.height or args.size
     w = args.width or args.size
     c = args.coils
     net = build_model(n, h, w, args.cascades, dev, coils=c, sparsity=args.sparsity)
+    net.conv_dtype = {"fp32": "bf16x3"}.get(args.dtype, args.dtype)     # CSModel.update() / test() select it per call
     img_full, img_aux = synth.phantom_pair(n, c, h, w, seed=1234 + rank)
     img_full, img_aux = img_full.to(dev), img_aux.to(dev)
 
@@ -338,6 +344,50 @@ def main(argv=None):
         barrier()
         dti = sdist.max_over_ranks(time.perf_counter() - t1, dist, dev)
         infer = {"value": n * world * args.steps / dti, "unit": "slices/s", "ms_per_step": 1e3 * dti / args.steps}
+    variants = None
+    if args.dtype == "fp32" and args.mode == "train" and not args.graph:
+        # the narrow-precision modes of the same step (BASELINE configs[1] is written "bf16"): timed the same way, fewer
+        # steps, judged by the PSNR of their reconstruction against the fp32-equivalent one just computed
+        ref_rec = net.img_rec.detach().clone()
+        variants = {}
+        vsteps = max(3, args.steps // 2)
+        for mode in ("bf16x2", "bf16"):
+            net.conv_dtype = mode
+            ops.set_conv_precision(mode)
+            net.train()
+            for _ in range(2):
+                train_step(net, img_full, img_aux)
+            torch.cuda.synchronize()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(vsteps):
+                train_step(net, img_full, img_aux)
+            torch.cuda.synchronize()
+            barrier()
+            dtt = sdist.max_over_ranks(time.perf_counter() - t2, dist, dev)
+            net.eval()
+            one_step(net, img_full, img_aux)
+            torch.cuda.synchronize()
+            barrier()
+            t3 = time.perf_counter()
+            for _ in range(vsteps):
+                one_step(net, img_full, img_aux)
+            torch.cuda.synchronize()
+            barrier()
+            dti2 = sdist.max_over_ranks(time.perf_counter() - t3, dist, dev)
+            variants[mode] = {"train_slices_per_s": n * world * vsteps / dtt, "train_ms_per_step": 1e3 * dtt / vsteps,
+                              "inference_slices_per_s": n * world * vsteps / dti2, "inference_ms_per_step": 1e3 * dti2 / vsteps,
+                              "steps": vsteps}
+        # (the weights moved during the variants' training steps, so the PSNR is taken on a fresh fp32-equivalent pass)
+        net.conv_dtype = "bf16x3"
+        ops.set_conv_precision("bf16x3")
+        ref_rec = one_step(net, img_full, img_aux).detach().clone()
+        for mode in variants:
+            with ops.conv_precision(mode):
+                rec = one_step(net, img_full, img_aux)
+            mse = ((rec.double() - ref_rec.double()) ** 2).mean().item()
+            variants[mode]["psnr_vs_fp32_equivalent_db"] = 10.0 * __import__("math").log10(float(ref_rec.max().item()) ** 2 / max(mse, 1e-30))
+        torch.cuda.synchronize()
     if rank == 0:
         total_slices = n * world * args.steps
         acc = int(round(1.0 / args.sparsity))
@@ -346,8 +396,12 @@ def main(argv=None):
             "metric": "slices/sec (320x320, 12-cascade VarNet+align)", "value": total_slices / dt, "unit": "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (convolutions from 16-18 channels up and all weight gradients: bf16 matrix cores, operands split "
-                     "in three, six products per MAC, fp32-equivalent; FFT / DC / norms / losses fp32)",
+            "dtype": {"fp32": "f32 (convolutions from 16-18 channels up and all weight gradients: bf16 matrix cores, operands split "
+                              "in three, six products per MAC, fp32-equivalent; FFT / DC / norms / losses fp32)",
+                      "bf16x2": "bf16x2 (matrix-core convolutions / weight gradients on two bf16 parts per operand, three products per "
+                                "MAC, fp32 accumulate; FFT / DC / norms / losses fp32; PSNR-judged, not parity-checked)",
+                      "bf16": "bf16 (matrix-core convolutions / weight gradients on plain bf16 operands, fp32 accumulate; FFT / DC / "
+                              "norms / losses fp32; PSNR-judged, not parity-checked)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": ("train step (regime Rec: fwd + hand-written bwd + grad all-reduce + AdamW) " if args.mode == "train"
                                     else "inference pass ") + f"set_input+align+warp+VarNet{args.cascades}+SSIM, "
@@ -361,6 +415,8 @@ def main(argv=None):
         }
         if infer is not None:
             out["inference"] = infer
+        if variants is not None:
+            out["narrow_precision"] = variants
         if timer is not None:
             tot = timer.totals()
             dom = max(tot, key=lambda k: tot[k]["ms"])
@@ -382,7 +438,8 @@ def main(argv=None):
                                ("wgrad3x3", "roofline_wgrad_fp32")):
                 if key not in tot or (field != "roofline" and key == dom) or tot[key]["sampled_launches"] == 0:
                     continue
-                out[field] = roofline_entry(key, tot[key], dt, args.steps, pmc, match)
+                out[field] = roofline_entry(key, tot[key], dt, args.steps, pmc, match and args.dtype == "fp32",
+                                            {"fp32": 6.0, "bf16x2": 3.0, "bf16": 1.0}[args.dtype])
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)

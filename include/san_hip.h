@@ -302,6 +302,15 @@ int san_window_copy_fwd(const float* x, int x_ctot, int x_coff, const float* sc,
                         int hx, int wx, float* y, int y_ctot, int y_coff, int hy, int wy, int off_y, int off_x,
                         int mode, int n, int c, void* stream);
 
+/* Narrow-precision modes of every bf16 matrix-core convolution / transposed convolution / weight gradient
+ * (BASELINE.json configs[1] names bf16, configs[4] fp8 U-Net convolutions; the reference's seam is
+ * torch.cuda.amp.autocast, model.py:83-87,104).  parts = 3: operands split in three bf16 parts, six products per MAC,
+ * fp32-equivalent (default, the only mode held to the 1e-4 parity bar); 2: two parts (16 mantissa bits), three
+ * products; 1: plain bf16, one product.  Judged by PSNR against the parts = 3 output.  FFT, data consistency,
+ * normalisation statistics and losses are fp32 in every mode.  Process-wide; returns SAN_E_ARG outside 1..3. */
+int san_set_conv_precision(int parts);
+int san_get_conv_precision(void);
+
 /* ------------------------------------------- image-domain cascade boundary */
 
 /* out = (i)fft along H only (ortho: scale 1/sqrt(h)) of interleaved complex [planes, h, w].  k0x = ifft_y(k0) is the

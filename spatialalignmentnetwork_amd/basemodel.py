@@ -67,10 +67,19 @@ def ckpt_save(ckpt: dict, folder: str) -> None:
                 np.savez(f, **{k: v.detach().cpu().numpy() for k, v in val.items()})
 
 
+def _torch_load(path: str):
+    """Legacy torch-pickle checkpoints (basemodel.py:17-41 accepts them): tensors / state_dicts load with
+    weights_only=True; a pickled Config object needs the full unpickler, which executes code -- only for files you trust."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def ckpt_load(folder: str) -> dict:
     """basemodel.py:17-41: a directory of npz blobs (or torch pickles), or a single torch file."""
     if os.path.isfile(folder):
-        return torch.load(folder, map_location="cpu")
+        return _torch_load(folder)
     ckpt = {}
     for key in sorted(os.listdir(folder)):
         path = os.path.join(folder, key)
@@ -79,14 +88,14 @@ def ckpt_load(folder: str) -> dict:
             try:
                 cfg.load(path)
             except (UnicodeDecodeError, json.JSONDecodeError):
-                cfg = torch.load(path, map_location="cpu")
+                cfg = _torch_load(path)
             ckpt[key] = cfg
             continue
         try:
             with np.load(path) as z:
                 ckpt[key] = {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
         except Exception:
-            ckpt[key] = torch.load(path, map_location="cpu")
+            ckpt[key] = _torch_load(path)
     return ckpt
 
 

@@ -29,6 +29,8 @@
 #include <cstdint>
 #include <cstdlib>
 
+void san_wgrad_set_parts(int parts);             // san_wgrad_bf16.hip
+
 namespace {
 
 constexpr int kT = 256;
@@ -109,7 +111,10 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
 // only the tile's interior is staged.
 // FLAT: run-time tile shape (narrow images: full-width rows, see tile_geom); otherwise the 32 x 8 tile with
 // compile-time offsets between a wave's blocks (immediate LDS offsets in the K-loop).
-template <int MB, bool WD, int KS, bool FLAT>
+// NP: operand parts used.  3 = the fp32-equivalent form (six products); 2 = a1 + a2 (16 mantissa bits, three products
+// a1w1 + a1w2 + a2w1); 1 = plain bf16 (one product).  The reduced forms are the narrow-precision modes selected with
+// san_set_conv_precision (judged by PSNR, not by the 1e-4 parity bar); the packed weight image is the same for all.
+template <int MB, bool WD, int KS, bool FLAT, int NP>
 __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     constexpr int kSteps = KS == 3 ? 7 : 1;            // (shadows the 3x3 constant)
     static_assert(KS == 3 || WD, "the 1x1 form reads its weights directly");
@@ -258,7 +263,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
+                for (int p = 0; p < NP; ++p) {
                     if constexpr (WD) wq[m][p].u = wsrc[((s * a.nblkp + m) * 3 + p) * 64];
                     else wq[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
                 }
@@ -285,8 +290,8 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
             }
             if (s_loff[s] >= 0) {
                 *reinterpret_cast<uint4*>(lds_a + s_loff[s]) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-                *reinterpret_cast<uint4*>(lds_a + kPartB + s_loff[s]) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
-                *reinterpret_cast<uint4*>(lds_a + 2 * kPartB + s_loff[s]) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
+                if constexpr (NP > 1) *reinterpret_cast<uint4*>(lds_a + kPartB + s_loff[s]) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+                if constexpr (NP > 2) *reinterpret_cast<uint4*>(lds_a + 2 * kPartB + s_loff[s]) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
             }
         }
         if constexpr (!WD) {
@@ -303,7 +308,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
+                for (int p = 0; p < NP; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
         };
         __syncthreads();
         if (chunk + 1 < c1) prefetch(chunk + 1);
@@ -316,9 +321,9 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 load_x(s + 1, xa[(s + 1) & 1]);
             }
 #pragma unroll
-            for (int pw = 0; pw < 3; ++pw)
+            for (int pw = 0; pw < NP; ++pw)
 #pragma unroll
-                for (int px = 0; px < 3 - pw; ++px)
+                for (int px = 0; px < NP - pw; ++px)
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -643,12 +648,14 @@ int pick_mb(int cout, int tiles) {
     return best > 5 ? 5 : best;
 }
 
-template <int MB, bool WD, int KS, bool FLAT>
-int launch_bf(const BArgs& a, hipStream_t s) {
+int g_conv_np = 3;             // operand parts of the bf16 convolutions / weight gradients (san_set_conv_precision)
+
+template <int MB, bool WD, int KS, bool FLAT, int NP>
+int launch_bfn(const BArgs& a, hipStream_t s) {
     constexpr size_t lds = 3 * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -656,8 +663,17 @@ int launch_bf(const BArgs& a, hipStream_t s) {
         configured = true;
     }
     const int total = a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT>), dim3(total), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT, NP>), dim3(total), dim3(kT), lds, s, a);
     return SAN_OK;
+}
+
+template <int MB, bool WD, int KS, bool FLAT>
+int launch_bf(const BArgs& a, hipStream_t s) {
+    switch (g_conv_np) {
+        case 1: return launch_bfn<MB, WD, KS, FLAT, 1>(a, s);
+        case 2: return launch_bfn<MB, WD, KS, FLAT, 2>(a, s);
+        default: return launch_bfn<MB, WD, KS, FLAT, 3>(a, s);
+    }
 }
 
 template <int MB, bool WD, int KS = 3>
@@ -670,6 +686,18 @@ int launch_b(const BArgs& a, hipStream_t s) {
 }  // namespace
 
 extern "C" {
+
+// Narrow-precision modes of every bf16 matrix-core convolution and weight gradient (BASELINE configs 2 / 5 name bf16 /
+// fp8 U-Net convolutions judged by PSNR): parts = 3 fp32-equivalent (default), 2 = 16 mantissa bits (three products),
+// 1 = plain bf16 (one product).  FFT, data consistency, normalisation statistics and losses stay fp32 in every mode.
+int san_set_conv_precision(int parts) {
+    SAN_CHECK_ARG(parts >= 1 && parts <= 3, "parts must be 1, 2 or 3");
+    g_conv_np = parts;
+    san_wgrad_set_parts(parts);
+    return SAN_OK;
+}
+
+int san_get_conv_precision(void) { return g_conv_np; }
 
 // tuning / test hook: wd = -1 automatic, 0 LDS-staged weights, 1 weights-direct where MB <= 4; mb = -1 automatic or 2..5
 int san_conv_bf16x3_set_tuning(int wd, int mb) {

@@ -311,7 +311,8 @@ struct WDArgs {
     int Q, P, ci_b, ncog, cin_pad, cout_pad;
 };
 
-template <int NB>
+// NP: operand parts used (3 = fp32-equivalent, six products; 2 = three products; 1 = plain bf16), san_set_conv_precision
+template <int NB, int NP>
 __global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -449,9 +450,9 @@ __global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int pa = 0; pa < 3; ++pa)
+            for (int pa = 0; pa < NP; ++pa)
 #pragma unroll
-                for (int pb = 0; pb < 3 - pa; ++pb)
+                for (int pb = 0; pb < NP - pa; ++pb)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         acc[kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.f[pa][kx].v, dyf[nb][pb].v, acc[kx][nb], 0, 0, 0);
@@ -512,7 +513,7 @@ struct W1Args {
     int Q, P, ci_b, ncog, cin_pad, cout_pad;
 };
 
-template <int NB>
+template <int NB, int NP>
 __global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -597,9 +598,9 @@ __global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
         load();                                         // next step's pieces (clamped past the end; masked when converted)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pa = 0; pa < 3; ++pa)
+        for (int pa = 0; pa < NP; ++pa)
 #pragma unroll
-            for (int pb = 0; pb < 3 - pa; ++pb)
+            for (int pb = 0; pb < NP - pa; ++pb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
                     acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[pa].v, dyf[nb][pb].v, acc[nb], 0, 0, 0);
@@ -734,20 +735,31 @@ int launch_wb(const WBArgs& a, int grid, hipStream_t s) {
     return SAN_OK;
 }
 
-template <int NB>
-int launch_wd(const WDArgs& a, int grid, hipStream_t s) {
+int g_wgrad_np = 3;            // operand parts (san_set_conv_precision)
+
+template <int NB, int NP>
+int launch_wdn(const WDArgs& a, int grid, hipStream_t s) {
     constexpr size_t lds = (size_t)(kWaves - 1) * 9 * NB * 64 * sizeof(f4);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_direct_kernel<NB>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_direct_kernel<NB, NP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 weight gradient", (int)lds);
             return SAN_E_UNSUPPORTED;
         }
         configured = true;
     }
-    hipLaunchKernelGGL((wgrad_bf16x3_direct_kernel<NB>), dim3(grid), dim3(kWT), lds, s, a);
+    hipLaunchKernelGGL((wgrad_bf16x3_direct_kernel<NB, NP>), dim3(grid), dim3(kWT), lds, s, a);
     return SAN_OK;
+}
+
+template <int NB>
+int launch_wd(const WDArgs& a, int grid, hipStream_t s) {
+    switch (g_wgrad_np) {
+        case 1: return launch_wdn<NB, 1>(a, grid, s);
+        case 2: return launch_wdn<NB, 2>(a, grid, s);
+        default: return launch_wdn<NB, 3>(a, grid, s);
+    }
 }
 
 SplitOne split_one(const float* src, int ctot, int coff, int C, int CB, const float* scale, const float* shift, float slope,
@@ -812,7 +824,11 @@ W1Plan w1_plan(int n, int hw, int cin, int cout) {
 template <int NB>
 int launch_w1(const W1Args& a, int grid, hipStream_t s) {
     constexpr size_t lds = (size_t)(kWaves - 1) * NB * 64 * sizeof(f4);
-    hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB>), dim3(grid), dim3(kWT), lds, s, a);
+    switch (g_wgrad_np) {
+        case 1: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 1>), dim3(grid), dim3(kWT), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 2>), dim3(grid), dim3(kWT), lds, s, a); break;
+        default: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 3>), dim3(grid), dim3(kWT), lds, s, a); break;
+    }
     return SAN_OK;
 }
 
@@ -827,6 +843,9 @@ bool wb_direct(const float* x, const float* dy, int n, int h, int w, int x_ctot,
 }
 
 }  // namespace
+
+// the split-plane form (rows that are not 16-byte aligned) always runs with three parts
+void san_wgrad_set_parts(int parts) { g_wgrad_np = parts; }
 
 extern "C" {
 

@@ -39,7 +39,7 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
 class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced"}
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -58,6 +58,14 @@ class CSModel(BaseModel):
         self.optim_T = FusedAdamW(self.net_T.parameters(), lr=cfg.lr, weight_decay=0)
         self.optim_R = FusedAdamW(self.net_R.parameters(), lr=cfg.lr, weight_decay=0)
         self.use_amp = bool(get("use_amp", False))
+        # The reference's mixed-precision seam is torch.cuda.amp.autocast(enabled=use_amp) around the forwards
+        # (model.py:83-87,104).  Here it selects the arithmetic of the matrix-core convolutions: cfg.conv_dtype in
+        # {"bf16x3" (fp32-equivalent, default), "bf16x2", "bf16"}; use_amp without conv_dtype means plain bf16.  FFT, data
+        # consistency, normalisation statistics and losses are fp32 in every mode; no GradScaler is needed (bf16 has
+        # fp32's exponent range).
+        self.conv_dtype = get("conv_dtype", None)      # None: follow use_amp (which eval.py:41 switches off after loading)
+        if self.conv_dtype is not None and self.conv_dtype not in ops.CONV_PRECISIONS:
+            raise ValueError(f"cfg.conv_dtype {self.conv_dtype!r}: choose from {sorted(ops.CONV_PRECISIONS)}")
         self.device = torch.device("cpu")
 
     # ------------------------------------------------------------------ inputs
@@ -117,6 +125,13 @@ class CSModel(BaseModel):
         self.net_T.backward(g_off)
 
     def update(self):
+        with ops.conv_precision(self._conv_mode()):
+            return self._update()
+
+    def _conv_mode(self) -> str:
+        return self.conv_dtype or ("bf16" if self.use_amp else "bf16x3")
+
+    def _update(self):
         """One optimisation step.  Regimes 'None' (train R, T frozen) and 'Rec' (train T and R through
         the warp), model.py:193-216; the GAN regimes are out of scope.  fp32 throughout: the
         GradScaler of the reference's AMP path is a no-op here."""
@@ -180,7 +195,7 @@ class CSModel(BaseModel):
     def test(self):
         """model.py:265-286 without the GAN branch; returns -PSNR."""
         assert self.training is False
-        with torch.no_grad():
+        with torch.no_grad(), ops.conv_precision(self._conv_mode()):
             self.loss_all = 0
             self.forwardT()
             self.loss_all = 0

@@ -161,6 +161,10 @@ class Arena:
         self._bufs.clear()
 
 
+# One process-wide arena: every model instance in a process shares the activation / tape buffers (they are keyed by name
+# and shape), so run ONE model's forward + backward at a time -- a forward of model B between A.forward and A.backward
+# overwrites A's tape.  Buffers of shapes that are no longer used stay allocated until Arena.clear() (the last partial
+# batch of an epoch costs a second set of per-cascade buffers; 288 GB of HBM make that a non-issue for this workload).
 GLOBAL_ARENA = Arena()
 
 
@@ -502,6 +506,34 @@ class _PackRegistryBf16(_PackRegistry):
 
 
 PACKS16 = _PackRegistryBf16()
+
+# Arithmetic of the matrix-core convolutions / weight gradients (san_set_conv_precision).  "bf16x3" is the default and the
+# only mode held to the 1e-4 parity bar; "bf16x2" / "bf16" are the narrow-precision modes (PSNR-judged).
+CONV_PRECISIONS = {"bf16x3": 3, "fp32": 3, "bf16x2": 2, "bf16": 1}
+
+
+def set_conv_precision(mode: str) -> str:
+    """Select the operand parts of every bf16 matrix-core kernel (process-wide); returns the previous mode's name."""
+    if mode not in CONV_PRECISIONS:
+        raise ValueError(f"conv precision {mode!r}: choose from {sorted(CONV_PRECISIONS)}")
+    prev = {3: "bf16x3", 2: "bf16x2", 1: "bf16"}[lib().query("san_get_conv_precision")]
+    lib().call("san_set_conv_precision", CONV_PRECISIONS[mode])
+    return prev
+
+
+class conv_precision:
+    """``with ops.conv_precision("bf16"): ...`` -- the mode inside the block, the previous one afterwards."""
+
+    def __init__(self, mode: str):
+        self.mode = mode
+
+    def __enter__(self):
+        self.prev = set_conv_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        set_conv_precision(self.prev)
+        return False
 USE_BF16X3 = [os.environ.get("SAN_NO_BF16X3", "0") != "1"]
 
 
@@ -861,19 +893,22 @@ def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, ar
     _on_side_stream(dy, x, lambda: _conv2d_wgrad(x, dy, dw, accumulate, arena))
 
 
-def _conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
-    """dw [cout, cin, ks, ks] (+)= correlation of dy with the lazily activated forward input x."""
+def _conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
+                  scratch_tag: str = "") -> None:
+    """dw [cout, cin, ks, ks] (+)= correlation of dy with the lazily activated forward input x.  ``scratch_tag``: callers
+    that run IN LINE on the main stream inside wgrad_overlap pass their own tag, so that their partial-sum scratch is
+    not the buffer a side-stream weight gradient may still be using."""
     cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
     assert x.c == cin and dy.c == cout and x.buf.shape[2:] == dy.buf.shape[2:]
     flops = 2.0 * x.n * x.h * x.w * cout * cin * ks * ks
     if USE_BF16X3[0] and lib().query("san_conv_wgrad_bf16x3_eligible", x.n, x.h, x.w, cin, cout, ks):
-        _conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena)
+        _conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena, scratch_tag)
         return
     if ks == 1 and wgrad1x1_bf16x3_ok(x, dy):
-        _conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena)
+        _conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena, scratch_tag=scratch_tag)
         return
     P = lib().query("san_conv_wgrad_partitions", x.n, x.h, x.w, cin, cout, ks)
-    partial = arena.get("wgrad_partial", (P * cout * cin * ks * ks,), x.buf.device)
+    partial = arena.get("wgrad_partial" + scratch_tag, (P * cout * cin * ks * ks,), x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff, cout,
             _p(_chk(dw, name="dw")), int(accumulate), _p(partial), x.n, x.h, x.w, ks, _stream())
     _timed("wgrad3x3" if ks == 3 else "wgrad1x1", flops, "FLOP", lambda: lib().call("san_conv2d_wgrad", *args),
@@ -884,7 +919,8 @@ def conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = Fa
     _on_side_stream(dy, x, lambda: _conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena))
 
 
-def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
+def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
+                         scratch_tag: str = "") -> None:
     """The 3x3 weight gradient on the bf16 matrix cores (three-way split operands, fp32-level accuracy;
     csrc/san_wgrad_bf16.hip).  conv2d_wgrad dispatches here where san_conv_wgrad_bf16x3_eligible says so."""
     cout, cin, ks = dw.shape[0], dw.shape[1], dw.shape[2]
@@ -892,7 +928,7 @@ def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = F
     if not lib().query("san_conv_wgrad_bf16x3_supported", x.n, x.h, x.w, cin, cout, ks):
         raise RuntimeError("layer too large for the bf16x3 weight gradient")
     nbytes = lib().query("san_conv_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
-    scratch = arena.scratch("wgrad_bf16x3", nbytes, x.buf.device)
+    scratch = arena.scratch("wgrad_bf16x3" + scratch_tag, nbytes, x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
             cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
     _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args),
@@ -910,14 +946,14 @@ def conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool =
 
 
 def _conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
-                            transposed: bool = False) -> None:
+                            transposed: bool = False, scratch_tag: str = "") -> None:
     """The 1x1 weight gradient on the bf16 matrix cores (csrc/san_wgrad_bf16.hip, wgrad1x1_bf16x3_kernel).
     transposed: dw is laid out [cin, cout(, ...)] -- a ConvTranspose2d weight [Cin, Cout, 2, 2] seen as [Cin, 4 Cout]."""
     cin, cout = x.c, dy.c
     assert dw.numel() == cin * cout and x.buf.shape[2:] == dy.buf.shape[2:]
     assert transposed or (dw.shape[0], dw.shape[1]) == (cout, cin)
     nbytes = lib().query("san_conv1x1_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
-    scratch = arena.scratch("wgrad_bf16x3", nbytes, x.buf.device)
+    scratch = arena.scratch("wgrad_bf16x3" + scratch_tag, nbytes, x.buf.device)
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
             cout, _p(_chk(dw, name="dw")), int(accumulate), int(transposed), _p(scratch), x.n, x.h, x.w, _stream())
     _timed("wgrad1x1_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin, "FLOP", lambda: lib().call("san_conv1x1_wgrad_bf16x3", *args))

@@ -119,7 +119,7 @@ class TransposeConvBlock(nn.Module):
             ops.conv2d_wgrad1x1_bf16x3(x, dyp, _grad_of(wt), accumulate=True, transposed=True)
         else:
             dwv = ARENA.get("bwd.dwv", (4 * cout, cin, 1, 1), dev)
-            ops._conv2d_wgrad(x, dyp, dwv, accumulate=False)      # in line: its result is consumed right here
+            ops._conv2d_wgrad(x, dyp, dwv, accumulate=False, scratch_tag=".inline")      # in line (own scratch): its result is consumed right here
             _grad_of(wt).add_(dwv.view(4 * cout, cin).t().reshape(cin, cout, 2, 2))
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:

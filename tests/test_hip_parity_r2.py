@@ -623,3 +623,80 @@ def test_update_data_parallel_two_ranks(S, tmp_path):
         den += (d_ref ** 2).sum().item()
     print("parameter displacement after 2 steps, data-parallel vs whole batch, relative L2:", (num / den) ** 0.5)
     assert den > 0 and (num / den) ** 0.5 < 5e-2
+
+
+# ------------------------------------------------------------------ narrow-precision modes (BASELINE configs 2 / 5)
+def _psnr(ref, x):
+    mse = ((ref.double() - x.double()) ** 2).mean().item()
+    return 10.0 * np.log10(float(ref.max().item()) ** 2 / max(mse, 1e-30))
+
+
+@pytest.mark.parametrize("mode,bar_conv,bar_wgrad", [("bf16x2", 3e-5, 3e-5), ("bf16", 6e-3, 6e-3)])
+def test_conv_precision_modes_layers(S, mode, bar_conv, bar_wgrad):
+    """The two- and one-part forms of the matrix-core convolution / weight gradient against float64: two bf16 parts carry
+    16 mantissa bits (2^-17 = 7.6e-6 per operand), one part 8 bits (2^-9 = 2e-3).  Measured values are printed."""
+    ops = S.ops
+    n, cin, cout, h, w = 2, 72, 36, 40, 40
+    x, wt = philox("np.x", (n, cin, h, w)), philox("np.w", (cout, cin, 3, 3)) * 0.05
+    dy = philox("np.dy", (n, cout, h, w))
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), padding=1)
+    x64, w64 = x.double(), wt.double().requires_grad_(True)
+    (torch.nn.functional.conv2d(x64, w64, padding=1) * dy.double()).sum().backward()
+    try:
+        with ops.conv_precision(mode):
+            y = torch.empty((n, cout, h, w), device=DEV)
+            ops.conv2d(ops.full(g(x)), g(wt), None, ops.full(y))
+            dw = torch.zeros((cout, cin, 3, 3), device=DEV)
+            ops.conv2d_wgrad_bf16x3(ops.full(g(x)), ops.full(g(dy)), dw)       # (conv2d_wgrad may pick the fp32 kernel here)
+            torch.cuda.synchronize()
+        e1, e2 = rel_err(y.cpu().double(), ref), rel_err(dw.cpu().double(), w64.grad)
+        print(f"{mode}: conv rel-L2 {e1:.2e}, weight gradient rel-L2 {e2:.2e}")
+        assert e1 < bar_conv and e2 < bar_wgrad
+        # back in the default mode the same call is fp32-equivalent again
+        ops.conv2d(ops.full(g(x)), g(wt), None, ops.full(y))
+        assert rel_err(y.cpu().double(), ref) < 3e-6
+    finally:
+        ops.set_conv_precision("bf16x3")
+
+
+@pytest.mark.parametrize("mode,bar_db", [("bf16x2", 70.0), ("bf16", 30.0)])
+def test_conv_precision_modes_e2e_psnr(S, mode, bar_db):
+    """The 12-cascade network at 320 x 320 with the convolutions in a narrow-precision mode, judged by PSNR against the
+    fp32-equivalent output of the same network ('bf16 / fp8 configs cannot meet 1e-4; judge those by
+    PSNR').  Also one optimisation step of the small model with cfg.use_amp (the reference's AMP seam, model.py:83-87)."""
+    gold = load_golden("e2e_full_320.npz")
+    w = 320
+    img_full, img_aux = S.synth.phantom_pair(1, 1, w, w, seed=1234)
+    pruned = as_t(gold["pruned"])
+    net_R = S.varnet.VarNet(num_cascades=12, sens_chans=8, sens_pools=4, chans=18, pools=4, use_ref=True)
+    _load(S, net_R, 1236)
+    net_R.to(DEV).eval()
+    keep = (~pruned).float().to(DEV)
+    k_samp = S.ops.fft2c(g(img_full), colmask_out=keep)
+    warped = g(as_t(gold["img_warped"]))
+    try:
+        with torch.no_grad():
+            ref = net_R(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32)).cpu()
+            with S.ops.conv_precision(mode):
+                rec = net_R(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32)).cpu()
+        assert rel_err(ref, as_t(gold["img_rec"])) < 1e-4
+        psnr, rel = _psnr(ref, rec), rel_err(rec, ref)
+        print(f"{mode}: PSNR vs the fp32-equivalent output {psnr:.1f} dB, rel-L2 {rel:.2e}")
+        assert psnr > bar_db
+        cfg = S.base.Config(sparsity=0.25, lr=1e-4, shape=80, coils=3, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                            weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=True, conv_dtype=mode, num_cascades=2,
+                            chans=18, sens_chans=8, pools=2, sens_pools=2)
+        net = S.model.CSModel(cfg)
+        net.net_mask.pruned = S.synth.equispaced_pruned(80, 0.25, 0)
+        _load(S, net.net_T, 41)
+        _load(S, net.net_R, 42)
+        net.to(DEV).train()
+        f, a_ = S.synth.phantom_pair(2, 3, 48, 80, seed=40)
+        before = [p.detach().clone() for p in net.net_R.parameters()]
+        net.set_input(g(f), g(a_))
+        net.update()
+        assert S.ops.lib().query("san_get_conv_precision") == 3          # update() restores the process-wide mode
+        after = list(net.net_R.parameters())
+        assert all(torch.isfinite(p).all() for p in after) and any(not torch.equal(p, q) for p, q in zip(after, before))
+    finally:
+        S.ops.set_conv_precision("bf16x3")
