@@ -301,15 +301,18 @@ def main(argv=None):
     if args.graph:
         # the arena, packed weights, twiddles and masks exist after warm-up, so the step neither
         # allocates through the library nor synchronises: it is capture-safe
-        graph = torch.cuda.CUDAGraph()
-        cap_stream = torch.cuda.Stream()
-        cap_stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(cap_stream):
-            one_step(net, img_full, img_aux)
-            torch.cuda.current_stream().synchronize()
-            with torch.cuda.graph(graph, stream=cap_stream):
+        if args.mode == "train":
+            graph = net.capture_update(img_full, img_aux, warmup=1)      # fork / join of the weight-gradient stream included
+        else:
+            graph = torch.cuda.CUDAGraph()
+            cap_stream = torch.cuda.Stream()
+            cap_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap_stream):
                 one_step(net, img_full, img_aux)
-        torch.cuda.current_stream().wait_stream(cap_stream)
+                torch.cuda.current_stream().synchronize()
+                with torch.cuda.graph(graph, stream=cap_stream):
+                    one_step(net, img_full, img_aux)
+            torch.cuda.current_stream().wait_stream(cap_stream)
         graph.replay()
         torch.cuda.synchronize()
         step = graph.replay
@@ -351,9 +354,10 @@ def main(argv=None):
         ref_rec = net.img_rec.detach().clone()
         variants = {}
         vsteps = max(3, args.steps // 2)
-        for mode in ("bf16x2", "bf16"):
-            net.conv_dtype = mode
-            ops.set_conv_precision(mode)
+        for mode in ("mixed", "bf16x2", "bf16"):
+            # "mixed": fp32-equivalent forward (the parity-checked outputs), backward convolutions on two bf16 parts
+            net.conv_dtype, net.bwd_dtype = ("bf16x3", "bf16x2") if mode == "mixed" else (mode, None)
+            ops.set_conv_precision(net.conv_dtype)
             net.train()
             for _ in range(2):
                 train_step(net, img_full, img_aux)
@@ -379,11 +383,11 @@ def main(argv=None):
                               "inference_slices_per_s": n * world * vsteps / dti2, "inference_ms_per_step": 1e3 * dti2 / vsteps,
                               "steps": vsteps}
         # (the weights moved during the variants' training steps, so the PSNR is taken on a fresh fp32-equivalent pass)
-        net.conv_dtype = "bf16x3"
+        net.conv_dtype, net.bwd_dtype = "bf16x3", None
         ops.set_conv_precision("bf16x3")
         ref_rec = one_step(net, img_full, img_aux).detach().clone()
         for mode in variants:
-            with ops.conv_precision(mode):
+            with ops.conv_precision("bf16x3" if mode == "mixed" else mode):
                 rec = one_step(net, img_full, img_aux)
             mse = ((rec.double() - ref_rec.double()) ** 2).mean().item()
             variants[mode]["psnr_vs_fp32_equivalent_db"] = 10.0 * __import__("math").log10(float(ref_rec.max().item()) ** 2 / max(mse, 1e-30))
@@ -411,7 +415,7 @@ def main(argv=None):
                        "parallelism": f"dp{world} (independent slice shards; one RCCL all-reduce of the flat gradient "
                                       f"buffers per step)" if args.mode == "train" else
                                       f"dp{world} (independent slice shards, no data-path collective)",
-                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks},
+                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks, "hip_graph": bool(args.graph)},
         }
         if infer is not None:
             out["inference"] = infer

@@ -485,6 +485,10 @@ int san_image_metrics(const float* gt, const float* pred, double* out, int n, in
  * All four buffers: count floats, 16-byte aligned. */
 int san_adamw_step(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int step, float grad_scale, void* stream);
+/* The same step with the count kept in device memory (one int64: steps taken so far; the call uses *step_dev + 1 and
+ * then advances it), so that a captured hipGraph of the training step replays correctly. */
+int san_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, long long* step_dev, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

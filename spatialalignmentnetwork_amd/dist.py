@@ -171,6 +171,7 @@ class ParamBucket(GradBucket):
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.steps = 0
+        self.step_dev = None            # int64 [1] on the device once FusedAdamW runs in its graph-safe form
 
     def owns(self, params) -> bool:
         """True while every parameter still lives in this bucket (``module.to()`` re-allocates them)."""

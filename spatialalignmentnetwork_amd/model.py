@@ -39,7 +39,7 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
 class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype"}
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -64,6 +64,12 @@ class CSModel(BaseModel):
         # consistency, normalisation statistics and losses are fp32 in every mode; no GradScaler is needed (bf16 has
         # fp32's exponent range).
         self.conv_dtype = get("conv_dtype", None)      # None: follow use_amp (which eval.py:41 switches off after loading)
+        # cfg.bwd_dtype (optional): arithmetic of the BACKWARD convolutions (data and weight gradients) only, e.g. "bf16x2"
+        # under an fp32-equivalent forward: the outputs keep the 1e-4 parity, the gradients carry 16 mantissa bits
+        # (4e-6 per layer, against the 1e-2-level fp32-vs-fp64 noise of the reference's own gradients).  Default: as forward.
+        self.bwd_dtype = get("bwd_dtype", None)
+        if self.bwd_dtype is not None and self.bwd_dtype not in ops.CONV_PRECISIONS:
+            raise ValueError(f"cfg.bwd_dtype {self.bwd_dtype!r}: choose from {sorted(ops.CONV_PRECISIONS)}")
         if self.conv_dtype is not None and self.conv_dtype not in ops.CONV_PRECISIONS:
             raise ValueError(f"cfg.conv_dtype {self.conv_dtype!r}: choose from {sorted(ops.CONV_PRECISIONS)}")
         self.device = torch.device("cpu")
@@ -153,8 +159,8 @@ class CSModel(BaseModel):
         opts = [self.optim_R] + ([self.optim_T] if train_T else [])
         for o in opts:
             o.zero_grad()                       # one memset of the flat gradient buffer per network
-        with ops.wgrad_overlap():               # weight gradients on a side stream, joined before the exchange / step
-            self.backward(train_T)
+        with ops.wgrad_overlap(), ops.conv_precision(self.bwd_dtype or self._conv_mode()):
+            self.backward(train_T)              # weight gradients on a side stream, joined before the exchange / step
         dist = _active_dist()
         scale = 1.0
         if dist is not None:                    # data parallel: one in-place RCCL all-reduce per network;
@@ -164,6 +170,35 @@ class CSModel(BaseModel):
         for o in opts:
             o.step(grad_scale=scale)
         del self.loss_all
+
+    def capture_update(self, img_full, img_aux=None, warmup: int = 3):
+        """Capture ``set_input(img_full, img_aux); update()`` into a hipGraph and return it (``graph.replay()`` runs one
+        optimisation step on whatever the two input tensors hold at that time: refill them in place between replays).
+        ~3,000 launches per step then cost one graph launch on the host.  The step count of both optimisers moves to
+        device memory (FusedAdamW.device_step); the weight gradients' side stream is captured as a fork / join.
+        Single-process only: the data-parallel all-reduce is not captured."""
+        assert self.training is True
+        if _active_dist() is not None:
+            raise NotImplementedError("capture_update with an active process group")
+        for o in (self.optim_R, self.optim_T):
+            o.device_step = True
+            o.bucket()                          # parameters move into the flat buffers now: their addresses are final
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):          # warm-up off the default stream: arena, packs, twiddles, flat buffers exist
+            for _ in range(max(1, warmup)):
+                self.set_input(img_full, img_aux)
+                self.update()
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        for reg in (ops.PACKS, ops.PACKS16):   # job tables are uploaded now, not inside the capture
+            reg.ensure_table(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.set_input(img_full, img_aux)
+            self.update()
+        return graph
 
     def sync_replicas(self, dist=None) -> None:
         """Broadcast rank 0's parameters, AdamW moments, BatchNorm buffers and column mask to every rank (what DDP does

@@ -378,6 +378,16 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
                int(step), grad_scale, _stream())
 
 
+def adamw_step_dev(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float,
+                   eps: float, weight_decay: float, step_dev: torch.Tensor, grad_scale: float = 1.0) -> None:
+    """adamw_step with the step count in device memory (int64 [1]): capture-safe (san_adamw_step_dev)."""
+    for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, name=name)
+    _chk(step_dev, torch.int64, "step_dev")
+    lib().call("san_adamw_step_dev", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+               _p(step_dev), grad_scale, _stream())
+
+
 class _PackRegistry:
     """Packed copies of conv weights (the layouts the MFMA kernels read).  Inference packs a weight
     once; in training every weight changes every step, so ALL registered (weight, mode) pairs are
@@ -430,8 +440,9 @@ class _PackRegistry:
     def _batch(self):
         lib().call("san_conv_pack_batch", _p(self.table), len(self.order), _stream())
 
-    def _run(self, device):
-        """Re-pack every live job on `device` in one launch."""
+    def ensure_table(self, device):
+        """Build (upload) the device job table if it is stale.  Called before a hipGraph capture: the upload is a
+        host-to-device copy, which a capturing stream does not allow."""
         if self.table is not None and any(j["wref"]() is None for j in self.order):
             self.table = None                   # a registered weight was freed: never read through its old pointer
         if self.table is None or self.table.device != device:
@@ -443,6 +454,10 @@ class _PackRegistry:
                 self._fill_job(row, j)
                 host[i] = torch.tensor(list(row), dtype=torch.int64)
             self.table = host.to(device)
+
+    def _run(self, device):
+        """Re-pack every live job on `device` in one launch."""
+        self.ensure_table(device)
         if self.order:
             self._batch()
         for j in self.order:
@@ -823,7 +838,7 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
 #   * allocator-owned operands get record_stream();
 #   * leaving the context joins the side stream back into the main one (before the all-reduce / optimiser).
 # ---------------------------------------------------------------------------
-_WG = {"stream": None, "main": None, "pool": {}, "busy": {}}
+_WG = {"stream": None, "main": None, "pool": {}, "busy": {}, "rr": {}}
 WGRAD_OVERLAP = [os.environ.get("SAN_NO_WGRAD_OVERLAP", "0") != "1"]
 
 
@@ -844,6 +859,7 @@ class wgrad_overlap:
         _WG["stream"] = None
         _WG["main"] = None
         _WG["busy"].clear()
+        _WG["rr"].clear()
         return False
 
 
@@ -858,6 +874,14 @@ def wgrad_dy_buffer(name: str, shape, device, arena: Arena = GLOBAL_ARENA) -> to
     one of up to four rotating copies without a side-stream reader in flight (else the oldest, after waiting)."""
     if _WG["stream"] is None:
         return arena.get(name, shape, device)
+    if torch.cuda.is_current_stream_capturing():
+        # hipGraph capture: events may not be queried; take the copies round-robin and wait (a graph dependency, not a
+        # host wait) for the reader that used this copy four requests ago
+        k = _WG["rr"].get(name, 0)
+        _WG["rr"][name] = (k + 1) & 3
+        t = arena.get(name if k == 0 else f"{name}#{k}", shape, device, _no_wait=True)
+        _wait_if_busy(t)
+        return t
     first = None
     for k in range(4):
         t = arena.get(name if k == 0 else f"{name}#{k}", shape, device, _no_wait=True)

@@ -18,6 +18,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(self.param_groups) != 1:
             raise ValueError("FusedAdamW keeps one flat buffer: a single parameter group")
         self._bucket = None
+        self.device_step = False      # True: keep the step count on the device (set it BEFORE capturing update() into a hipGraph)
 
     def _params(self):
         return self.param_groups[0]["params"]
@@ -43,7 +44,20 @@ class FusedAdamW(torch.optim.Optimizer):
             raise NotImplementedError("closures are not supported")
         b = self.bucket()
         g = self.param_groups[0]
-        b.steps += 1
-        ops.adamw_step(b.flat_p, b.flat, b.exp_avg, b.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
-                       float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), b.steps, float(grad_scale))
+        if self.device_step or torch.cuda.is_current_stream_capturing():
+            # graph-safe form: the step count lives in device memory (a captured launch cannot change its arguments)
+            if b.step_dev is None:
+                b.step_dev = torch.tensor([b.steps], dtype=torch.int64, device=b.flat_p.device)
+            self.device_step = True
+            ops.adamw_step_dev(b.flat_p, b.flat, b.exp_avg, b.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
+                               float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), b.step_dev, float(grad_scale))
+        else:
+            b.steps += 1
+            ops.adamw_step(b.flat_p, b.flat, b.exp_avg, b.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
+                           float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), b.steps, float(grad_scale))
         ops.bump_weight_epoch()
+
+    def steps_taken(self) -> int:
+        """Optimisation steps so far (reads the device counter in the graph-safe form: a host synchronisation)."""
+        b = self.bucket()
+        return int(b.step_dev.item()) if (self.device_step and b.step_dev is not None) else b.steps

@@ -700,3 +700,88 @@ def test_conv_precision_modes_e2e_psnr(S, mode, bar_db):
         assert all(torch.isfinite(p).all() for p in after) and any(not torch.equal(p, q) for p, q in zip(after, before))
     finally:
         S.ops.set_conv_precision("bf16x3")
+
+
+# ------------------------------------------------------------------ hipGraph capture of the training step
+def test_captured_update_matches_eager(S):
+    """CSModel.capture_update(): three replays of the captured 'Rec' step (two streams forked / joined inside the graph,
+    AdamW step count in device memory, weights re-packed by the captured batch launch) leave bit-identical parameters and
+    BatchNorm buffers to three eager steps from the same state."""
+    n, c, h, w = 2, 3, 48, 80
+
+    def make():
+        cfg = S.base.Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                            weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=2, chans=18,
+                            sens_chans=8, pools=2, sens_pools=2)
+        net = S.model.CSModel(cfg)
+        net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+        _load(S, net.net_T, 41)
+        _load(S, net.net_R, 42)
+        net.to(DEV).train()
+        for o in (net.optim_R, net.optim_T):
+            o.device_step = True
+        return net
+
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    xf, xa = g(img_full), g(img_aux)
+    eager = make()
+    for _ in range(5):                                   # capture_update(warmup=2) + 3 replays = 5 steps
+        eager.set_input(xf, xa)
+        eager.update()
+    torch.cuda.synchronize()
+    want = {k: v.detach().cpu().clone() for m in (eager.net_R, eager.net_T) for k, v in m.state_dict().items()}
+    assert eager.optim_R.steps_taken() == 5
+    cap = make()
+    graph = cap.capture_update(xf, xa, warmup=2)          # 2 warm-up steps; the capture itself does not execute
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert cap.optim_R.steps_taken() == 5 and cap.optim_T.steps_taken() == 5
+    got = {k: v.detach().cpu() for m in (cap.net_R, cap.net_T) for k, v in m.state_dict().items()}
+    bad = [k for k in want if not torch.equal(want[k], got[k])]
+    assert not bad, bad[:5]
+    # new data through the same graph: refill the captured input tensors in place
+    f2, a2 = S.synth.phantom_pair(n, c, h, w, seed=77)
+    xf.copy_(g(f2))
+    xa.copy_(g(a2))
+    graph.replay()
+    eager.set_input(xf, xa)
+    eager.update()
+    torch.cuda.synchronize()
+    assert all(torch.equal(p.cpu(), q.cpu()) for p, q in zip(eager.net_R.parameters(), cap.net_R.parameters()))
+
+
+def test_mixed_backward_precision_full_320(S):
+    """cfg.bwd_dtype = 'bf16x2' (fp32-equivalent forward, backward convolutions on two bf16 parts) on the damped full-size
+    fixture: the forward is untouched (same bars as test_train_step_full_320_golden) and the gradients stay within the
+    same 3x-the-reference's-own-noise bars against the float64 arbiter."""
+    gold = load_golden("train_full_320.npz")
+    tag, n, c, h, w = "damped", 2, 1, 320, 320
+    cfg = S.base.Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                        weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=12, bwd_dtype="bf16x2")
+    net = S.model.CSModel(cfg)
+    net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+    _load(S, net.net_T, 2235)
+    net.net_R.load_state_dict(S.synth.fill_params(_shapes(net.net_R), seed=2236, damp=0.1))
+    net.to(DEV).train()
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=2234)
+    net.set_input(g(img_full), g(img_aux))
+    net.loss_all = 0
+    net.forwardT()
+    net.forwardR()
+    assert rel_err(net.img_rec.cpu(), as_t(gold[f"{tag}.f32.img_rec"])) < 1e-4
+    for o in (net.optim_R, net.optim_T):
+        o.zero_grad()
+    try:
+        with S.ops.wgrad_overlap(), S.ops.conv_precision(net.bwd_dtype):
+            net.backward(train_T=True)
+        torch.cuda.synchronize()
+    finally:
+        S.ops.set_conv_precision("bf16x3")
+    for nt, mod in (("R", net.net_R), ("T", net.net_T)):
+        named = [(nm, p.grad) for nm, p in mod.named_parameters()]
+        floor = float(gold[f"{tag}.ref32_vs_ref64.grad.{nt}"])
+        wn64, name64, pe64 = _digest_errors(S, named, gold, f"{tag}.f64.grad.{nt}.")
+        print(f"mixed backward, net_{nt}: probe-estimated relative L2 vs ref64 {pe64:.2e}, worst per-tensor norm {wn64:.2e} "
+              f"({name64}); reference fp32-vs-fp64 {floor:.2e}")
+        assert pe64 < max(3.0 * floor, 2e-3) and wn64 < max(3.0 * floor, 2e-3)
