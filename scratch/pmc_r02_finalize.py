@@ -4,8 +4,9 @@ HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are reported in KiB of 64-byte fab
 read is tallied at half its bytes (MI355X_MICROARCH.md, HBM section), other widths are uncalibrated -> the factors are
 calibrated in the same run on kernels of known traffic far beyond the 256 MiB Infinity Cache (scratch/pmc_traffic.py:
 apply_kernel 512 MiB in / out at 16 B and 4 B per lane, rss_kernel 512 MiB in at 8 B per lane).
-MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) per kernel family (the gfx94x MfmaUtil formula
-rocprofv3 falls back to on gfx950), next to SQ_BUSY_CYCLES and SQ_WAVE_CYCLES."""
+MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES (SIMD-cycles with the matrix pipe busy, summed over the chip: 16 per 16x16x32 bf16
+MFMA) / (elapsed cycles x 1024 SIMDs) per kernel family, elapsed = GRBM_GUI_ACTIVE / 8 (that counter comes back summed
+over the 8 XCDs); SQ_BUSY_CYCLES and SQ_WAVE_CYCLES are kept next to it."""
 import json
 import os
 import sys
@@ -37,7 +38,9 @@ for k, v in raw.items():
                  hbm_bytes_per_launch=int(f + w), read_factor=round(width.get(k, f16), 3))
     if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
         busy, gui = v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"], v["GRBM_GUI_ACTIVE"]["sum"]
-        e["mfma_busy"] = busy / (gui * 1024.0) if gui else None
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (the 1 GiB calibration copy reads 5.26 M "cycles" for ~310 us
+        # at ~2.1 GHz), so elapsed cycles = gui / 8 and the chip offers (gui / 8) * 1024 SIMD-cycles
+        e["mfma_busy"] = busy / (gui / 8.0 * 1024.0) if gui else None
         e["mfma_counters_avg_per_launch"] = {c: v[c]["avg"] for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
                                                                       "GRBM_GUI_ACTIVE") if c in v}
     kern[k] = e
@@ -45,15 +48,12 @@ alias = {"conv3x3": "conv_mfma_3x3", "conv3x3_bf16x3": "conv_bf16x3", "wgrad3x3_
 for a, b in alias.items():
     if b in kern:
         kern[a] = dict(kern[b])
-if "fft320_rows" in kern and "fft320_cols" in kern and "hbm_bytes_per_launch" in kern["fft320_rows"]:
-    r, c = kern["fft320_rows"], kern["fft320_cols"]
-    n = r["launches"] + c["launches"]
-    kern["fft_dc"] = {"launches": n, "hbm_bytes_per_launch": int((r["hbm_bytes_per_launch"] * r["launches"] + c["hbm_bytes_per_launch"] * c["launches"]) / n),
-                      "note": "launch-weighted average over the rows and (fused) columns kernels"}
+if "dc_rows" in kern and "hbm_bytes_per_launch" in kern["dc_rows"]:
+    kern["fft_dc"] = dict(kern["dc_rows"], note="the image-domain cascade kernel (forward launches with and without dk_out, and the backward form)")
 out = {"note": "rocprofv3 --pmc passes of scratch/pmc_traffic.py (calibration kernels + 3 train steps at N = 8, 320 x 320, 12 cascades), "
                "each counter set in its own run with --kernel-trace only (scratch/prof_r02.sh); corrected by scratch/pmc_r02_finalize.py",
        "calibration": cal, "fetch_factor": {"16B_per_lane": f16, "8B_per_lane": f8, "4B_per_lane": f4}, "write_factor": wf,
-       "mfma_busy_definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs), summed over the family's launches",
+       "mfma_busy_definition": "SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs), summed over the family's launches",
        "kernels": kern}
 json.dump(out, open(os.path.join(R, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
 print(json.dumps({k: {"hbm": v.get("hbm_bytes_per_launch"), "mfma_busy": v.get("mfma_busy")} for k, v in kern.items()}, indent=1))

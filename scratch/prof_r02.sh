@@ -33,6 +33,7 @@ def family(k):
             'conv_mfma_1x1' if 'conv_mfma_kernel' in k else
             'wgrad_vec_3x3' if 'conv_wgrad_vec_kernel<3' in k else
             'wgrad_vec_1x1' if 'conv_wgrad_vec_kernel<1' in k else
+            'dc_rows' if 'dc_rows' in k else
             'fft320_rows' if 'fft320_rows' in k else 'fft320_cols' if 'fft320_cols' in k else None)
 res = {}
 for d in ('/tmp/pmc_f', '/tmp/pmc_w', '/tmp/pmc_m'):

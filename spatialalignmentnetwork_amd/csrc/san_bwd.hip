@@ -667,13 +667,77 @@ WgradPlan wgrad_plan(int n, int h, int w, int cin, int cout, int ks, bool allow_
 //   mode 0 (plain affine, e.g. eval BatchNorm / identity): dy = sc * u
 //   mode 1 (InstanceNorm, biased var):  dy = sc * (u - mean(u) - yh * mean(u*yh))   per (n, c) plane
 // bwd_stats writes per-chunk (sum u, sum u*yh) partials; act_bwd sums the chunks itself.
+typedef float bf4 __attribute__((ext_vector_type(4)));
+
+// InstanceNorm + LeakyReLU backward of a whole (sample, channel) plane in ONE pass: the plane's g and y (<= V float4 per
+// thread each, 512 threads) stay in registers between the two reductions and the write of dy, so g and y are read once
+// instead of twice and there is one launch instead of two.  Planes of up to 512 * 4 * V values (V = 13: 160 x 160).
+template <int V>
+__global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
+                                                            const float* __restrict__ y, int y_ctot, int y_coff,
+                                                            const float* __restrict__ sc, const float* __restrict__ sh, float slope,
+                                                            float* __restrict__ dy, int d_ctot, int d_coff, int hw) {
+    __shared__ float red[16];
+    const int ch = blockIdx.x, n = blockIdx.y;
+    const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
+    const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
+    const bf4* gp = reinterpret_cast<const bf4*>(g + ((size_t)(n * g_ctot + g_coff + ch)) * hw);
+    const bf4* yp = reinterpret_cast<const bf4*>(y + ((size_t)(n * y_ctot + y_coff + ch)) * hw);
+    bf4* dp = reinterpret_cast<bf4*>(dy + ((size_t)(n * d_ctot + d_coff + ch)) * hw);
+    const int n4 = hw >> 2;
+    bf4 u[V], yh[V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i = threadIdx.x + 512 * k;
+        u[k] = bf4{0.f, 0.f, 0.f, 0.f};
+        yh[k] = bf4{0.f, 0.f, 0.f, 0.f};
+        if (i < n4) {
+            const bf4 gv = gp[i], yv = yp[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = fmaf(yv[e], s, b);
+                const float uu = gv[e] * (t >= 0.f ? 1.f : slope);
+                yh[k][e] = t;
+                u[k][e] = uu;
+                s1 += uu;
+                s2 = fmaf(uu, t, s2);
+            }
+        }
+    }
+    s1 = san_wave_total(s1);
+    s2 = san_wave_total(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s1;
+        red[8 + (threadIdx.x >> 6)] = s2;
+    }
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        t1 += (double)red[w];
+        t2 += (double)red[8 + w];
+    }
+    const float m1 = (float)(t1 / hw), m2 = (float)(t2 / hw);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i = threadIdx.x + 512 * k;
+        if (i < n4) {
+            bf4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = s * (u[k][e] - m1 - yh[k][e] * m2);
+            dp[i] = o;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kThreads)
 bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
                  const float* __restrict__ sc, const float* __restrict__ sh, float slope, int c, int hw, int tiles,
                  float* __restrict__ part) {
     __shared__ float red[8];
     const int t = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
-    const int chunk = (hw + tiles - 1) / tiles;
+    const int chunk = (((hw + tiles - 1) / tiles) + 3) & ~3;       // multiples of 4: every chunk starts 16-byte aligned
     const int lo = t * chunk;
     const int cnt = max(0, min(hw, lo + chunk) - lo);
     const float* gp = g + ((size_t)(n * g_ctot + g_coff + ch)) * hw + lo;
@@ -681,11 +745,31 @@ bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const floa
     const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
     const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    for (int i = threadIdx.x; i < cnt; i += kThreads) {
-        const float yh = fmaf(yp[i], s, b);
-        const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
-        s1 += u;
-        s2 = fmaf(u, yh, s2);
+    if ((((uintptr_t)gp | (uintptr_t)yp) & 15) == 0) {            // 16-byte loads (chunks of a 4-divisible plane are 4-divisible)
+        const int c4 = cnt >> 2;
+        for (int i = threadIdx.x; i < c4; i += kThreads) {
+            const bf4 gv = reinterpret_cast<const bf4*>(gp)[i], yv = reinterpret_cast<const bf4*>(yp)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float yh = fmaf(yv[e], s, b);
+                const float u = gv[e] * (yh >= 0.f ? 1.f : slope);
+                s1 += u;
+                s2 = fmaf(u, yh, s2);
+            }
+        }
+        for (int i = 4 * c4 + threadIdx.x; i < cnt; i += kThreads) {
+            const float yh = fmaf(yp[i], s, b);
+            const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
+            s1 += u;
+            s2 = fmaf(u, yh, s2);
+        }
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += kThreads) {
+            const float yh = fmaf(yp[i], s, b);
+            const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
+            s1 += u;
+            s2 = fmaf(u, yh, s2);
+        }
     }
     s1 = san_wave_total(s1);
     s2 = san_wave_total(s2);
@@ -722,6 +806,20 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
     const float* gp = g + ((size_t)(n * g_ctot + g_coff + ch)) * hw;
     const float* yp = y + ((size_t)(n * y_ctot + y_coff + ch)) * hw;
     float* dp = dy + ((size_t)(n * d_ctot + d_coff + ch)) * hw;
+    if ((hw & 3) == 0 && ((((uintptr_t)gp | (uintptr_t)yp | (uintptr_t)dp)) & 15) == 0) {
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < (hw >> 2); i += gridDim.x * kThreads) {
+            const bf4 gv = reinterpret_cast<const bf4*>(gp)[i], yv = reinterpret_cast<const bf4*>(yp)[i];
+            bf4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float yh = fmaf(yv[e], s, b);
+                const float u = gv[e] * (yh >= 0.f ? 1.f : slope);
+                o[e] = s * (u - m1 - yh * m2);
+            }
+            reinterpret_cast<bf4*>(dp)[i] = o;
+        }
+        return;
+    }
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads) {
         const float yh = fmaf(yp[i], s, b);
         const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
@@ -1239,6 +1337,8 @@ int san_plane_dot_stats(const float* g, int g_ctot, int g_coff, const float* y, 
     return SAN_OK;
 }
 
+static int g_act_bwd_fused = getenv("SAN_NO_ACT_BWD_FUSED") ? 0 : 1;     // tuning hook: 0 = always the two-kernel form
+
 int san_bwd_stat_tiles(int hw) {
     int t = san_cdiv(hw, 4096);
     return t < 1 ? 1 : (t > 32 ? 32 : t);
@@ -1256,6 +1356,21 @@ int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ct
                       d_coff + c <= d_ctot, "bad channel view");
     hipStream_t s = (hipStream_t)stream;
     const int tiles = san_bwd_stat_tiles(hw);
+    if (mode == 1 && (hw & 3) == 0 && hw <= 512 * 4 * 13 && g_act_bwd_fused &&
+        ((((uintptr_t)g | (uintptr_t)y | (uintptr_t)dy)) & 15) == 0) {
+        // the whole plane fits one workgroup's registers: statistics and gradient in one pass
+        const int v = san_cdiv(hw >> 2, 512);
+        const dim3 grid(c, n);
+#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw)
+        if (v <= 1) SAN_ABP(1);
+        else if (v <= 2) SAN_ABP(2);
+        else if (v <= 4) SAN_ABP(4);
+        else if (v <= 7) SAN_ABP(7);
+        else SAN_ABP(13);
+#undef SAN_ABP
+        SAN_LAUNCH_CHECK();
+        return SAN_OK;
+    }
     if (mode == 1) {
         hipLaunchKernelGGL(bwd_stats_kernel, dim3(tiles, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot,
                            y_coff, sc, sh, slope, c, hw, tiles, part);
