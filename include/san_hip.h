@@ -326,9 +326,9 @@ int san_fft_cols(const float* in, float* out, int planes, int h, int w, int inve
  * be NULL (term absent / result not wanted).  dk_out (optional): mask (fft_x(x) - k0x), kept for the backward pass.
  * backward != 0 (the DC term is self-adjoint; k0x, r_planar, dk_out must be NULL):
  *     x_out = g - dc_w ifft_x(mask fft_x(g)),   m_out = - sum_c conj(S_c) g_c   (gradient wrt the regulariser output),
- *     dcw_part[san_dc_rows_partials(n, h, w)] = per-workgroup partials of Re sum conj(fft_x(g)) dk_in, whose total is
+ *     dcw_part[san_dc_rows_partials(n, c, h, w)] = per-workgroup partials of Re sum conj(fft_x(g)) dk_in, whose total is
  *     -dL/d(dc_w). */
-int san_dc_rows_partials(int n, int h, int w);
+int san_dc_rows_partials(int n, int c, int h, int w);
 int san_dc_rows(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
                 const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, const float* dk_in,
                 float* dcw_part, int backward, int n, int c, int h, int w, void* stream);

@@ -21,11 +21,15 @@ rs = raw.get("cal_rss", {})
 # the two largest apply launches are the 16 B/lane shape (512 MiB), the next two the 4 B/lane shape (511.998 MiB)
 f_list, w_list = ap.get("FETCH_SIZE_list", []), ap.get("WRITE_SIZE_list", [])
 cal["raw_KiB"] = {"apply_FETCH": f_list, "apply_WRITE": w_list, "rss_FETCH": rs.get("FETCH_SIZE_list", [])}
-f16 = 512 * MiB / (max(f_list) * 1024) if f_list else 2.0
-f4 = 511.998 * MiB / (sorted(f_list)[0] * 1024) if len(f_list) >= 3 else f16
+# apply_kernel launches in descending raw order: the two 4 B / lane ones (511 x 513 planes: 511.998 MiB read and written), then
+# the two 16 B / lane ones (512 x 512: 512 MiB); rss_kernel reads 512 MiB at 8 B / lane
+f4 = 511.998 * MiB / (f_list[0] * 1024) if len(f_list) >= 4 else 2.0
+f16 = 512 * MiB / (f_list[2] * 1024) if len(f_list) >= 4 else 2.0
 f8 = 512 * MiB / (max(rs["FETCH_SIZE_list"]) * 1024) if rs.get("FETCH_SIZE_list") else f16
-wf = 512 * MiB / (max(w_list) * 1024) if w_list else 1.0
+wf4 = 511.998 * MiB / (w_list[0] * 1024) if len(w_list) >= 4 else 1.0
+wf = 512 * MiB / (w_list[2] * 1024) if len(w_list) >= 4 else 1.0
 width = {"conv_mfma_3x3": f4, "conv_mfma_1x1": f4, "conv_bf16x3": f4, "conv_bf16x3_1x1": f4}
+wwidth = {"conv_mfma_3x3": wf4, "conv_mfma_1x1": wf4, "conv_bf16x3": wf4, "conv_bf16x3_1x1": wf4}
 kern = {}
 for k, v in raw.items():
     if k.startswith("cal_"):
@@ -33,7 +37,7 @@ for k, v in raw.items():
     e = {}
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         f = v["FETCH_SIZE"]["avg"] * 1024 * width.get(k, f16)
-        w = v["WRITE_SIZE"]["avg"] * 1024 * wf
+        w = v["WRITE_SIZE"]["avg"] * 1024 * wwidth.get(k, wf)
         e.update(launches=v["FETCH_SIZE"]["launches"], fetch_bytes_per_launch=int(f), write_bytes_per_launch=int(w),
                  hbm_bytes_per_launch=int(f + w), read_factor=round(width.get(k, f16), 3))
     if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
@@ -52,7 +56,7 @@ if "dc_rows" in kern and "hbm_bytes_per_launch" in kern["dc_rows"]:
     kern["fft_dc"] = dict(kern["dc_rows"], note="the image-domain cascade kernel (forward launches with and without dk_out, and the backward form)")
 out = {"note": "rocprofv3 --pmc passes of scratch/pmc_traffic.py (calibration kernels + 3 train steps at N = 8, 320 x 320, 12 cascades), "
                "each counter set in its own run with --kernel-trace only (scratch/prof_r02.sh); corrected by scratch/pmc_r02_finalize.py",
-       "calibration": cal, "fetch_factor": {"16B_per_lane": f16, "8B_per_lane": f8, "4B_per_lane": f4}, "write_factor": wf,
+       "calibration": cal, "fetch_factor": {"16B_per_lane": f16, "8B_per_lane": f8, "4B_per_lane": f4}, "write_factor": {"16B_per_lane": wf, "4B_per_lane": wf4},
        "mfma_busy_definition": "SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs), summed over the family's launches",
        "kernels": kern}
 json.dump(out, open(os.path.join(R, "profiles", f"{tag}_pmc.json"), "w"), indent=1)

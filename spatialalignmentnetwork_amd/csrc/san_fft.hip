@@ -918,7 +918,11 @@ __global__ void __launch_bounds__(kThreads) dc_rows_kernel(const FftArgs a) {
 #pragma unroll
     for (int i = 0; i < kMaxAcc; ++i) acc[i] = make_float2(0.f, 0.f);
     float wsum = 0.f;
-    for (int c = 0; c < a.C; ++c) {
+    // multi-coil launches run one coil per workgroup (blockIdx.z) and leave the coil combination to coil_combine_kernel:
+    // a serial coil loop left 80 workgroups with 15 planes each at 640 x 368
+    const bool cpar = gridDim.z > 1;
+    const int c_lo = cpar ? blockIdx.z : 0, c_hi = cpar ? blockIdx.z + 1 : a.C;
+    for (int c = c_lo; c < c_hi; ++c) {
         const size_t base = ((size_t)(n * a.C + c) * H + h0) * W;
         __syncthreads();
         for (int e = tid; e < a.B * W; e += kThreads) bufA[e] = e < cnt ? a.in[base + e] : make_float2(0.f, 0.f);
@@ -969,7 +973,7 @@ __global__ void __launch_bounds__(kThreads) dc_rows_kernel(const FftArgs a) {
             }
         }
     }
-    if (a.out_real) {
+    if (a.out_real && !cpar) {
         const size_t rb = ((size_t)n * a.out_ctot * H + h0) * W;
 #pragma unroll
         for (int it = 0; it < kMaxAcc; ++it) {
@@ -986,7 +990,24 @@ __global__ void __launch_bounds__(kThreads) dc_rows_kernel(const FftArgs a) {
         float* red = reinterpret_cast<float*>(twf);         // (one __shared__ object only: the dynamic one may then be the full 160 KB)
         if ((tid & 63) == 0) red[tid >> 6] = wsum;
         __syncthreads();
-        if (tid == 0) a.dcw_part[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        if (tid == 0) a.dcw_part[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// m[n] = m_scale * sum_c conj(S[n,c]) q[n,c]  (planar into channels 0, 1 of [n, ctot, hw]); one pass over 2C planes
+__global__ void __launch_bounds__(kThreads) coil_combine_kernel(const float2* __restrict__ q, const float2* __restrict__ S,
+                                                                 float* __restrict__ out, int out_ctot, float m_scale, int C, int HW) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < HW; i += gridDim.x * kThreads) {
+        float ar = 0.f, ai = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const size_t e = ((size_t)n * C + c) * HW + i;
+            const float2 v = q[e], s = S[e];
+            ar += v.x * s.x + v.y * s.y;
+            ai += v.y * s.x - v.x * s.y;
+        }
+        out[(size_t)n * out_ctot * HW + i] = ar * m_scale;
+        out[(size_t)n * out_ctot * HW + HW + i] = ai * m_scale;
     }
 }
 
@@ -1429,11 +1450,11 @@ static void dc_rows_geom(int h, int w, int* B, int* gx) {
     *gx = san_cdiv(h, *B);
 }
 
-int san_dc_rows_partials(int n, int h, int w) {
-    if (n <= 0 || h <= 0 || w <= 0) return 0;
+int san_dc_rows_partials(int n, int c, int h, int w) {
+    if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return 0;
     int B, gx;
     dc_rows_geom(h, w, &B, &gx);
-    return gx * n;
+    return gx * n * (w == kN320 ? 1 : c);      // the general-length kernel runs one coil per workgroup when c > 1
 }
 
 int san_fft_cols(const float* in, float* out, int planes, int h, int w, int inverse, void* stream) {
@@ -1510,10 +1531,20 @@ int san_dc_rows(const float* x, const float* sens, const float* k0x, const float
             err = hipFuncSetAttribute(reinterpret_cast<const void*>(dc_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
     if (err != hipSuccess) return (int)err;
-    const dim3 grid(gx, n);
+    const dim3 grid(gx, n, c);
     if (backward) hipLaunchKernelGGL((dc_rows_kernel<1>), grid, dim3(kThreads), lds, s, a);
     else hipLaunchKernelGGL((dc_rows_kernel<0>), grid, dim3(kThreads), lds, s, a);
     SAN_LAUNCH_CHECK();
+    if (c > 1 && m_out) {
+        // coil combination in its own pass: of the result (forward) or of the incoming gradient (backward)
+        const float2* q = backward ? (const float2*)x : (const float2*)x_out;
+        SAN_CHECK_ARG(q != nullptr, "the coil combination of a multi-coil forward launch needs x_out");
+        int bx = san_cdiv(h * w, kThreads);
+        if (bx > 1024) bx = 1024;
+        hipLaunchKernelGGL(coil_combine_kernel, dim3(bx, n), dim3(kThreads), 0, s, q, (const float2*)sens, m_out, m_ctot,
+                           a.m_scale, c, h * w);
+        SAN_LAUNCH_CHECK();
+    }
     return SAN_OK;
 }
 

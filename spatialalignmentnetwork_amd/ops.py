@@ -304,7 +304,7 @@ def dc_rows_bwd(g: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, dc_w: t
     """Backward form: g_out = g - dc_w ifft_x(mask fft_x(g)); h_out = -sum_c conj(S_c) g_c (planar: the gradient wrt the
     regulariser output); returns dL/d(dc_w) as a 0-d tensor (fixed-order sum of the per-workgroup partials)."""
     n, c, h, w = g.shape
-    part = GLOBAL_ARENA.get("dcw_part", (lib().query("san_dc_rows_partials", n, h, w),), g.device)
+    part = GLOBAL_ARENA.get("dcw_part", (lib().query("san_dc_rows_partials", n, c, h, w),), g.device)
     lib().call("san_dc_rows", _p(_creal(g, "g")), _p(_creal(sens, "sens")), _p(None), _p(_chk(mask, name="mask")),
                _p(_chk(dc_w, name="dc_w")), _p(None), _p(_creal(g_out, "g_out")), _p(_chk(h_out, name="h_out")),
                int(h_out.shape[1]), _p(None), _p(_creal(dk, "dk")), _p(part), 1, n, c, h, w, _stream())

@@ -320,8 +320,9 @@ def test_csmodel_protocol_scalars_save_load(S, tmp_path):
     assert set(want) - set(sc) == {"loss_gan_sim"}, (sorted(want), sorted(sc))
     assert set(sc) <= set(want)
     # measured differences are listed in DESIGN.md section 4; bars are 10x those
-    tol = {"loss_all": 2e-5, "loss_sim": 2e-5, "loss_smooth": 1e-3 * abs(want["loss_smooth"]) + 1e-12, "metric_MI": 2e-3,
-           "metric_PSNR": 5e-3, "metric_SSIM": 2e-5, "metric_MAE": 5e-6, "metric_MSE": 5e-6}
+    # measured: loss_all / loss_sim 6e-8, loss_smooth 1e-7 relative, MI 1e-9, PSNR 2e-6 dB, SSIM 3e-8, MAE 7e-8, MSE 4e-8
+    tol = {"loss_all": 1e-6, "loss_sim": 1e-6, "loss_smooth": 1e-5 * abs(want["loss_smooth"]) + 1e-15, "metric_MI": 1e-4,
+           "metric_PSNR": 5e-5, "metric_SSIM": 1e-6, "metric_MAE": 1e-6, "metric_MSE": 1e-6}
     for k_, v in sc.items():
         print(f"{k_}: hip {v:.9g} reference {want[k_]:.9g}")
         assert abs(v - want[k_]) <= tol[k_], (k_, v, want[k_])
@@ -450,9 +451,9 @@ def test_cascade_checksums_full_320(S):
         got = np.array([k.real.double().sum().item(), k.imag.double().sum().item(), k.abs().double().pow(2).sum().sqrt().item()])
         l2 = want[j, 2]
         # sums of 102,400 values of magnitude ~L2/320 carry ~1e-5 of relative noise through 12 cascades; L2 itself ~1e-5
-        assert abs(got[2] - l2) < 1e-4 * l2, (j, got, want[j])
+        assert abs(got[2] - l2) < 1e-5 * l2, (j, got, want[j])            # measured <= 3e-7
         print(j, got - want[j], l2)
-        assert abs(got[0] - want[j, 0]) < 1e-3 * l2 and abs(got[1] - want[j, 1]) < 1e-3 * l2, (j, got, want[j])
+        assert abs(got[0] - want[j, 0]) < 2e-4 * l2 and abs(got[1] - want[j, 1]) < 2e-4 * l2, (j, got, want[j])   # measured <= 1.2e-5 l2
 
 
 # ------------------------------------------------------------------ config 4: multi-coil 640 x 368 x 15
@@ -537,7 +538,8 @@ def test_multicoil_two_cascade_train_step_golden(S):
     for tag, mod in (("R", net.net_R), ("T", net.net_T)):
         wn, name, pe = _digest_errors(S, [(nm, p.grad) for nm, p in mod.named_parameters()], gold, f"train2.grad.{tag}.")
         print(f"multi-coil net_{tag}: worst per-tensor norm error {wn:.2e} ({name}), probe-estimated relative L2 {pe:.2e}")
-        assert wn < 1e-2 and pe < 1e-2, (tag, wn, name, pe)
+        # measured 1.5e-3 / 1.1e-3 (net_R), 2.6e-3 / 3.4e-3 (net_T: train-mode BatchNorm on one slice); bars ~4x
+        assert wn < 1e-2 and pe < 1.2e-2, (tag, wn, name, pe)
 
 
 # ------------------------------------------------------------------ data parallel (two ranks on one GPU)
