@@ -228,7 +228,10 @@ def roofline_entry(key, d, dt, steps, pmc, match_profile, products=BF16X3_PRODUC
         ach = d["work"] / sec / 1e12           # ALGORITHMIC TFLOP/s
         if key.endswith("_bf16x3"):
             peak = BF16_PEAK_TFLOPS
-            extra = {"dtype": f"bf16 matrix cores, {int(products)} bf16 product(s) per MAC",
+            if d.get("xwork", 0.0) > 0:
+                products = d["xwork"] / d["work"]          # launch-weighted: fp16 two-part forward launches execute 3, bf16 three-part ones 6
+            extra = {"dtype": f"bf16 / fp16 matrix cores, {products:.2f} products per MAC on average (forward: two fp16 parts, 3 products; gradients: three bf16 parts, 6)",
+                     "products_per_mac": products,
                      "executed_tflops": products * ach, "executed_frac": products * ach / peak,
                      "bf16x3_ceiling_tflops": peak / products,
                      "frac_of_bf16x3_ceiling": ach / (peak / products)}

@@ -31,6 +31,9 @@ def bench(fn, reps=30):
 
 
 which = sys.argv[1] if len(sys.argv) > 1 else "conv"
+if len(sys.argv) > 2:
+    ops.set_conv_precision(sys.argv[2])          # bf16x3 | bf16x2 | bf16
+STATS = os.environ.get("BL_STATS", "1") == "1"
 total = 0.0
 for cin, cout, s, cnt in LAYERS:
     x = torch.randn(N, cin, s, s, device=dev)
@@ -40,7 +43,7 @@ for cin, cout, s, cnt in LAYERS:
     y = torch.empty(N, cout, s, s, device=dev)
     xa = ops.Act(x, 0, cin, sc, sh, 0.2)
     if which == "conv":
-        t = bench(lambda: ops.conv2d(xa, wt, None, ops.full(y), stats=True))
+        t = bench(lambda: ops.conv2d(xa, wt, None, ops.full(y), stats=STATS))
     else:
         dw = torch.zeros_like(wt)
         dy = torch.randn(N, cout, s, s, device=dev)

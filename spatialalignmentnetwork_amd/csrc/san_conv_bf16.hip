@@ -28,6 +28,8 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 void san_wgrad_set_parts(int parts);             // san_wgrad_bf16.hip
 
@@ -45,9 +47,11 @@ constexpr int kUnits = (kNP * 3 + kT - 1) / kT;  // (pixel, group) staging units
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
 union Frag {
     uint4 u;
     bf8 v;
+    h8 h;
 };
 
 struct BArgs {
@@ -67,6 +71,7 @@ struct BArgs {
     int S;                     // split-K: S workgroups share an output tile, each takes a contiguous range of the chunks
     float* ws;                 // [S][N][cout][H][W] partial outputs (S > 1); splitk_reduce_kernel adds them up
     int tw, th, hp, npx;       // tile width / height (tw * th <= 256 pixels, taken in flattened order), halo pitch tw + 2, halo pixels
+    int fmt;                   // operand format of the packed weights / the staging: 0 = bf16 parts, 1 = two fp16 parts
 };
 
 // round-to-nearest-even bf16 of f, returned as the fp32 it represents (upper 16 bits)
@@ -102,6 +107,30 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
     p3 = cvt_pk(r0 - __builtin_bit_cast(float, p2 << 16), r1 - __builtin_bit_cast(float, p2 & 0xffff0000u));
 }
 
+// fp16 operand format ("f16x2"): a = a1 + a2 with a1 = fp16(a), a2 = fp16(a - a1): 22 mantissa bits in two parts, so the three
+// products a1w1 + a1w2 + a2w1 are fp32-equivalent (dropped: 2^-22) at HALF the matrix work of the six bf16 products.  The
+// matrix cores keep fp16 denormal inputs (scratch/probe/mfma_f16_denorm.hip), so small a2 cost nothing but an absolute
+// floor of 2^-25; what fp16 lacks is RANGE (|x| <= 65504, full precision above 6e-5): fine for the forward pass, whose
+// operands are normalised activations and weights, NOT for gradients (1e-7-sized dy): data and weight gradients stay on
+// the bf16 split.  End to end (scratch/study/split_fp16_accuracy.py): 2.8e-5 from the fp32 result, 5.3e-5 from fp64
+// (fp32 itself: 4.7e-5).
+typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
+__device__ __forceinline__ uint32_t cvt_pk_h(float f0, float f1) {
+    const fl2 v = {f0, f1};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hf2));      // round to nearest even, denormal results kept
+}
+__device__ __forceinline__ void split2h_pair(float f0, float f1, uint32_t& p1, uint32_t& p2) {
+    p1 = cvt_pk_h(f0, f1);
+    const hf2 h = __builtin_bit_cast(hf2, p1);
+    p2 = cvt_pk_h(f0 - (float)h[0], f1 - (float)h[1]);
+}
+__device__ __forceinline__ void split2h(float f, uint32_t& p1, uint32_t& p2) {
+    const _Float16 a = (_Float16)f;
+    const _Float16 b = (_Float16)(f - (float)a);
+    p1 = __builtin_bit_cast(uint16_t, a);
+    p2 = __builtin_bit_cast(uint16_t, b);
+}
+
 // WD ("weights direct"): the K-steps read their weight operands straight from the packed image in L2 instead of
 // staging each chunk's weights through LDS.  All four waves then fetch the same weights (4x the L1 traffic), but the
 // workgroup needs 49 KB of LDS instead of 92-156 KB, so three of them share a CU: measured +17..30 % for MB <= 4 with
@@ -114,8 +143,13 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
 // NP: operand parts used.  3 = the fp32-equivalent form (six products); 2 = a1 + a2 (16 mantissa bits, three products
 // a1w1 + a1w2 + a2w1); 1 = plain bf16 (one product).  The reduced forms are the narrow-precision modes selected with
 // san_set_conv_precision (judged by PSNR, not by the 1e-4 parity bar); the packed weight image is the same for all.
-template <int MB, bool WD, int KS, bool FLAT, int NP>
+// SWAP: the ACTIVATIONS are the MFMA's A operand (16 pixels = rows of D) and the weights its B operand (16 channels = columns):
+// a lane ends with FOUR CONSECUTIVE PIXELS of ONE channel per accumulator tile (D[4 kg + r][nn]), so the epilogue stores 16
+// bytes per lane and the plane statistics are 16 in-lane values + two cross-row steps per channel.  Not for the pixel-shuffle
+// epilogue of the transposed form (there a lane must hold the four virtual channels of one real channel).
+template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16>
 __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
+    static_assert(!F16 || NP == 2, "the fp16 format has two parts");
     constexpr int kSteps = KS == 3 ? 7 : 1;            // (shadows the 3x3 constant)
     static_assert(KS == 3 || WD, "the 1x1 form reads its weights directly");
     constexpr int WCH = kSteps * MB * 3 * 64;          // uint4 per (cg, chunk) weight image
@@ -286,7 +320,12 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 const float sha = i < 4 ? sh0[i] : sh1[i - 4], shb = i < 4 ? sh0[i + 1] : sh1[i - 3];
                 const float v0 = s_in[s] ? san_act(st[s][i], sca, sha, a.in_slope) : 0.f;
                 const float v1 = s_in[s] ? san_act(st[s][i + 1], scb, shb, a.in_slope) : 0.f;
-                split3_pair(v0, v1, q1[i >> 1], q2[i >> 1], q3[i >> 1]);
+                if constexpr (F16) {
+                    split2h_pair(v0, v1, q1[i >> 1], q2[i >> 1]);
+                    q3[i >> 1] = 0u;
+                } else {
+                    split3_pair(v0, v1, q1[i >> 1], q2[i >> 1], q3[i >> 1]);
+                }
             }
             if (s_loff[s] >= 0) {
                 *reinterpret_cast<uint4*>(lds_a + s_loff[s]) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
@@ -327,12 +366,127 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1][m][pw].v, xa[s & 1][b][px].v, acc[m][b], 0, 0, 0);
+                        for (int b = 0; b < 4; ++b) {
+                            if constexpr (F16) {
+                                if constexpr (SWAP)
+                                    acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][px].h, wa[s & 1][m][pw].h, acc[m][b], 0, 0, 0);
+                                else
+                                    acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s & 1][m][pw].h, xa[s & 1][b][px].h, acc[m][b], 0, 0, 0);
+                            } else if constexpr (SWAP)
+                                acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[s & 1][b][px].v, wa[s & 1][m][pw].v, acc[m][b], 0, 0, 0);
+                            else
+                                acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1][m][pw].v, xa[s & 1][b][px].v, acc[m][b], 0, 0, 0);
+                        }
         }
     }
 
     // ------------------------------------------------------------ epilogue
+    if constexpr (SWAP) {
+        // acc[m][b][r] = output channel (cg MB + m) 16 + nn at the tile pixel r places after pixel 64 wave + 16 b + 4 kg
+        const int cb0 = cg * MB * 16 + nn;
+        const bool quad_ok = !FLAT || (tw & 3) == 0;    // FLAT tiles are full-width rows: a quad stays inside one row
+        int qy[4], qx[4];
+        bool vq[4], v1[4][4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int q = 64 * wave + 16 * b + 4 * kg;
+            int orow, ocol;
+            bool oin = true;
+            if constexpr (FLAT) {
+                const int qq = min(q, tw * th - 1);
+                orow = qq / tw;
+                ocol = qq - orow * tw;
+                oin = q < tw * th;
+            } else {
+                orow = q >> 5;
+                ocol = q & 31;
+            }
+            qy[b] = y0 + orow;
+            qx[b] = x0 + ocol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (quad_ok) {
+                    v1[b][r] = oin && qy[b] < H && qx[b] + r < W;
+                } else {
+                    const int q1 = q + r, rr = q1 / tw, cc = q1 - rr * tw;
+                    v1[b][r] = q1 < tw * th && y0 + rr < H && x0 + cc < W;
+                }
+            }
+            vq[b] = quad_ok && v1[b][3] && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(a.S > 1 ? a.ws : a.y) & 15) == 0;
+        }
+        float* ybase = a.S > 1 ? a.ws + ((size_t)(sk * a.N + n) * a.cout) * HWp : a.y + (size_t)(n * a.y_ctot + a.y_coff) * HWp;
+        if (a.S == 1) {
+            if (a.bias) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const int co = cb0 + 16 * m;
+                    const float bv = co < a.cout ? a.bias[co] : 0.f;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[m][b] += f4{bv, bv, bv, bv};
+                }
+            }
+            if (a.part) {
+                float cnt = 0.f;
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cnt += v1[b][r] ? 1.f : 0.f;
+                cnt += __shfl_xor(cnt, 16, 64);
+                cnt += __shfl_xor(cnt, 32, 64);
+                const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+                const int tiles = ntile * 4;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const float pilot = __shfl(acc[m][0][0], nn, 64);      // the wave's first pixel of this channel
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = v1[b][r] ? acc[m][b][r] - pilot : 0.f;
+                            s1 += e;
+                            s2 = fmaf(e, e, s2);
+                        }
+                    s1 += __shfl_xor(s1, 16, 64);
+                    s2 += __shfl_xor(s2, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    const int co = cb0 + 16 * m;
+                    if (kg == 0 && co < a.cout) {
+                        float* o = a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
+                        o[0] = cnt;
+                        o[1] = cnt > 0.f ? pilot + s1 * inv : 0.f;
+                        o[2] = cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+            const int co = cb0 + 16 * m;
+            if (co < a.cout) {
+                float* dst = ybase + (size_t)co * HWp;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    if (vq[b]) {
+                        *reinterpret_cast<f4*>(dst + qy[b] * W + qx[b]) = acc[m][b];
+                    } else if (quad_ok) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (v1[b][r]) dst[qy[b] * W + qx[b] + r] = acc[m][b][r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (v1[b][r]) {
+                                const int q1 = 64 * wave + 16 * b + 4 * kg + r, rr = q1 / tw, cc = q1 - rr * tw;
+                                dst[(y0 + rr) * W + x0 + cc] = acc[m][b][r];
+                            }
+                    }
+                }
+            }
+        }
+        return;
+    }
     // acc[m][b][r] = output channel co = (cg MB + m) 16 + 4 (lane >> 4) + r at tile pixel (trow[b], tcol[b])
     const int cbase = cg * MB * 16 + 4 * kg;
     int oy[4], ox[4];
@@ -508,7 +662,9 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // One thread per (chunk, step, blk, lane): its 8 values (consecutive input channels of one tap) are gathered once,
 // split three ways and written as three 16-byte vectors (one per part).
 __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t u, int cout,
-                                          int cin, int nblkp, int mode, int ks) {
+                                          int cin, int nblkp, int mode_, int ks) {
+    const bool f16 = (mode_ & 16) != 0;            // mode + 16: two fp16 parts (parts 0, 1 of the image; part 2 zero)
+    const int mode = mode_ & 15;
     const int lane = (int)(u & 63);
     size_t r = u >> 6;
     const int blk = (int)(r % nblkp);
@@ -535,9 +691,14 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t*
                 else v[k] = mode == 2 ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
             }
         }
-        uint32_t a1, a2, a3, b1, b2, b3;
-        split3(v[0], a1, a2, a3);
-        split3(v[1], b1, b2, b3);
+        uint32_t a1, a2, a3 = 0, b1, b2, b3 = 0;
+        if (f16) {
+            split2h(v[0], a1, a2);
+            split2h(v[1], b1, b2);
+        } else {
+            split3(v[0], a1, a2, a3);
+            split3(v[1], b1, b2, b3);
+        }
         q[0][i >> 1] = (a1 & 0xffffu) | (b1 << 16);
         q[1][i >> 1] = (a2 & 0xffffu) | (b2 << 16);
         q[2][i >> 1] = (a3 & 0xffffu) | (b3 << 16);
@@ -570,6 +731,7 @@ int g_b16_mb = -1;             // tuning hook (SAN_B16_MB=2..5): force the chann
 int g_b16_flat = 1;            // tuning hook (SAN_B16_FLAT=0): always 32 x 8 tiles
 int g_b16_splitk = 4;          // tuning hook (SAN_B16_SPLITK=1 disables split-K, 2 / 4 = most parts per tile)
 int g_b16_splitcap = 1024;     // tuning hook (SAN_B16_SPLITCAP): most workgroups a split launch may have
+int g_b16_swap = 1;            // tuning hook (SAN_B16_SWAP=0): the channel-per-register accumulator layout everywhere
 struct B16Env {
     B16Env() {
         if (const char* e = getenv("SAN_B16_WD")) g_b16_wd = atoi(e);
@@ -577,6 +739,7 @@ struct B16Env {
         if (const char* e = getenv("SAN_B16_FLAT")) g_b16_flat = atoi(e);
         if (const char* e = getenv("SAN_B16_SPLITK")) g_b16_splitk = atoi(e);
         if (const char* e = getenv("SAN_B16_SPLITCAP")) g_b16_splitcap = atoi(e);
+        if (const char* e = getenv("SAN_B16_SWAP")) g_b16_swap = atoi(e);
     }
 } g_b16_env;
 
@@ -650,12 +813,27 @@ int pick_mb(int cout, int tiles) {
 
 int g_conv_np = 3;             // operand parts of the bf16 convolutions / weight gradients (san_set_conv_precision)
 
-template <int MB, bool WD, int KS, bool FLAT, int NP>
-int launch_bfn(const BArgs& a, hipStream_t s) {
+// Which packed weight images hold two fp16 parts (packed with mode + 16) instead of bf16 parts: recorded by the pack entry
+// points (host side), looked up by the launchers, so the convolution entry points need no format argument.
+std::mutex g_fmt_mu;
+std::unordered_map<const void*, int> g_fmt;
+void note_format(const void* packed, int mode) {
+    std::lock_guard<std::mutex> lk(g_fmt_mu);
+    if (mode & 16) g_fmt[packed] = 1;
+    else g_fmt.erase(packed);
+}
+int format_of(const void* packed) {
+    std::lock_guard<std::mutex> lk(g_fmt_mu);
+    auto it = g_fmt.find(packed);
+    return it == g_fmt.end() ? 0 : it->second;
+}
+
+template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16 = false>
+int launch_bfns(const BArgs& a, hipStream_t s) {
     constexpr size_t lds = 3 * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -663,12 +841,25 @@ int launch_bfn(const BArgs& a, hipStream_t s) {
         configured = true;
     }
     const int total = a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT, NP>), dim3(total), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16>), dim3(total), dim3(kT), lds, s, a);
     return SAN_OK;
+}
+
+template <int MB, bool WD, int KS, bool FLAT, int NP>
+int launch_bfn(const BArgs& a, hipStream_t s) {
+    // the pixel-shuffle epilogue of the transposed form needs the channel-per-register layout
+    // (measured: +3-5 % on the 32 x 8-tile wide layers, neutral on the 18- / 36-channel ones, -2-3 % on the full-width FLAT
+    // tiles of the 20^2 / 40^2 levels, whose quads need per-lane row / column arithmetic)
+    if (g_b16_swap && !a.shuffle && !FLAT) return launch_bfns<MB, WD, KS, FLAT, NP, true>(a, s);
+    return launch_bfns<MB, WD, KS, FLAT, NP, false>(a, s);
 }
 
 template <int MB, bool WD, int KS, bool FLAT>
 int launch_bf(const BArgs& a, hipStream_t s) {
+    if (a.fmt == 1) {                               // two fp16 parts (forward operands, fp32-equivalent mode only)
+        if (g_b16_swap && !a.shuffle && !FLAT) return launch_bfns<MB, WD, KS, FLAT, 2, true, true>(a, s);
+        return launch_bfns<MB, WD, KS, FLAT, 2, false, true>(a, s);
+    }
     switch (g_conv_np) {
         case 1: return launch_bfn<MB, WD, KS, FLAT, 1>(a, s);
         case 2: return launch_bfn<MB, WD, KS, FLAT, 2>(a, s);
@@ -729,9 +920,10 @@ int san_conv_bf16x3_stat_tiles(int n, int h, int w) {
 
 int san_conv_bf16x3_pack_ks(const float* w, void* packed, int cout, int cin, int mode, int ks, void* stream) {
     SAN_CHECK_ARG(w && packed, "null pointer");
-    SAN_CHECK_ARG(cout > 0 && cin > 0 && (mode == 0 || mode == 2) && (ks == 1 || ks == 3), "bad dims / mode / ks");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && ((mode & 15) == 0 || (mode & 15) == 2) && (mode & ~16) == (mode & 15) && (ks == 1 || ks == 3), "bad dims / mode / ks");
     // mode 2: `cout`, `cin` are those of the DATA-GRADIENT convolution (cout = forward cin, cin = forward cout)
     const BPlan p = bplan(cout, cin, ks);
+    note_format(packed, mode);
     size_t blocks = (p.packed_elems + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)packed,
@@ -746,8 +938,9 @@ int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mo
 
 int san_conv_bf16x3_pack_job_ks(long long* job8, const float* w, void* packed, int cout, int cin, int mode, int ks) {
     SAN_CHECK_ARG(job8 && w && packed, "null pointer");
-    SAN_CHECK_ARG(cout > 0 && cin > 0 && (mode == 0 || mode == 2) && (ks == 1 || ks == 3), "bad dims / mode / ks");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && ((mode & 15) == 0 || (mode & 15) == 2) && (mode & ~16) == (mode & 15) && (ks == 1 || ks == 3), "bad dims / mode / ks");
     const BPlan p = bplan(cout, cin, ks);
+    note_format(packed, mode);
     job8[0] = (long long)(uintptr_t)w;
     job8[1] = (long long)(uintptr_t)packed;
     job8[2] = cout;
@@ -786,6 +979,8 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.in_shift = in_shift;
     a.in_slope = in_slope;
     a.wp = (const uint4*)w_packed;
+    a.fmt = g_conv_np == 3 ? format_of(w_packed) : 0;
+    SAN_CHECK_ARG(g_conv_np == 3 || format_of(w_packed) == 0, "fp16-format weights are for the fp32-equivalent mode only");
     a.shuffle = shuffle;
     a.bias = bias;
     a.y = y;

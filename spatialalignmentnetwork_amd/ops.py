@@ -35,11 +35,12 @@ class KernelTimer:
         self.recs = []
         self.seen = {}
 
-    def bracket(self, name, work, unit, fn, abytes=0.0):
-        d = self.seen.setdefault(name, {"launches": 0, "work": 0.0, "unit": unit, "abytes": 0.0})
+    def bracket(self, name, work, unit, fn, abytes=0.0, xwork=0.0):
+        d = self.seen.setdefault(name, {"launches": 0, "work": 0.0, "unit": unit, "abytes": 0.0, "xwork": 0.0})
         d["launches"] += 1
         d["work"] += work
         d["abytes"] += abytes
+        d["xwork"] += xwork
         if (d["launches"] - 1) % self.stride:
             fn()
             return
@@ -79,13 +80,18 @@ TIMER: Optional[KernelTimer] = None
 TIMED_KERNELS = ("conv3x3", "conv3x3_bf16x3", "wgrad3x3", "wgrad3x3_bf16x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
 
 
-def _timed(name, work, unit, fn, abytes=0.0):
+def _timed(name, work, unit, fn, abytes=0.0, products=0):
     """abytes: the launch's ALGORITHMIC bytes (operands read once + results written once), reported next to the PMC
-    traffic so that a waste ratio can be formed."""
+    traffic so that a waste ratio can be formed.  products: matrix-core products the kernel executes per algorithmic MAC
+    (6 / 3 / 1 bf16 parts modes, 3 for the fp16 two-part forward form)."""
     if TIMER is None or name not in TIMED_KERNELS:
         fn()
     else:
-        TIMER.bracket(name, work, unit, fn, abytes)
+        TIMER.bracket(name, work, unit, fn, abytes, work * products)
+
+
+def _products(f16: bool = False) -> int:
+    return 3 if f16 else {3: 6, 2: 3, 1: 1}[_CONV_NP[0]]
 
 
 def _conv_abytes(n, h, w, cin, cout, ks):
@@ -494,6 +500,7 @@ class _PackRegistryBf16(_PackRegistry):
     mode 2 data gradient; dims = (cout, cin) of the convolution that will run."""
 
     def _alloc(self, w: torch.Tensor, mode: int):
+        mode &= 15                                      # (+16 = two fp16 parts instead of bf16 parts: same image size)
         if mode == 3:                                   # ConvTranspose2d [Cin, Cout, 2, 2] as a 1x1 conv to 4 Cout channels
             return (4 * w.shape[1], w.shape[0], 1), torch.empty(
                 lib().query("san_conv_bf16x3_packed_bytes_ks", 4 * w.shape[1], w.shape[0], 1), device=w.device, dtype=torch.uint8)
@@ -508,19 +515,33 @@ class _PackRegistryBf16(_PackRegistry):
     def _fill_job(self, row, j):
         cout, cin, ks = j["dims"]
         lib().call("san_conv_bf16x3_pack_job_ks", ctypes.c_void_p(ctypes.addressof(row)), ctypes.c_void_p(j["ptr"]),
-                   _p(j["packed"]), cout, cin, 2 if j["mode"] == 3 else j["mode"], ks)
+                   _p(j["packed"]), cout, cin, self._cmode(j["mode"]), ks)
+
+    @staticmethod
+    def _cmode(mode: int) -> int:
+        """registry mode -> library mode: 3 (transposed) packs like a data gradient (2); bit 4 (fp16 parts) passes through"""
+        return (2 if (mode & 15) == 3 else (mode & 15)) | (mode & 16)
 
     def _batch(self):
         lib().call("san_conv_bf16x3_pack_batch", _p(self.table), len(self.order), _stream())
 
     def _pack_one(self, job, w):
         cout, cin, ks = job["dims"]
-        lib().call("san_conv_bf16x3_pack_ks", _p(w.detach()), _p(job["packed"]), cout, cin, 2 if job["mode"] == 3 else job["mode"],
+        lib().call("san_conv_bf16x3_pack_ks", _p(w.detach()), _p(job["packed"]), cout, cin, self._cmode(job["mode"]),
                    ks, _stream())
         job["version"] = w._version
 
 
 PACKS16 = _PackRegistryBf16()
+# Forward convolutions of the fp32-equivalent mode run on TWO fp16 parts per operand (three products instead of six bf16
+# ones; csrc/san_conv_bf16.hip "f16x2"): their operands are normalised activations and weights, for which fp16's range
+# is ample.  Gradients (1e-7-sized) keep the three-part bf16 split.  SAN_NO_F16X2=1 switches it off.
+F16_FWD = [os.environ.get("SAN_NO_F16X2", "0") != "1"]
+_CONV_NP = [3]
+
+
+def _fwd_fmt() -> int:
+    return 16 if (F16_FWD[0] and _CONV_NP[0] == 3) else 0
 
 # Arithmetic of the matrix-core convolutions / weight gradients (san_set_conv_precision).  "bf16x3" is the default and the
 # only mode held to the 1e-4 parity bar; "bf16x2" / "bf16" are the narrow-precision modes (PSNR-judged).
@@ -533,6 +554,7 @@ def set_conv_precision(mode: str) -> str:
         raise ValueError(f"conv precision {mode!r}: choose from {sorted(CONV_PRECISIONS)}")
     prev = {3: "bf16x3", 2: "bf16x2", 1: "bf16"}[lib().query("san_get_conv_precision")]
     lib().call("san_set_conv_precision", CONV_PRECISIONS[mode])
+    _CONV_NP[0] = CONV_PRECISIONS[mode]
     return prev
 
 
@@ -581,9 +603,10 @@ def _bf16x3_launch(ks: int, bargs, n: int, h: int, w: int, cin: int, cout: int, 
 
 def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: bool = False,
            out_scale: Optional[torch.Tensor] = None, out_shift: Optional[torch.Tensor] = None,
-           arena: Arena = GLOBAL_ARENA, tag: str = "") -> Optional[torch.Tensor]:
+           arena: Arena = GLOBAL_ARENA, tag: str = "", grad_input: bool = False) -> Optional[torch.Tensor]:
     """y.buf[:, y.coff:y.coff+cout] = conv(T(x)) (+bias).  Returns the per-tile
-    statistics partials [N, cout, tiles, 3] when ``stats``."""
+    statistics partials [N, cout, tiles, 3] when ``stats``.  ``grad_input``: x is a gradient (arbitrary magnitude):
+    keep the bf16 operand split, whose exponent range is fp32's."""
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert cin == x.c and cout == y.c, (cin, x.c, cout, y.c)
     assert x.buf.shape[2:] == y.buf.shape[2:]
@@ -591,13 +614,15 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
     part = None
     if out_scale is None and bf16x3_eligible(cin, cout, h, w, ks):
         # bf16 matrix cores, operands split in three (fp32-level accuracy), csrc/san_conv_bf16.hip
-        wp = PACKS16.get(weight, 0)
+        fmt = 0 if grad_input else _fwd_fmt()
+        wp = PACKS16.get(weight, fmt)
         if stats:
             part = arena.get("part" + tag, (n, cout, lib().query("san_conv_bf16x3_stat_tiles", n, h, w), 3), x.buf.device)
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
                  y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
         _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
-               lambda: _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena), _conv_abytes(n, h, w, cin, cout, ks))
+               lambda: _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena), _conv_abytes(n, h, w, cin, cout, ks),
+               _products(fmt != 0))
         return part
     wp = packed_weight(weight)
     if stats:
@@ -617,7 +642,7 @@ def tconv2x2(x: Act, weight: torch.Tensor, y: Act, stats: bool = False, arena: A
     assert y.h == 2 * x.h and y.w == 2 * x.w
     part = None
     if USE_BF16X3[0] and lib().query("san_tconv2x2_bf16x3_eligible", cin, cout, x.h, x.w) and y.buf.data_ptr() % 8 == 0:
-        wp = PACKS16.get(weight, 3)
+        wp = PACKS16.get(weight, 3 + _fwd_fmt())
         if stats:
             tiles = 4 * lib().query("san_conv_bf16x3_stat_tiles", x.n, x.h, x.w)
             part = arena.get("tpart" + tag, (x.n, cout, tiles, 3), x.buf.device)
@@ -817,7 +842,7 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
                  _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), dy.n, dy.h, dy.w, _stream())
         _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
                lambda: _bf16x3_launch(ks, bargs, dy.n, dy.h, dy.w, cout, cin, dy.buf.device, GLOBAL_ARENA),
-               _conv_abytes(dy.n, dy.h, dy.w, cin, cout, ks))
+               _conv_abytes(dy.n, dy.h, dy.w, cin, cout, ks), _products())
         return
     wp = packed_weight_dgrad(weight)
     args = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
@@ -956,7 +981,7 @@ def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = F
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
             cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
     _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args),
-           _conv_abytes(x.n, x.h, x.w, cin, cout, 3))
+           _conv_abytes(x.n, x.h, x.w, cin, cout, 3), _products())
 
 
 def wgrad1x1_bf16x3_ok(x: Act, dy: Act) -> bool:

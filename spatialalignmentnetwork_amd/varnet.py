@@ -113,7 +113,7 @@ class TransposeConvBlock(nn.Module):
         ops.unshuffle2(dyt, dyp)
         wv = _view_cached(wt, (cin, 4 * cout, 1, 1))
         # dL/dx[ci] = sum_c' Wv[ci, c'] dy'[c']  == forward 1x1 conv with weight [cout'=Cin, cin'=4Cout]
-        ops.conv2d(dyp, wv, None, g_in)
+        ops.conv2d(dyp, wv, None, g_in, grad_input=True)
         if ops.wgrad1x1_bf16x3_ok(x, dyp):
             # the reduction writes [Cin][4 Cout] = the ConvTranspose2d weight layout: accumulate in place
             ops.conv2d_wgrad1x1_bf16x3(x, dyp, _grad_of(wt), accumulate=True, transposed=True)
