@@ -311,6 +311,30 @@ int san_window_copy_fwd(const float* x, int x_ctot, int x_coff, const float* sc,
 int san_set_conv_precision(int parts);
 int san_get_conv_precision(void);
 
+/* fp16-format gradients (fp32-equivalent mode only).  The matrix-core kernels can run on TWO fp16 parts per operand (22
+ * mantissa bits, three products instead of the six of the bf16 split) when their operands fit fp16's range.  Forward
+ * operands (normalised activations, weights) do: pack the weights with mode + 16 and the convolution entry points pick
+ * the format up from the packed image.  Gradients (1e-7-sized) need a scale: the `_amax` forms of san_act_bwd /
+ * san_act_bwd_coef keep the largest |dy| of everything written to a dy tensor in *amax (one uint32 holding float bits,
+ * zeroed by the caller; per-wave maxima into `wave_max`, reduced by one more launch: no atomics, deterministic), and the `_amax` forms of the data / weight gradient read it,
+ * multiply dy by 2^(13 - floor(log2 max)) while loading and the result by the inverse.  amax == NULL: the plain forms. */
+int san_act_bwd_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
+                     const float* sc, const float* sh, float slope, int mode, float* part,
+                     float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw, void* stream);
+int san_act_bwd_amax_scratch_floats(int n, int c);     /* floats of `wave_max` scratch (per-wave maxima, reduced by a final launch) */
+int san_act_bwd_coef_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
+                          const float* sc, const float* sh, float slope, const float* coef,
+                          float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw, void* stream);
+int san_conv_bf16x3_dgrad_amax(const float* dy, int dy_ctot, int dy_coff, int cin, const void* w_packed, float* dx, int dx_ctot,
+                               int dx_coff, int cout, const void* amax, int n, int h, int w, int ks, void* ws, size_t ws_bytes,
+                               void* stream);
+int san_conv2d_wgrad_bf16x3_amax(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                                 float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                                 void* scratch, const void* dy_amax, int n, int h, int w, void* stream);
+int san_conv1x1_wgrad_bf16x3_amax(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                                  float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                                  int transposed, void* scratch, const void* dy_amax, int n, int h, int w, void* stream);
+
 /* ------------------------------------------- image-domain cascade boundary */
 
 /* out = (i)fft along H only (ortho: scale 1/sqrt(h)) of interleaved complex [planes, h, w].  k0x = ifft_y(k0) is the

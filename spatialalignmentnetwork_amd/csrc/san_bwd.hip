@@ -669,6 +669,32 @@ WgradPlan wgrad_plan(int n, int h, int w, int cin, int cout, int ks, bool allow_
 // bwd_stats writes per-chunk (sum u, sum u*yh) partials; act_bwd sums the chunks itself.
 typedef float bf4 __attribute__((ext_vector_type(4)));
 
+// Largest |dy| of a launch, for the fp16-format gradient kernels (they scale dy by a power of two derived from it).
+// Every wave stores its own maximum (no atomics: 16 k atomic maxima on one address cost ~200 us per launch, and per-CU L1
+// copies of that address go stale, so "look before you leap" did not help); amax_finalize_kernel reduces the <= 32 k wave
+// maxima and merges them into *amax (max is order-independent: deterministic).
+__device__ __forceinline__ void record_wave_max(float* pmax, int wave_slot, float mx) {
+    if (!pmax) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) pmax[wave_slot] = mx;
+}
+
+__global__ void __launch_bounds__(1024) amax_finalize_kernel(const float* __restrict__ pmax, int count, unsigned* __restrict__ amax) {
+    __shared__ float red[16];
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < count; i += 1024) mx = fmaxf(mx, pmax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+        const unsigned bits = __builtin_bit_cast(unsigned, mx);
+        if (bits > *amax) *amax = bits;              // (several launches may feed one slot: keep the largest)
+    }
+}
+
 // InstanceNorm + LeakyReLU backward of a whole (sample, channel) plane in ONE pass: the plane's g and y (<= V float4 per
 // thread each, 512 threads) stay in registers between the two reductions and the write of dy, so g and y are read once
 // instead of twice and there is one launch instead of two.  Planes of up to 512 * 4 * V values (V = 13: 160 x 160).
@@ -676,7 +702,7 @@ template <int V>
 __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
                                                             const float* __restrict__ y, int y_ctot, int y_coff,
                                                             const float* __restrict__ sc, const float* __restrict__ sh, float slope,
-                                                            float* __restrict__ dy, int d_ctot, int d_coff, int hw) {
+                                                            float* __restrict__ dy, int d_ctot, int d_coff, int hw, float* pmax) {
     __shared__ float red[16];
     const int ch = blockIdx.x, n = blockIdx.y;
     const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
@@ -719,16 +745,21 @@ __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restr
         t2 += (double)red[8 + w];
     }
     const float m1 = (float)(t1 / hw), m2 = (float)(t2 / hw);
+    float mx = 0.f;
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const int i = threadIdx.x + 512 * k;
         if (i < n4) {
             bf4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = s * (u[k][e] - m1 - yh[k][e] * m2);
+            for (int e = 0; e < 4; ++e) {
+                o[e] = s * (u[k][e] - m1 - yh[k][e] * m2);
+                mx = fmaxf(mx, fabsf(o[e]));
+            }
             dp[i] = o;
         }
     }
+    record_wave_max(pmax, (blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6), mx);
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -788,7 +819,7 @@ bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const floa
 __global__ void __launch_bounds__(kThreads)
 act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
                const float* __restrict__ sc, const float* __restrict__ sh, float slope, const float* __restrict__ part,
-               int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw) {
+               int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, float* pmax) {
     const int ch = blockIdx.y, n = blockIdx.z;
     const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
     const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
@@ -806,6 +837,7 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
     const float* gp = g + ((size_t)(n * g_ctot + g_coff + ch)) * hw;
     const float* yp = y + ((size_t)(n * y_ctot + y_coff + ch)) * hw;
     float* dp = dy + ((size_t)(n * d_ctot + d_coff + ch)) * hw;
+    float mx = 0.f;
     if ((hw & 3) == 0 && ((((uintptr_t)gp | (uintptr_t)yp | (uintptr_t)dp)) & 15) == 0) {
         for (int i = blockIdx.x * kThreads + threadIdx.x; i < (hw >> 2); i += gridDim.x * kThreads) {
             const bf4 gv = reinterpret_cast<const bf4*>(gp)[i], yv = reinterpret_cast<const bf4*>(yp)[i];
@@ -815,16 +847,21 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
                 const float yh = fmaf(yv[e], s, b);
                 const float u = gv[e] * (yh >= 0.f ? 1.f : slope);
                 o[e] = s * (u - m1 - yh * m2);
+                mx = fmaxf(mx, fabsf(o[e]));
             }
             reinterpret_cast<bf4*>(dp)[i] = o;
         }
+        record_wave_max(pmax, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6), mx);
         return;
     }
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads) {
         const float yh = fmaf(yp[i], s, b);
         const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
-        dp[i] = s * (u - m1 - yh * m2);
+        const float o = s * (u - m1 - yh * m2);
+        dp[i] = o;
+        mx = fmaxf(mx, fabsf(o));
     }
+    record_wave_max(pmax, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6), mx);
 }
 
 
@@ -1028,7 +1065,7 @@ ssim_bwd_gather_kernel(const float* __restrict__ X, const float* __restrict__ Y,
 __global__ void __launch_bounds__(kThreads)
 act_bwd_coef_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot,
                     int y_coff, const float* __restrict__ sc, const float* __restrict__ sh, float slope,
-                    const float* __restrict__ coef, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw) {
+                    const float* __restrict__ coef, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, float* pmax) {
     const int ch = blockIdx.y, n = blockIdx.z;
     const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
     const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
@@ -1037,11 +1074,15 @@ act_bwd_coef_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const f
     const float* gp = g + ((size_t)(n * g_ctot + g_coff + ch)) * hw;
     const float* yp = y + ((size_t)(n * y_ctot + y_coff + ch)) * hw;
     float* dp = dy + ((size_t)(n * d_ctot + d_coff + ch)) * hw;
+    float mx = 0.f;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads) {
         const float yh = fmaf(yp[i], s, b);
         const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
-        dp[i] = s * (u - m1 - fmaf(p, yh, q) * m2);
+        const float o = s * (u - m1 - fmaf(p, yh, q) * m2);
+        dp[i] = o;
+        mx = fmaxf(mx, fabsf(o));
     }
+    record_wave_max(pmax, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6), mx);
 }
 
 // bilinear warp backward wrt the sampling grid (zeros padding, align_corners = False):
@@ -1344,11 +1385,12 @@ int san_bwd_stat_tiles(int hw) {
     return t < 1 ? 1 : (t > 32 ? 32 : t);
 }
 
-int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
-                const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, int n, int c,
-                int hw, void* stream) {
+static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                        const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, int n, int c,
+                        int hw, unsigned* amax, float* pmax, void* stream) {
     SAN_CHECK_ARG(g && y && dy, "null pointer");
     SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    SAN_CHECK_ARG((amax == nullptr) == (pmax == nullptr), "amax and its wave-maxima scratch come together");
     SAN_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (affine) or 1 (instance norm)");
     SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
     SAN_CHECK_ARG(mode == 0 || part != nullptr, "instance-norm backward needs the partial buffer");
@@ -1361,7 +1403,7 @@ int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ct
         // the whole plane fits one workgroup's registers: statistics and gradient in one pass
         const int v = san_cdiv(hw >> 2, 512);
         const dim3 grid(c, n);
-#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw)
+#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw, pmax)
         if (v <= 1) SAN_ABP(1);
         else if (v <= 2) SAN_ABP(2);
         else if (v <= 4) SAN_ABP(4);
@@ -1369,6 +1411,10 @@ int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ct
         else SAN_ABP(13);
 #undef SAN_ABP
         SAN_LAUNCH_CHECK();
+        if (amax) {
+            hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(1024), 0, s, pmax, c * n * 8, amax);
+            SAN_LAUNCH_CHECK();
+        }
         return SAN_OK;
     }
     if (mode == 1) {
@@ -1382,9 +1428,32 @@ int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ct
     if (bx > cap) bx = (int)cap;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(bx, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc,
-                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw);
+                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw, pmax);
     SAN_LAUNCH_CHECK();
+    if (amax) {
+        hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(1024), 0, s, pmax, bx * c * n * 4, amax);
+        SAN_LAUNCH_CHECK();
+    }
     return SAN_OK;
+}
+
+int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, int n, int c,
+                int hw, void* stream) {
+    return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw, nullptr, nullptr, stream);
+}
+
+int san_act_bwd_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                     const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, void* amax,
+                     float* wave_max, int n, int c, int hw, void* stream) {
+    return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw,
+                        static_cast<unsigned*>(amax), wave_max, stream);
+}
+
+// floats of scratch the _amax forms need for the per-wave maxima
+int san_act_bwd_amax_scratch_floats(int n, int c) {
+    const long planes = (long)n * c;
+    return (int)((planes > 4096 ? planes : 4096) * 8);
 }
 
 int san_dc_weight_grad(const float* g, const float* k, const float* k0, const float* mask, float* partial, int planes,
@@ -1464,9 +1533,9 @@ int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, i
     return SAN_OK;
 }
 
-int san_act_bwd_coef(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
-                     const float* sh, float slope, const float* coef, float* dy, int d_ctot, int d_coff, int n, int c,
-                     int hw, void* stream) {
+static int act_bwd_coef_impl(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                             const float* sh, float slope, const float* coef, float* dy, int d_ctot, int d_coff, int n, int c,
+                             int hw, unsigned* amax, float* pmax, void* stream) {
     SAN_CHECK_ARG(g && y && dy && coef, "null pointer");
     SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
     SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
@@ -1478,9 +1547,27 @@ int san_act_bwd_coef(const float* g, int g_ctot, int g_coff, const float* y, int
     if (bx > cap) bx = (int)cap;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(act_bwd_coef_kernel, dim3(bx, c, n), dim3(kThreads), 0, (hipStream_t)stream, g, g_ctot, g_coff, y,
-                       y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, c, hw);
+                       y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, c, hw, pmax);
     SAN_LAUNCH_CHECK();
+    if (amax) {
+        SAN_CHECK_ARG(pmax != nullptr, "amax needs its wave-maxima scratch");
+        hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pmax, bx * c * n * 4, amax);
+        SAN_LAUNCH_CHECK();
+    }
     return SAN_OK;
+}
+
+int san_act_bwd_coef(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                     const float* sh, float slope, const float* coef, float* dy, int d_ctot, int d_coff, int n, int c,
+                     int hw, void* stream) {
+    return act_bwd_coef_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, n, c, hw, nullptr, nullptr, stream);
+}
+
+int san_act_bwd_coef_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                          const float* sh, float slope, const float* coef, float* dy, int d_ctot, int d_coff, void* amax,
+                          float* wave_max, int n, int c, int hw, void* stream) {
+    return act_bwd_coef_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, n, c, hw,
+                             static_cast<unsigned*>(amax), wave_max, stream);
 }
 
 int san_warp_bwd_grid(const float* img, const float* grid, const float* g, float* g_off, int n, int c, int h, int w,

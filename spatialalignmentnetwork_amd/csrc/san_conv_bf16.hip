@@ -72,6 +72,7 @@ struct BArgs {
     float* ws;                 // [S][N][cout][H][W] partial outputs (S > 1); splitk_reduce_kernel adds them up
     int tw, th, hp, npx;       // tile width / height (tw * th <= 256 pixels, taken in flattened order), halo pitch tw + 2, halo pixels
     int fmt;                   // operand format of the packed weights / the staging: 0 = bf16 parts, 1 = two fp16 parts
+    const uint32_t* amax;      // fp16 format on a GRADIENT input: bits of max |x| (device scalar); the input is scaled by a power of two
 };
 
 // round-to-nearest-even bf16 of f, returned as the fp32 it represents (upper 16 bits)
@@ -221,11 +222,25 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     float* lds_aff = reinterpret_cast<float*>(smem + 3 * kPartB + (WD ? (size_t)0 : (size_t)WCH * 16));
     const bool has_aff = a.in_scale != nullptr;
     float my_aff = 0.f;
+    // gradient input in the fp16 format: x S (S = 2^(13 - floor(log2 max |x|)), exact) rides in the affine table, the
+    // accumulators get 1 / S at the end
+    float inS = 1.f, inInvS = 1.f;
+    if constexpr (F16) {
+        if (a.amax) {
+            const uint32_t b = *a.amax;
+            int e = (int)((b >> 23) & 255u);
+            if (b != 0u) {
+                e = e < 14 ? 14 : (e > 250 ? 250 : e);
+                inS = __builtin_bit_cast(float, (uint32_t)(267 - e) << 23);
+                inInvS = __builtin_bit_cast(float, (uint32_t)(e - 13) << 23);
+            }
+        }
+    }
     auto fetch_aff = [&](int chunk) {
         if (tid < 48) {
             const int ci = min(chunk * kCKC + (tid < 24 ? tid : tid - 24), a.cin - 1);
             const float* src = tid < 24 ? a.in_scale : a.in_shift;
-            my_aff = has_aff ? src[n * a.x_ctot + a.x_coff + ci] : (tid < 24 ? 1.f : 0.f);
+            my_aff = has_aff ? src[n * a.x_ctot + a.x_coff + ci] * inS : (tid < 24 ? inS : 0.f);
         }
     };
     auto prefetch = [&](int chunk) {
@@ -381,6 +396,14 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     }
 
     // ------------------------------------------------------------ epilogue
+    if constexpr (F16) {
+        if (a.amax) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[m][b] *= inInvS;
+        }
+    }
     if constexpr (SWAP) {
         // acc[m][b][r] = output channel (cg MB + m) 16 + nn at the tile pixel r places after pixel 64 wave + 16 b + 4 kg
         const int cb0 = cg * MB * 16 + nn;
@@ -966,7 +989,7 @@ int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* strea
 static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
                            float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
                            float* part_stats, int n, int h, int w, int ks, void* stream, int shuffle = 0,
-                           void* ws = nullptr, size_t ws_bytes = 0) {
+                           void* ws = nullptr, size_t ws_bytes = 0, const void* amax = nullptr) {
     SAN_CHECK_ARG(x && w_packed && y, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + (shuffle ? cout / 4 : cout) <= y_ctot, "bad channel view");
@@ -980,6 +1003,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.in_slope = in_slope;
     a.wp = (const uint4*)w_packed;
     a.fmt = g_conv_np == 3 ? format_of(w_packed) : 0;
+    a.amax = a.fmt == 1 ? static_cast<const uint32_t*>(amax) : nullptr;
     SAN_CHECK_ARG(g_conv_np == 3 || format_of(w_packed) == 0, "fp16-format weights are for the fp32-equivalent mode only");
     a.shuffle = shuffle;
     a.bias = bias;
@@ -1100,6 +1124,17 @@ int san_conv2d_bf16x3_fwd_ws(const float* x, int x_ctot, int x_coff, int cin, co
                              int cout, float* part_stats, int n, int h, int w, void* ws, size_t ws_bytes, void* stream) {
     return conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout,
                            part_stats, n, h, w, 3, stream, 0, ws, ws_bytes);
+}
+
+// Data gradient on fp16-format weights (packed with mode 2 + 16): x = dy [n, cout_fwd, h, w] materialised, amax = device
+// pointer to the bits of max |dy| (san_act_bwd* maintain it).  ks = 3 or 1; ws / ws_bytes as in san_conv2d_bf16x3_fwd_ws
+// (may be NULL / 0).  With bf16-format weights or amax == NULL this is san_conv2d_bf16x3_fwd_ws / san_conv1x1_bf16x3_fwd.
+int san_conv_bf16x3_dgrad_amax(const float* dy, int dy_ctot, int dy_coff, int cin, const void* w_packed, float* dx, int dx_ctot,
+                               int dx_coff, int cout, const void* amax, int n, int h, int w, int ks, void* ws, size_t ws_bytes,
+                               void* stream) {
+    SAN_CHECK_ARG(ks == 1 || ks == 3, "ks must be 1 or 3");
+    return conv_bf16x3_run(dy, dy_ctot, dy_coff, cin, nullptr, nullptr, 1.f, w_packed, nullptr, dx, dx_ctot, dx_coff, cout, nullptr,
+                           n, h, w, ks, stream, 0, ks == 3 ? ws : nullptr, ks == 3 ? ws_bytes : 0, amax);
 }
 
 }  // extern "C"

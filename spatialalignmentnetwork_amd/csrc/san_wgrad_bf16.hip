@@ -34,9 +34,12 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float fl2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
 union Frag {
     u32x4 u;
     bf8 v;
+    h8 h;
 };
 
 constexpr int kWaves = 4;
@@ -52,6 +55,46 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
     const float r0 = f0 - __builtin_bit_cast(float, p1 << 16), r1 = f1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
     p2 = cvt_pk(r0, r1);
     p3 = cvt_pk(r0 - __builtin_bit_cast(float, p2 << 16), r1 - __builtin_bit_cast(float, p2 & 0xffff0000u));
+}
+
+// Two fp16 parts instead of three bf16 parts (F16 forms of the direct and the 1x1 kernel: three products instead of six, see
+// san_conv_bf16.hip "f16x2").  fp16 has the mantissa (2 x 11 bits) but not the range for gradients, so dy is multiplied by a
+// power of two S that brings the tensor's largest magnitude (a device scalar the producing kernel maintained with an
+// integer atomic max: order-independent, deterministic) to ~2^13, and the accumulators by 1 / S at the end: both exact.
+// Elements more than 2^27 below the maximum lose relative precision gradually (absolute floor 2^-25 / S).
+__device__ __forceinline__ uint32_t cvt_pk_h(float a, float b) {
+    fl2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hf2));
+}
+template <bool F16>
+__device__ __forceinline__ void split_pair(float f0, float f1, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    if constexpr (F16) {
+        p1 = cvt_pk_h(f0, f1);
+        const hf2 h = __builtin_bit_cast(hf2, p1);
+        p2 = cvt_pk_h(f0 - (float)h[0], f1 - (float)h[1]);
+        p3 = 0u;
+    } else {
+        split3_pair(f0, f1, p1, p2, p3);
+    }
+}
+template <bool F16>
+__device__ __forceinline__ f4 mma(const Frag& x, const Frag& y, f4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(x.h, y.h, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, c, 0, 0, 0);
+}
+// S = 2^(13 - floor(log2 max)) and 1 / S from the bits of the tensor's largest magnitude (0 -> 1, 1)
+__device__ __forceinline__ void amax_scale(const uint32_t* amax, float& S, float& invS) {
+    S = 1.f;
+    invS = 1.f;
+    if (amax) {
+        const uint32_t b = *amax;
+        int e = (int)((b >> 23) & 255u);
+        if (b != 0u) {
+            e = e < 14 ? 14 : (e > 250 ? 250 : e);
+            S = __builtin_bit_cast(float, (uint32_t)(267 - e) << 23);
+            invS = __builtin_bit_cast(float, (uint32_t)(e - 13) << 23);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -309,11 +352,15 @@ struct WDArgs {
     int x_ctot, x_coff, cin, dy_ctot, dy_coff, cout;
     int H, W, npc, nbands, L;
     int Q, P, ci_b, ncog, cin_pad, cout_pad;
+    const uint32_t* amax;      // F16 form: bits of max |dy| (device scalar)
 };
 
 // NP: operand parts used (3 = fp32-equivalent, six products; 2 = three products; 1 = plain bf16), san_set_conv_precision
-template <int NB, int NP>
+template <int NB, int NP, bool F16>
 __global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a) {
+    static_assert(!F16 || NP == 2, "the fp16 form has two parts");
+    float dyS, dyInvS;
+    amax_scale(F16 ? a.amax : nullptr, dyS, dyInvS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -381,9 +428,9 @@ __global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a
         const float vr = (ok && right_ok) ? san_act(xr_, sc, sh, slope) : 0.f;
         uint32_t d[3][4], dm[3], dp[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) split3_pair(v[2 * i], v[2 * i + 1], d[0][i], d[1][i], d[2][i]);
-        split3_pair(0.f, vl, dm[0], dm[1], dm[2]);       // high half = the pixel to the left
-        split3_pair(vr, 0.f, dp[0], dp[1], dp[2]);       // low half = the pixel to the right
+        for (int i = 0; i < 4; ++i) split_pair<F16>(v[2 * i], v[2 * i + 1], d[0][i], d[1][i], d[2][i]);
+        split_pair<F16>(0.f, vl, dm[0], dm[1], dm[2]);       // high half = the pixel to the left
+        split_pair<F16>(vr, 0.f, dp[0], dp[1], dp[2]);       // low half = the pixel to the right
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const uint32_t s01 = __builtin_amdgcn_alignbit(d[p][1], d[p][0], 16), s12 = __builtin_amdgcn_alignbit(d[p][2], d[p][1], 16),
@@ -416,8 +463,8 @@ __global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a
             uint32_t d[3][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                split3_pair(ok ? dlo[nb][2 * i] : 0.f, ok ? dlo[nb][2 * i + 1] : 0.f, d[0][i], d[1][i], d[2][i]);
-                split3_pair(okh ? dhi[nb][2 * i] : 0.f, okh ? dhi[nb][2 * i + 1] : 0.f, d[0][2 + i], d[1][2 + i], d[2][2 + i]);
+                split_pair<F16>(ok ? dlo[nb][2 * i] * dyS : 0.f, ok ? dlo[nb][2 * i + 1] * dyS : 0.f, d[0][i], d[1][i], d[2][i]);
+                split_pair<F16>(okh ? dhi[nb][2 * i] * dyS : 0.f, okh ? dhi[nb][2 * i + 1] * dyS : 0.f, d[0][2 + i], d[1][2 + i], d[2][2 + i]);
             }
 #pragma unroll
             for (int p = 0; p < 3; ++p) dyf[nb][p].u = u32x4{d[p][0], d[p][1], d[p][2], d[p][3]};
@@ -455,9 +502,9 @@ __global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a
                 for (int pb = 0; pb < NP - pa; ++pb)
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
-                        acc[kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0.f[pa][kx].v, dyf[nb][pb].v, acc[kx][nb], 0, 0, 0);
-                        acc[3 + kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1.f[pa][kx].v, dyf[nb][pb].v, acc[3 + kx][nb], 0, 0, 0);
-                        acc[6 + kx][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2.f[pa][kx].v, dyf[nb][pb].v, acc[6 + kx][nb], 0, 0, 0);
+                        acc[kx][nb] = mma<F16>(w0.f[pa][kx], dyf[nb][pb], acc[kx][nb]);
+                        acc[3 + kx][nb] = mma<F16>(w1.f[pa][kx], dyf[nb][pb], acc[3 + kx][nb]);
+                        acc[6 + kx][nb] = mma<F16>(w2.f[pa][kx], dyf[nb][pb], acc[6 + kx][nb]);
                     }
         __builtin_amdgcn_sched_barrier(0);
         make_row(w0);                                   // the x row fetched during the previous step replaces the oldest
@@ -470,6 +517,12 @@ __global__ void __launch_bounds__(kWT) wgrad_bf16x3_direct_kernel(const WDArgs a
         step(rc, ra, rb);
     }
 
+    if constexpr (F16) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[t][nb] *= dyInvS;
+    }
     f4* red = reinterpret_cast<f4*>(smem);
     if (wave > 0) {
 #pragma unroll
@@ -511,10 +564,14 @@ struct W1Args {
     int x_ctot, x_coff, cin, dy_ctot, dy_coff, cout;
     int HW, L, S;              // pixels per plane, steps per span, spans per image
     int Q, P, ci_b, ncog, cin_pad, cout_pad;
+    const uint32_t* amax;      // F16 form: bits of max |dy| (device scalar)
 };
 
-template <int NB, int NP>
+template <int NB, int NP, bool F16>
 __global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
+    static_assert(!F16 || NP == 2, "the fp16 form has two parts");
+    float dyS, dyInvS;
+    amax_scale(F16 ? a.amax : nullptr, dyS, dyInvS);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -568,9 +625,9 @@ __global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
         uint32_t d[3][4];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            split3_pair(ok ? san_act(xlo[2 * i], sc, sh, slope) : 0.f, ok ? san_act(xlo[2 * i + 1], sc, sh, slope) : 0.f, d[0][i], d[1][i],
+            split_pair<F16>(ok ? san_act(xlo[2 * i], sc, sh, slope) : 0.f, ok ? san_act(xlo[2 * i + 1], sc, sh, slope) : 0.f, d[0][i], d[1][i],
                         d[2][i]);
-            split3_pair(okh ? san_act(xhi[2 * i], sc, sh, slope) : 0.f, okh ? san_act(xhi[2 * i + 1], sc, sh, slope) : 0.f, d[0][2 + i],
+            split_pair<F16>(okh ? san_act(xhi[2 * i], sc, sh, slope) : 0.f, okh ? san_act(xhi[2 * i + 1], sc, sh, slope) : 0.f, d[0][2 + i],
                         d[1][2 + i], d[2][2 + i]);
         }
 #pragma unroll
@@ -579,8 +636,8 @@ __global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
         for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                split3_pair(ok ? dlo[nb][2 * i] : 0.f, ok ? dlo[nb][2 * i + 1] : 0.f, d[0][i], d[1][i], d[2][i]);
-                split3_pair(okh ? dhi[nb][2 * i] : 0.f, okh ? dhi[nb][2 * i + 1] : 0.f, d[0][2 + i], d[1][2 + i], d[2][2 + i]);
+                split_pair<F16>(ok ? dlo[nb][2 * i] * dyS : 0.f, ok ? dlo[nb][2 * i + 1] * dyS : 0.f, d[0][i], d[1][i], d[2][i]);
+                split_pair<F16>(okh ? dhi[nb][2 * i] * dyS : 0.f, okh ? dhi[nb][2 * i + 1] * dyS : 0.f, d[0][2 + i], d[1][2 + i], d[2][2 + i]);
             }
 #pragma unroll
             for (int p = 0; p < 3; ++p) dyf[nb][p].u = u32x4{d[p][0], d[p][1], d[p][2], d[p][3]};
@@ -603,10 +660,14 @@ __global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
             for (int pb = 0; pb < NP - pa; ++pb)
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
-                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[pa].v, dyf[nb][pb].v, acc[nb], 0, 0, 0);
+                    acc[nb] = mma<F16>(xf[pa], dyf[nb][pb], acc[nb]);
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    if constexpr (F16) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb] *= dyInvS;
+    }
     f4* red = reinterpret_cast<f4*>(smem);
     if (wave > 0) {
 #pragma unroll
@@ -737,24 +798,25 @@ int launch_wb(const WBArgs& a, int grid, hipStream_t s) {
 
 int g_wgrad_np = 3;            // operand parts (san_set_conv_precision)
 
-template <int NB, int NP>
+template <int NB, int NP, bool F16 = false>
 int launch_wdn(const WDArgs& a, int grid, hipStream_t s) {
     constexpr size_t lds = (size_t)(kWaves - 1) * 9 * NB * 64 * sizeof(f4);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_direct_kernel<NB, NP>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_direct_kernel<NB, NP, F16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 weight gradient", (int)lds);
             return SAN_E_UNSUPPORTED;
         }
         configured = true;
     }
-    hipLaunchKernelGGL((wgrad_bf16x3_direct_kernel<NB, NP>), dim3(grid), dim3(kWT), lds, s, a);
+    hipLaunchKernelGGL((wgrad_bf16x3_direct_kernel<NB, NP, F16>), dim3(grid), dim3(kWT), lds, s, a);
     return SAN_OK;
 }
 
 template <int NB>
 int launch_wd(const WDArgs& a, int grid, hipStream_t s) {
+    if (a.amax && g_wgrad_np == 3) return launch_wdn<NB, 2, true>(a, grid, s);      // two fp16 parts, dy scaled by its maximum
     switch (g_wgrad_np) {
         case 1: return launch_wdn<NB, 1>(a, grid, s);
         case 2: return launch_wdn<NB, 2>(a, grid, s);
@@ -824,10 +886,14 @@ W1Plan w1_plan(int n, int hw, int cin, int cout) {
 template <int NB>
 int launch_w1(const W1Args& a, int grid, hipStream_t s) {
     constexpr size_t lds = (size_t)(kWaves - 1) * NB * 64 * sizeof(f4);
+    if (a.amax && g_wgrad_np == 3) {
+        hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 2, true>), dim3(grid), dim3(kWT), lds, s, a);
+        return SAN_OK;
+    }
     switch (g_wgrad_np) {
-        case 1: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 1>), dim3(grid), dim3(kWT), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 2>), dim3(grid), dim3(kWT), lds, s, a); break;
-        default: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 3>), dim3(grid), dim3(kWT), lds, s, a); break;
+        case 1: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 1, false>), dim3(grid), dim3(kWT), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 2, false>), dim3(grid), dim3(kWT), lds, s, a); break;
+        default: hipLaunchKernelGGL((wgrad1x1_bf16x3_kernel<NB, 3, false>), dim3(grid), dim3(kWT), lds, s, a); break;
     }
     return SAN_OK;
 }
@@ -884,9 +950,9 @@ size_t san_conv_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int cou
     return split > d.partial_bytes ? split : d.partial_bytes;
 }
 
-int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
-                            float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
-                            void* scratch, int n, int h, int w, void* stream) {
+static int wgrad3_impl(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                       float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                       void* scratch, int n, int h, int w, const void* dy_amax, void* stream) {
     SAN_CHECK_ARG(x && dy && dw && scratch, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && dy_coff >= 0 && dy_coff + cout <= dy_ctot, "bad channel view");
@@ -928,6 +994,7 @@ int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, con
         d.ncog = p.ncog;
         d.cin_pad = p.cin_pad;
         d.cout_pad = p.cout_pad;
+        d.amax = static_cast<const uint32_t*>(dy_amax);
         switch (p.NB) {
             case 1: rc = launch_wd<1>(d, grid, s); break;
             case 2: rc = launch_wd<2>(d, grid, s); break;
@@ -998,9 +1065,9 @@ size_t san_conv1x1_wgrad_bf16x3_scratch_bytes(int n, int h, int w, int cin, int 
     return w1_plan(n, h * w, cin, cout).partial_bytes;
 }
 
-int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
-                             float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
-                             int transposed, void* scratch, int n, int h, int w, void* stream) {
+static int wgrad1_impl(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                       float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                       int transposed, void* scratch, int n, int h, int w, const void* dy_amax, void* stream) {
     SAN_CHECK_ARG(x && dy && dw && scratch, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && dy_coff >= 0 && dy_coff + cout <= dy_ctot, "bad channel view");
@@ -1032,6 +1099,7 @@ int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, co
     a.ncog = p.ncog;
     a.cin_pad = p.cin_pad;
     a.cout_pad = p.cout_pad;
+    a.amax = static_cast<const uint32_t*>(dy_amax);
     const int grid = p.P * p.ci_b * p.ncog;
     int rc = SAN_OK;
     switch (p.NB) {
@@ -1048,6 +1116,37 @@ int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, co
                        p.cin_pad, p.cout_pad, accumulate, 1, transposed);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
+}
+
+int san_conv2d_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                            float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                            void* scratch, int n, int h, int w, void* stream) {
+    return wgrad3_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, dy, dy_ctot, dy_coff, cout, dw, accumulate, scratch, n, h,
+                       w, nullptr, stream);
+}
+
+int san_conv1x1_wgrad_bf16x3(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                             float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                             int transposed, void* scratch, int n, int h, int w, void* stream) {
+    return wgrad1_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, dy, dy_ctot, dy_coff, cout, dw, accumulate, transposed,
+                       scratch, n, h, w, nullptr, stream);
+}
+
+// The same with dy_amax = device pointer to the bits of max |dy| (maintained by san_act_bwd* with an integer atomic max):
+// in the fp32-equivalent mode the kernels then run on two fp16 parts per operand (three products), dy scaled by a power
+// of two derived from that maximum.  dy_amax == NULL: exactly the entry points above.
+int san_conv2d_wgrad_bf16x3_amax(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                                 float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                                 void* scratch, const void* dy_amax, int n, int h, int w, void* stream) {
+    return wgrad3_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, dy, dy_ctot, dy_coff, cout, dw, accumulate, scratch, n, h,
+                       w, dy_amax, stream);
+}
+
+int san_conv1x1_wgrad_bf16x3_amax(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                                  float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
+                                  int transposed, void* scratch, const void* dy_amax, int n, int h, int w, void* stream) {
+    return wgrad1_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, dy, dy_ctot, dy_coff, cout, dw, accumulate, transposed,
+                       scratch, n, h, w, dy_amax, stream);
 }
 
 }  // extern "C"

@@ -120,6 +120,7 @@ class CSModel(BaseModel):
         """Hand-written backward of loss_all = weight_smooth*loss_smooth + weight_sim*loss_sim through
         forwardR (VarNet) and, when train_T, through the warp into forwardT (alignment network).
         Replaces ``scalar.scale(loss_all).backward()`` (model.py:203-214)."""
+        ops.AMAX.reset(self.device)             # one memset: the per-tensor gradient maxima of this step (ops.AmaxPool)
         g_rec = ops.ssim_loss_bwd(self.img_full_rss, self.img_rec, float(self.cfg.weight_sim))
         g_warped = self.net_R.backward(g_rec, want_ref_grad=train_T)
         if not train_T:

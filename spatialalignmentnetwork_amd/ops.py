@@ -185,6 +185,7 @@ class Act:
     scale: Optional[torch.Tensor] = None
     shift: Optional[torch.Tensor] = None
     slope: float = 1.0
+    amax: Optional[torch.Tensor] = None     # gradients: int32 [1] holding the float bits of max |value| (see AmaxPool)
 
     @property
     def n(self):
@@ -203,7 +204,7 @@ class Act:
         return self.buf.shape[3]
 
     def view(self, coff: int, c: int) -> "Act":
-        return Act(self.buf, self.coff + coff, c, self.scale, self.shift, self.slope)
+        return Act(self.buf, self.coff + coff, c, self.scale, self.shift, self.slope, self.amax)
 
 
 def full(buf: torch.Tensor, scale=None, shift=None, slope: float = 1.0) -> Act:
@@ -543,6 +544,41 @@ _CONV_NP = [3]
 def _fwd_fmt() -> int:
     return 16 if (F16_FWD[0] and _CONV_NP[0] == 3) else 0
 
+
+# Gradients on two fp16 parts need a per-tensor power-of-two scale: the kernels that WRITE a dy tensor (san_act_bwd*_amax)
+# keep its largest magnitude in one int32 slot of this pool (integer atomic max of the float bits: deterministic), the data /
+# weight gradient kernels that READ it derive the scale from that slot.  CSModel.backward() resets the pool once per step.
+F16_BWD = [os.environ.get("SAN_NO_F16X2_BWD", os.environ.get("SAN_NO_F16X2", "0")) != "1"]
+
+
+class AmaxPool:
+    SLOTS = 4096
+
+    def __init__(self):
+        self.buf = {}
+        self.idx = 0
+
+    def reset(self, device=None) -> None:
+        for t in self.buf.values():
+            if device is None or t.device == torch.device(device):
+                t.zero_()
+        self.idx = 0
+
+    def next(self, device) -> Optional[torch.Tensor]:
+        if not (F16_BWD[0] and _CONV_NP[0] == 3):
+            return None
+        key = str(device)
+        t = self.buf.get(key)
+        if t is None:
+            t = self.buf[key] = torch.zeros(self.SLOTS, dtype=torch.int32, device=device)
+        if self.idx >= self.SLOTS:
+            self.reset(device)
+        self.idx += 1
+        return t[self.idx - 1:self.idx]
+
+
+AMAX = AmaxPool()
+
 # Arithmetic of the matrix-core convolutions / weight gradients (san_set_conv_precision).  "bf16x3" is the default and the
 # only mode held to the 1e-4 parity bar; "bf16x2" / "bf16" are the narrow-precision modes (PSNR-judged).
 CONV_PRECISIONS = {"bf16x3": 3, "fp32": 3, "bf16x2": 2, "bf16": 1}
@@ -614,8 +650,17 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
     part = None
     if out_scale is None and bf16x3_eligible(cin, cout, h, w, ks):
         # bf16 matrix cores, operands split in three (fp32-level accuracy), csrc/san_conv_bf16.hip
-        fmt = 0 if grad_input else _fwd_fmt()
+        fmt = (16 if (x.amax is not None and _CONV_NP[0] == 3) else 0) if grad_input else _fwd_fmt()
         wp = PACKS16.get(weight, fmt)
+        if grad_input and fmt:
+            # a gradient through a plain convolution (the transposed convolution's data gradient): fp16 parts, scaled by its maximum
+            nbytes = lib().query("san_conv_bf16x3_ws_bytes", n, h, w, cin, cout, 3) if ks == 3 else 0
+            ws = arena.scratch("b16_splitk", nbytes, x.buf.device) if nbytes else None
+            gargs = (_p(x.buf), x.ctot, x.coff, cin, _p(wp), _p(y.buf), y.ctot, y.coff, cout, _p(x.amax), n, h, w, ks, _p(ws), nbytes,
+                     _stream())
+            _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
+                   lambda: lib().call("san_conv_bf16x3_dgrad_amax", *gargs), _conv_abytes(n, h, w, cin, cout, ks), 3)
+            return None
         if stats:
             part = arena.get("part" + tag, (n, cout, lib().query("san_conv_bf16x3_stat_tiles", n, h, w), 3), x.buf.device)
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
@@ -837,6 +882,15 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert dy.c == cout and dx.c == cin
     if bf16x3_eligible(cout, cin, dy.h, dy.w, ks):       # the data-gradient conv maps cout -> cin channels
+        if dy.amax is not None and _CONV_NP[0] == 3 and dy.scale is None:
+            wp = PACKS16.get(weight, 2 + 16)             # two fp16 parts; dy scaled by the power of two its maximum asks for
+            nbytes = lib().query("san_conv_bf16x3_ws_bytes", dy.n, dy.h, dy.w, cout, cin, 3) if ks == 3 else 0
+            ws = GLOBAL_ARENA.scratch("b16_splitk", nbytes, dy.buf.device) if nbytes else None
+            gargs = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(wp), _p(dx.buf), dx.ctot, dx.coff, cin, _p(dy.amax), dy.n, dy.h, dy.w,
+                     ks, _p(ws), nbytes, _stream())
+            _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
+                   lambda: lib().call("san_conv_bf16x3_dgrad_amax", *gargs), _conv_abytes(dy.n, dy.h, dy.w, cin, cout, ks), 3)
+            return
         wp = PACKS16.get(weight, 2)
         bargs = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(dy.scale), _p(dy.shift), float(dy.slope), _p(wp), _p(None),
                  _p(dx.buf), dx.ctot, dx.coff, cin, _p(None), dy.n, dy.h, dy.w, _stream())
@@ -978,10 +1032,12 @@ def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = F
         raise RuntimeError("layer too large for the bf16x3 weight gradient")
     nbytes = lib().query("san_conv_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
     scratch = arena.scratch("wgrad_bf16x3" + scratch_tag, nbytes, x.buf.device)
+    f16 = dy.amax is not None and _CONV_NP[0] == 3
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
-            cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch), x.n, x.h, x.w, _stream())
-    _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call("san_conv2d_wgrad_bf16x3", *args),
-           _conv_abytes(x.n, x.h, x.w, cin, cout, 3), _products())
+            cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch)) + ((_p(dy.amax),) if f16 else ()) + (x.n, x.h, x.w, _stream())
+    fn = "san_conv2d_wgrad_bf16x3_amax" if f16 else "san_conv2d_wgrad_bf16x3"
+    _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call(fn, *args),
+           _conv_abytes(x.n, x.h, x.w, cin, cout, 3), _products(f16))
 
 
 def wgrad1x1_bf16x3_ok(x: Act, dy: Act) -> bool:
@@ -1003,9 +1059,17 @@ def _conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool 
     assert transposed or (dw.shape[0], dw.shape[1]) == (cout, cin)
     nbytes = lib().query("san_conv1x1_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
     scratch = arena.scratch("wgrad_bf16x3" + scratch_tag, nbytes, x.buf.device)
+    f16 = dy.amax is not None and _CONV_NP[0] == 3
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
-            cout, _p(_chk(dw, name="dw")), int(accumulate), int(transposed), _p(scratch), x.n, x.h, x.w, _stream())
-    _timed("wgrad1x1_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin, "FLOP", lambda: lib().call("san_conv1x1_wgrad_bf16x3", *args))
+            cout, _p(_chk(dw, name="dw")), int(accumulate), int(transposed), _p(scratch)) + ((_p(dy.amax),) if f16 else ()) + (
+            x.n, x.h, x.w, _stream())
+    fn = "san_conv1x1_wgrad_bf16x3_amax" if f16 else "san_conv1x1_wgrad_bf16x3"
+    _timed("wgrad1x1_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin, "FLOP", lambda: lib().call(fn, *args))
+
+
+def _wave_max(n: int, c: int, device, arena: "Arena") -> torch.Tensor:
+    """scratch of the _amax activation-backward forms (stream-ordered reuse: written and reduced within one C-ABI call)"""
+    return arena.get("amax_waves", (lib().query("san_act_bwd_amax_scratch_floats", n, c),), device, _no_wait=True)
 
 
 def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA) -> None:
@@ -1016,14 +1080,21 @@ def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_
     if instance_norm:
         tiles = lib().query("san_bwd_stat_tiles", hw)
         part = arena.get("bwd_part", (y.n, y.c, tiles, 2), y.buf.device)
-    lib().call("san_act_bwd", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
-               float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, hw, _stream())
+    dy.amax = AMAX.next(y.buf.device)
+    if dy.amax is None:
+        lib().call("san_act_bwd", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+                   float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, hw, _stream())
+    else:
+        lib().call("san_act_bwd_amax", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+                   float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax),
+                   _p(_wave_max(y.n, y.c, y.buf.device, arena)), y.n, y.c, hw, _stream())
 
 
 def unshuffle2(x: Act, y: Act) -> None:
     """y[n, 4c+2dy+dx, i, j] = x[n, c, 2i+dy, 2j+dx] (x is read raw: pass a materialised gradient)."""
     assert y.c == 4 * x.c and x.h == 2 * y.h and x.w == 2 * y.w
     lib().call("san_unshuffle2_fwd", _p(x.buf), x.ctot, x.coff, _p(y.buf), y.ctot, y.coff, x.n, x.c, y.h, y.w, _stream())
+    y.amax = x.amax                                     # a permutation: the same largest magnitude
 
 
 def plane_dot_part(g: Act, y: Act, tag: str = "", arena: Arena = GLOBAL_ARENA) -> torch.Tensor:
@@ -1127,8 +1198,14 @@ def ssim_loss_bwd(x: torch.Tensor, y: torch.Tensor, gscale: float = 1.0) -> torc
 def act_bwd_coef(g: Act, y: Act, coef: torch.Tensor, dy: Act) -> None:
     """dy = sc*(u - m1 - (p*yh + q)*m2), coef [n, c, 4] = (m1, m2, p, q)."""
     assert g.c == y.c == dy.c and coef.shape == (y.n, y.c, 4)
-    lib().call("san_act_bwd_coef", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
-               float(y.slope), _p(_chk(coef, name="coef")), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, y.h * y.w, _stream())
+    dy.amax = AMAX.next(y.buf.device)
+    if dy.amax is None:
+        lib().call("san_act_bwd_coef", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+                   float(y.slope), _p(_chk(coef, name="coef")), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, y.h * y.w, _stream())
+    else:
+        lib().call("san_act_bwd_coef_amax", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+                   float(y.slope), _p(_chk(coef, name="coef")), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax),
+                   _p(_wave_max(y.n, y.c, y.buf.device, GLOBAL_ARENA)), y.n, y.c, y.h * y.w, _stream())
 
 
 def warp_bwd_grid(img: torch.Tensor, grid: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
