@@ -787,3 +787,47 @@ def test_mixed_backward_precision_full_320(S):
         print(f"mixed backward, net_{nt}: probe-estimated relative L2 vs ref64 {pe64:.2e}, worst per-tensor norm {wn64:.2e} "
               f"({name64}); reference fp32-vs-fp64 {floor:.2e}")
         assert pe64 < max(3.0 * floor, 2e-3) and wn64 < max(3.0 * floor, 2e-3)
+
+
+# ------------------------------------------------------------------ fp16 two-part operand format (default fp32-equivalent mode)
+@pytest.mark.parametrize("scale", [1.0, 3e-7, 2e4])
+@pytest.mark.parametrize("n,cin,cout,h,w,ks", [(2, 72, 36, 40, 40, 3), (1, 18, 18, 64, 64, 3), (2, 64, 64, 16, 32, 1), (1, 288, 144, 20, 20, 3)])
+def test_f16x2_forward_and_gradients_vs_float64(S, n, cin, cout, h, w, ks, scale):
+    """The fp16 two-part forms against float64: forward convolution (activations, no scale needed), data gradient and weight
+    gradient with dy of magnitude `scale` x [tiny .. 1] (a 1e-6 dynamic range inside the tensor) scaled by the power of two
+    its recorded maximum asks for.  22 mantissa bits: bars 3e-6 like the six-product bf16 form (measured ~3e-7)."""
+    ops = S.ops
+    assert ops.F16_FWD[0] and ops.F16_BWD[0]
+    x = philox("f16.x", (n, cin, h, w)) * 2
+    wt = philox("f16.w", (cout, cin, ks, ks)) * 0.1
+    pad = ks // 2
+    g0 = philox("f16.g", (n, cout, h, w))
+    rng = torch.exp(philox("f16.r", (n, cout, h, w)) * 7.0)                  # e^-7 .. e^7 spread inside the tensor
+    gout = g0 * rng * (scale / rng.max())
+    x64, w64 = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, w64, padding=pad)
+    (y64 * gout.double()).sum().backward()
+    # forward (two fp16 parts picked automatically for non-gradient inputs)
+    y = torch.empty((n, cout, h, w), device=DEV)
+    ops.conv2d(ops.full(g(x)), g(wt), None, ops.full(y))
+    assert ops.lib().query("san_get_conv_precision") == 3
+    assert rel_err(y.cpu().double(), y64.detach()) < 3e-6
+    # a dy tensor whose maximum was recorded by the activation backward: identity activation (slope 1, no affine) passes g through
+    ops.AMAX.reset(DEV)
+    dy = ops.Act(torch.empty((n, cout, h, w), device=DEV), 0, cout)
+    ops.act_bwd(ops.full(g(gout)), ops.full(g(philox("f16.y", (n, cout, h, w)))), dy, instance_norm=False)
+    assert dy.amax is not None and torch.equal(dy.buf.cpu(), gout)
+    got_max = torch.tensor([dy.amax.item()], dtype=torch.int32).view(torch.float32).item()
+    assert got_max == gout.abs().max().item()
+    dx = torch.empty((n, cin, h, w), device=DEV)
+    ops.conv2d_dgrad(dy, g(wt), ops.full(dx))
+    e_d = rel_err(dx.cpu().double(), x64.grad)
+    dw = torch.zeros((cout, cin, ks, ks), device=DEV)
+    if ks == 3:
+        ops.conv2d_wgrad_bf16x3(ops.full(g(x)), dy, dw)
+    else:
+        ops.conv2d_wgrad1x1_bf16x3(ops.full(g(x)), dy, dw)
+    torch.cuda.synchronize()
+    e_w = rel_err(dw.cpu().double(), w64.grad)
+    print(f"f16x2 {cin}->{cout} k{ks} @{h}x{w} scale {scale:g}: data gradient {e_d:.2e}, weight gradient {e_w:.2e}")
+    assert e_d < 3e-6 and e_w < 3e-6
