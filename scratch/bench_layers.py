@@ -17,6 +17,10 @@ LAYERS = [  # (cin, cout, size, count per cascade pass)
     (32, 32, 320, 0.25), (96, 32, 320, 0.08), (64, 64, 160, 0.5), (128, 64, 160, 0.08)]
 
 
+if os.environ.get("BL_ONLY"):                      # e.g. BL_ONLY=128-64-160,64-64-160
+    LAYERS = [tuple(int(v) for v in t.split("-")) + (1,) for t in os.environ["BL_ONLY"].split(",")]
+
+
 def bench(fn, reps=30):
     for _ in range(3):
         fn()

@@ -834,6 +834,17 @@ int pick_mb(int cout, int tiles) {
     return best > 5 ? 5 : best;
 }
 
+// Block count for the fp16-part format (3x3).  Measured (scratch/bench_layers.py, N = 8): with half the matrix work per chunk the
+// kernel is resident three workgroups deep up to 3 blocks, so many small workgroups win: the largest count of 2..4 that still
+// gives >= 768 workgroups (256 CUs x 3), and 2 whenever the reduction is deep enough (cin >= 64) for the matrix part to dominate.
+int pick_mb_f16(int cin, int cout, int tiles) {
+    const int nblk = san_cdiv(cout, 16);
+    if (nblk <= 2 || cin >= 64) return 2;
+    for (int mb = 4; mb > 2; --mb)
+        if (mb <= nblk && tiles * san_cdiv(nblk, mb) >= 768) return mb;
+    return 2;
+}
+
 int g_conv_np = 3;             // operand parts of the bf16 convolutions / weight gradients (san_set_conv_precision)
 
 // Which packed weight images hold two fp16 parts (packed with mode + 16) instead of bf16 parts: recorded by the pack entry
@@ -1025,7 +1036,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.th = tg.th;
     a.hp = tg.tw + 2;
     a.npx = (tg.tw + 2) * (tg.th + 2);
-    int mb = pick_mb(cout, a.tiles_x * a.tiles_y * n);
+    int mb = a.fmt == 1 && ks == 3 ? pick_mb_f16(cin, cout, a.tiles_x * a.tiles_y * n) : pick_mb(cout, a.tiles_x * a.tiles_y * n);
     if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
     a.cgs = san_cdiv(san_cdiv(cout, 16), mb);
     a.chunks = p.chunks;
@@ -1049,6 +1060,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
         }
     } else {
         int wd = (mb <= 4 && p.chunks <= 6 && h * w >= 1600) ? 1 : 0;        // see the WD note at the kernel
+        if (a.fmt == 1 && mb <= 4) wd = 1;      // fp16 parts: half the matrix work per chunk, residency wins at every depth
         if (g_b16_wd >= 0) wd = g_b16_wd && mb <= 4;
         switch (mb * 2 + wd) {
             case 4: rc = launch_b<2, false>(a, s); break;
@@ -1112,10 +1124,15 @@ size_t san_conv_bf16x3_ws_bytes(int n, int h, int w, int cin, int cout, int ks) 
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0 || ks != 3) return 0;
     const BPlan p = bplan(cout, cin, ks);
     const TileGeom tg = tile_geom(h, w);
-    int mb = pick_mb(cout, tg.tiles_x * tg.tiles_y * n);
-    if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
-    const int groups = tg.tiles_x * tg.tiles_y * n * san_cdiv(san_cdiv(cout, 16), mb);
-    const int S = splitk_parts(groups, p.chunks, ks, h * w);
+    // the run picks its block count per operand format; size the scratch for whichever of the two splits further
+    int S = 1;
+    for (int f = 0; f < 2; ++f) {
+        int mb = f ? pick_mb_f16(cin, cout, tg.tiles_x * tg.tiles_y * n) : pick_mb(cout, tg.tiles_x * tg.tiles_y * n);
+        if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
+        const int groups = tg.tiles_x * tg.tiles_y * n * san_cdiv(san_cdiv(cout, 16), mb);
+        const int Sf = splitk_parts(groups, p.chunks, ks, h * w);
+        if (Sf > S) S = Sf;
+    }
     return S > 1 ? splitk_bytes(S, n, cout, h * w) : 0;
 }
 
