@@ -21,8 +21,9 @@ Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max ran
                    launches (FLOPs the layer needs: 2 N H W Cout Cin k^2; or SURVEY 8(d) bytes) / HIP-event time of
                    those launches on their stream; peak = the roof of the unit the kernel runs on (dense bf16 MFMA
                    2.5 PFLOP/s for the bf16x3 kernels, fp32 MFMA 157.3 TFLOP/s, HBM 8 TB/s); frac = achieved / peak.
-                   The bf16x3 kernels execute 6 bf16 products per fp32 MAC: `executed_tflops` and
-                   `frac_of_bf16x3_ceiling` (ceiling = 2500 / 6 = 416.7 TFLOP/s fp32-equivalent) are extras.
+                   The split-operand kernels execute 3 fp16 products per fp32 MAC (two fp16 parts per operand; 6 on
+                   three bf16 parts with SAN_NO_F16X2=1): `executed_tflops` and `frac_of_bf16x3_ceiling` (ceiling =
+                   2500 / products TFLOP/s fp32-equivalent; fp16 and bf16 dense MFMA peaks are equal) are extras.
                    Every 29th launch of a family is bracketed and run alone (an event pair around each of ~1,700
                    launches per step costs ~6 % of the step and would serialise the two streams).
   roofline_*     : the same for the fused FFT + data-consistency kernels (HBM) and the other conv families.
@@ -45,7 +46,7 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP32_PEAK_TFLOPS = 157.3     # fp32 vector == fp32-input MFMA peak
 BF16_PEAK_TFLOPS = 2500.0    # dense bf16 MFMA peak
-BF16X3_PRODUCTS = 6.0        # bf16 products the bf16x3 kernels execute per fp32 MAC (3 with --dtype bf16x2, 1 with bf16)
+BF16X3_PRODUCTS = 6.0        # fallback when a family carries no executed-work record: products of the three-bf16-part form
 
 
 def parse_args(argv=None):
@@ -68,6 +69,8 @@ def parse_args(argv=None):
                          "products; bf16 = plain bf16 (BASELINE configs[1] as written).  FFT / DC / norms / losses are fp32 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--main-only", action="store_true",
+                    help="only the timed steps of --mode: no inference / narrow-precision legs after them (profiling runs)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step into a hipGraph and time replays (no per-kernel timer in that mode)")
     ap.add_argument("--launch-test", action="store_true",
@@ -229,8 +232,9 @@ def roofline_entry(key, d, dt, steps, pmc, match_profile, products=BF16X3_PRODUC
         if key.endswith("_bf16x3"):
             peak = BF16_PEAK_TFLOPS
             if d.get("xwork", 0.0) > 0:
-                products = d["xwork"] / d["work"]          # launch-weighted: fp16 two-part forward launches execute 3, bf16 three-part ones 6
-            extra = {"dtype": f"bf16 / fp16 matrix cores, {products:.2f} products per MAC on average (forward: two fp16 parts, 3 products; gradients: three bf16 parts, 6)",
+                products = d["xwork"] / d["work"]          # launch-weighted: fp16 two-part launches execute 3, bf16 three-part ones 6
+            extra = {"dtype": f"fp16 / bf16 matrix cores, {products:.2f} products per MAC on average (two fp16 parts: 3 products; "
+                              f"three bf16 parts, SAN_NO_F16X2=1: 6; narrow modes 3 / 1)",
                      "products_per_mac": products,
                      "executed_tflops": products * ach, "executed_frac": products * ach / peak,
                      "bf16x3_ceiling_tflops": peak / products,
@@ -336,7 +340,7 @@ def main(argv=None):
     dt = sdist.max_over_ranks(dt, dist, dev)
 
     infer = None
-    if args.mode == "train":
+    if args.mode == "train" and not args.main_only:
         # the forward-only (serving) rate of the same model, timed right after, reported alongside
         net.eval()
         for _ in range(2):
@@ -351,15 +355,16 @@ def main(argv=None):
         dti = sdist.max_over_ranks(time.perf_counter() - t1, dist, dev)
         infer = {"value": n * world * args.steps / dti, "unit": "slices/s", "ms_per_step": 1e3 * dti / args.steps}
     variants = None
-    if args.dtype == "fp32" and args.mode == "train" and not args.graph:
+    if args.dtype == "fp32" and args.mode == "train" and not args.graph and not args.main_only:
         # the narrow-precision modes of the same step (BASELINE configs[1] is written "bf16"): timed the same way, fewer
         # steps, judged by the PSNR of their reconstruction against the fp32-equivalent one just computed
-        ref_rec = net.img_rec.detach().clone()
+        # (--dtype bf16x2, two bf16 parts, stays selectable; since the fp32-equivalent mode runs on two fp16 parts it is
+        # neither faster nor more accurate than the default and is left out of this line)
         variants = {}
         vsteps = max(3, args.steps // 2)
-        for mode in ("mixed", "bf16x2", "bf16"):
-            # "mixed": fp32-equivalent forward (the parity-checked outputs), backward convolutions on two bf16 parts
-            net.conv_dtype, net.bwd_dtype = ("bf16x3", "bf16x2") if mode == "mixed" else (mode, None)
+        for mode in ("mixed", "bf16"):
+            # "mixed": fp32-equivalent forward (the parity-checked outputs), backward convolutions on plain bf16 operands
+            net.conv_dtype, net.bwd_dtype = ("bf16x3", "bf16") if mode == "mixed" else (mode, None)
             ops.set_conv_precision(net.conv_dtype)
             net.train()
             for _ in range(2):
@@ -403,8 +408,11 @@ def main(argv=None):
             "metric": "slices/sec (320x320, 12-cascade VarNet+align)", "value": total_slices / dt, "unit": "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32 (convolutions from 16-18 channels up and all weight gradients: bf16 matrix cores, operands split "
-                              "in three, six products per MAC, fp32-equivalent; FFT / DC / norms / losses fp32)",
+            "dtype": {"fp32": "f32 (convolutions from 16-18 channels up, their data and weight gradients: " + (
+                                  "fp16 matrix cores, every fp32 operand split in two fp16 parts (22 mantissa bits; gradients scaled "
+                                  "by a recorded power of two), three products per MAC, fp32 accumulate" if ops.F16_FWD[0] and ops.F16_BWD[0]
+                                  else "bf16 / fp16 matrix cores, operands split in two fp16 or three bf16 parts, fp32 accumulate") +
+                              ": fp32-equivalent and parity-checked; FFT / DC / norms / losses fp32)",
                       "bf16x2": "bf16x2 (matrix-core convolutions / weight gradients on two bf16 parts per operand, three products per "
                                 "MAC, fp32 accumulate; FFT / DC / norms / losses fp32; PSNR-judged, not parity-checked)",
                       "bf16": "bf16 (matrix-core convolutions / weight gradients on plain bf16 operands, fp32 accumulate; FFT / DC / "

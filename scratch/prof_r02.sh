@@ -1,5 +1,6 @@
 # Round-2 profile set of the default bench workload (train step, N = 8, 320 x 320, 12 cascades), one call:
-#   (1) rocprofv3 --kernel-trace --stats of `python bench.py`, as shipped and with SAN_NO_WGRAD_OVERLAP=1 (serial);
+#   (1) rocprofv3 --kernel-trace --stats of `python bench.py`, as shipped, and of the 13 training steps alone with the
+#       weight gradients in line (SAN_NO_WGRAD_OVERLAP=1 --main-only: the per-step kernel budget);
 #   (2) PMC passes of scratch/pmc_traffic.py (calibration kernels + 3 train steps), each in its own run with
 #       --kernel-trace only: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
 # Results land in gpurun_out/r02_*; scratch/pmc_r02_finalize.py turns the raw PMC json into profiles/r02_pmc.json.
@@ -9,8 +10,8 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 for mode in overlap serial; do
   rm -rf /tmp/pbench
-  if [ $mode = serial ]; then export SAN_NO_WGRAD_OVERLAP=1; else unset SAN_NO_WGRAD_OVERLAP; fi
-  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pbench -o b --output-format csv -- python $R/bench.py --no-cpu-baseline > /tmp/pbench_stdout.txt 2>&1 < /dev/null
+  if [ $mode = serial ]; then export SAN_NO_WGRAD_OVERLAP=1; EXTRA=--main-only; else unset SAN_NO_WGRAD_OVERLAP; EXTRA=; fi
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pbench -o b --output-format csv -- python $R/bench.py --no-cpu-baseline $EXTRA > /tmp/pbench_stdout.txt 2>&1 < /dev/null
   grep '"metric"' /tmp/pbench_stdout.txt | tail -1 > $R/gpurun_out/${TAG}_${mode}_bench_line.json
   for f in /tmp/pbench/*kernel_stats.csv /tmp/pbench/*/*kernel_stats.csv; do if [ -f "$f" ]; then cp "$f" $R/gpurun_out/${TAG}_${mode}_kernel_stats.csv; fi; done
 done

@@ -111,10 +111,12 @@ __device__ __forceinline__ void split3_pair(float f0, float f1, uint32_t& p1, ui
 // fp16 operand format ("f16x2"): a = a1 + a2 with a1 = fp16(a), a2 = fp16(a - a1): 22 mantissa bits in two parts, so the three
 // products a1w1 + a1w2 + a2w1 are fp32-equivalent (dropped: 2^-22) at HALF the matrix work of the six bf16 products.  The
 // matrix cores keep fp16 denormal inputs (scratch/probe/mfma_f16_denorm.hip), so small a2 cost nothing but an absolute
-// floor of 2^-25; what fp16 lacks is RANGE (|x| <= 65504, full precision above 6e-5): fine for the forward pass, whose
-// operands are normalised activations and weights, NOT for gradients (1e-7-sized dy): data and weight gradients stay on
-// the bf16 split.  End to end (scratch/study/split_fp16_accuracy.py): 2.8e-5 from the fp32 result, 5.3e-5 from fp64
-// (fp32 itself: 4.7e-5).
+// floor of 2^-25; what fp16 lacks is RANGE (|x| <= 65504, full precision above 6e-5): fine as it is for the forward pass,
+// whose operands are normalised activations and weights; GRADIENT inputs (1e-7-sized dy) are multiplied by a power of two
+// S = 2^(13 - floor(log2 max|dy|)) while they are staged and the accumulators by 1 / S in the epilogue -- exact, and max|dy|
+// is a device scalar recorded by the kernel that wrote dy (san_act_bwd_amax: per-wave maxima + a one-workgroup finalize,
+// no atomics), so nothing synchronises with the host.  End to end (scratch/study/split_fp16_accuracy.py): 2.8e-5 from the
+// fp32 result, 5.3e-5 from fp64 (fp32 itself: 4.7e-5).
 typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
 __device__ __forceinline__ uint32_t cvt_pk_h(float f0, float f1) {
     const fl2 v = {f0, f1};
