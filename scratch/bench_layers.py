@@ -51,7 +51,10 @@ for cin, cout, s, cnt in LAYERS:
     else:
         dw = torch.zeros_like(wt)
         dy = torch.randn(N, cout, s, s, device=dev)
-        t = bench(lambda: ops.conv2d_wgrad(xa, ops.full(dy), dw, accumulate=True))
+        dya = ops.full(dy)
+        if ops.F16_BWD[0]:                        # the two-fp16-part form needs the recorded max |dy| (bits of the float)
+            dya.amax = dy.abs().max().reshape(1).view(torch.int32)
+        t = bench(lambda: ops.conv2d_wgrad(xa, dya, dw, accumulate=True))
     fl = 2.0 * N * s * s * cin * cout * 9
     total += t * cnt
     print(f"{which} {cin:3d}->{cout:3d} @{s:3d}: {t:8.1f} us {fl / t / 1e6:6.1f} TF", flush=True)
