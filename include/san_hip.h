@@ -414,6 +414,7 @@ int san_gradient_loss_fwd(const float* offset, float* loss, int n, int h, int w,
  * san_conv_bf16x3_pack_job / _pack_batch: the batched form (host table entry, one launch), as for
  * san_conv_pack_job / san_conv_pack_batch. */
 int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks);
+int san_conv_bf16x3_debug_timeline(void* buf);   /* tuning: per-workgroup clock marks of the next launches (8 x u64 each; NULL = off), scratch/conv_timeline.py */
 int san_conv_bf16x3_set_tuning(int wd, int mb);   /* tests / tuning: weights-direct form (-1 auto, 0, 1), channel blocks per workgroup (-1 auto, 2..5) */
 size_t san_conv_bf16x3_packed_bytes(int cout, int cin);
 int san_conv_bf16x3_stat_tiles(int n, int h, int w);

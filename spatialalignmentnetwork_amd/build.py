@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libsan_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off", "-Wall",
-         "-Wno-unused-function"]
+         "-Wno-unused-function"] + os.environ.get("SAN_EXTRA_HIPCC_FLAGS", "").split()      # tuning builds (-DSAN_B16_RING=3 ...): use force
 
 
 def _sources():

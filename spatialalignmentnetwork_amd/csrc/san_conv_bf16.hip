@@ -72,6 +72,8 @@ struct BArgs {
     float* ws;                 // [S][N][cout][H][W] partial outputs (S > 1); splitk_reduce_kernel adds them up
     int tw, th, hp, npx;       // tile width / height (tw * th <= 256 pixels, taken in flattened order), halo pitch tw + 2, halo pixels
     int fmt;                   // operand format of the packed weights / the staging: 0 = bf16 parts, 1 = two fp16 parts
+    unsigned long long* dbg;   // tuning hook (san_conv_bf16x3_debug_timeline): per workgroup 8 x u64 = 100 MHz clock at start, first
+                               // chunk staged, epilogue start, end; HW_ID; XCC_ID -- null in normal use
     const uint32_t* amax;      // fp16 format on a GRADIENT input: bits of max |x| (device scalar); the input is scaled by a power of two
 };
 
@@ -174,6 +176,15 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         const int xcd = id & 7, slot = id >> 3;
         lin = xcd * (total >> 3) + min(xcd, total & 7) + slot;
     }
+    // (compiled in with -DSAN_B16_TIMELINE only: the marks cost ~10 VGPRs, i.e. a resident workgroup for some forms)
+    auto mark = [&](int i) {
+#ifdef SAN_B16_TIMELINE
+        if (a.dbg && tid == 0) a.dbg[(size_t)blockIdx.x * 8 + i] = __builtin_amdgcn_s_memrealtime();
+#else
+        (void)i;
+#endif
+    };
+    mark(0);
     const int ntile = a.tiles_x * a.tiles_y;
     const int sk = lin % a.S;                           // split-K part (fastest: the S parts of a tile share its input)
     const int group = lin / a.S;                        // (n, tile, cg)
@@ -367,6 +378,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 for (int p = 0; p < NP; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
         };
         __syncthreads();
+        if (chunk == c0) mark(1);
         if (chunk + 1 < c1) prefetch(chunk + 1);
         if constexpr (KS == 3) load_w(0, wa[0]);
         load_x(0, xa[0]);
@@ -394,10 +406,21 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                             else
                                 acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1][m][pw].v, xa[s & 1][b][px].v, acc[m][b], 0, 0, 0);
                         }
+#ifdef SAN_B16_TIMELINE
+            if (chunk == c0 && s == 0) mark(6);
+            if (chunk == c0 && s == 3) mark(7);
+#endif
         }
     }
 
     // ------------------------------------------------------------ epilogue
+    mark(2);
+#ifdef SAN_B16_TIMELINE
+    if (a.dbg && tid == 0) {
+        a.dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_ID
+        a.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
+    }
+#endif
     if constexpr (F16) {
         if (a.amax) {
 #pragma unroll
@@ -510,6 +533,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 }
             }
         }
+        mark(3);
         return;
     }
     // acc[m][b][r] = output channel co = (cg MB + m) 16 + 4 (lane >> 4) + r at tile pixel (trow[b], tcol[b])
@@ -756,6 +780,7 @@ int g_b16_mb = -1;             // tuning hook (SAN_B16_MB=2..5): force the chann
 int g_b16_flat = 1;            // tuning hook (SAN_B16_FLAT=0): always 32 x 8 tiles
 int g_b16_splitk = 4;          // tuning hook (SAN_B16_SPLITK=1 disables split-K, 2 / 4 = most parts per tile)
 int g_b16_splitcap = 1024;     // tuning hook (SAN_B16_SPLITCAP): most workgroups a split launch may have
+unsigned long long* g_b16_dbg = nullptr;
 int g_b16_swap = 1;            // tuning hook (SAN_B16_SWAP=0): the channel-per-register accumulator layout everywhere
 struct B16Env {
     B16Env() {
@@ -935,6 +960,21 @@ int san_conv_bf16x3_set_tuning(int wd, int mb) {
 
 // 1 when san_conv2d_bf16x3_fwd takes this layer (3x3, channel counts that fill 16-wide tiles); the caller then
 // packs the weights with san_conv_bf16x3_pack and sizes statistics with san_conv_bf16x3_stat_tiles.
+// Tuning hook (builds with -DSAN_B16_TIMELINE only; -1 otherwise): buf = device array of 8 x u64 per workgroup of the NEXT
+// bf16x3 / fp16-part convolution launches (null: off).
+// Each workgroup records the 100 MHz clock at its start, after its first chunk is staged, at the epilogue start and at its
+// end (entries 0-3), and HW_ID / XCC_ID (4, 5): scratch/conv_timeline.py turns that into per-CU occupancy and phase times.
+int san_conv_bf16x3_debug_timeline(void* buf) {
+#ifdef SAN_B16_TIMELINE
+    g_b16_dbg = static_cast<unsigned long long*>(buf);
+    return 0;
+#else
+    (void)buf;
+    san_set_error("san_conv_bf16x3_debug_timeline: build with SAN_EXTRA_HIPCC_FLAGS=-DSAN_B16_TIMELINE");
+    return -1;
+#endif
+}
+
 int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks) {
     if (ks != 3) return 0;
     // measured against the fp32 4x4x1 kernel (N = 8): faster from 18 -> 18 (66 vs 92 us @320^2) and 24 -> 24 upwards
@@ -1017,6 +1057,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.wp = (const uint4*)w_packed;
     a.fmt = g_conv_np == 3 ? format_of(w_packed) : 0;
     a.amax = a.fmt == 1 ? static_cast<const uint32_t*>(amax) : nullptr;
+    a.dbg = g_b16_dbg;
     SAN_CHECK_ARG(g_conv_np == 3 || format_of(w_packed) == 0, "fp16-format weights are for the fp32-equivalent mode only");
     a.shuffle = shuffle;
     a.bias = bias;
