@@ -321,6 +321,14 @@ int san_get_conv_precision(void);
 int san_act_bwd_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                      const float* sc, const float* sh, float slope, int mode, float* part,
                      float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw, void* stream);
+/* san_act_bwd_amax with g(p) + g2_scale * g2(p / 2) as the incoming gradient (g2: [n, g2_ctot, h/2, w/2], c channels from
+ * g2_coff): the U-Net encoder's "skip-connection gradient + average-pool adjoint" (varnet.py:118-134 under autograd: the
+ * avg_pool2d backward and the gradient accumulation at the block output) without materialising the up-sampled tensor or
+ * the sum.  hw = h * w, w % 4 == 0, h even, 16-byte aligned tensors; amax and wave_max may both be NULL. */
+int san_act_bwd_up_amax(const float* g, int g_ctot, int g_coff, const float* g2, int g2_ctot, int g2_coff, float g2_scale,
+                        const float* y, int y_ctot, int y_coff, const float* sc, const float* sh, float slope, int mode,
+                        float* part, float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw,
+                        int w, void* stream);
 int san_act_bwd_amax_scratch_floats(int n, int c);     /* floats of `wave_max` scratch (per-wave maxima, reduced by a final launch) */
 int san_act_bwd_coef_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                           const float* sc, const float* sh, float slope, const float* coef,

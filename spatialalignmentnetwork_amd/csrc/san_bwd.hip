@@ -680,6 +680,28 @@ __device__ __forceinline__ void record_wave_max(float* pmax, int wave_slot, floa
     if ((threadIdx.x & 63) == 0) pmax[wave_slot] = mx;
 }
 
+// Optional second source of the incoming gradient: g(p) += scale * g2(p / 2) with g2 a [n, c2, h/2, w/2] view -- the
+// encoder levels of the U-Net backward, where dL/d(block output) = skip-connection gradient + the average pool's adjoint
+// (x 0.25, nearest 2 x 2) of the pooled gradient.  Read here, the up-sampled tensor and the sum are never written.
+struct G2Src {
+    const float* p;        // null: no second source
+    int ctot, coff;
+    float scale;
+    int w4;                // plane width / 4 (width % 4 == 0, height even)
+    float inv_w4;
+};
+// the four values at flattened pixels 4 i .. 4 i + 3 of the (h x w) plane whose half-resolution plane starts at q
+__device__ __forceinline__ bf4 g2_add(bf4 gv, const float* __restrict__ q, int i, int w4, float inv_w4, float scale) {
+    const int row = (int)(((float)i + 0.5f) * inv_w4);              // exact for i < 2^22
+    const int c4 = i - row * w4;
+    const float2 v = *reinterpret_cast<const float2*>(q + (size_t)(row >> 1) * (2 * w4) + 2 * c4);
+    gv[0] = fmaf(scale, v.x, gv[0]);
+    gv[1] = fmaf(scale, v.x, gv[1]);
+    gv[2] = fmaf(scale, v.y, gv[2]);
+    gv[3] = fmaf(scale, v.y, gv[3]);
+    return gv;
+}
+
 __global__ void __launch_bounds__(1024) amax_finalize_kernel(const float* __restrict__ pmax, int count, unsigned* __restrict__ amax) {
     __shared__ float red[16];
     float mx = 0.f;
@@ -702,9 +724,11 @@ template <int V>
 __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
                                                             const float* __restrict__ y, int y_ctot, int y_coff,
                                                             const float* __restrict__ sc, const float* __restrict__ sh, float slope,
-                                                            float* __restrict__ dy, int d_ctot, int d_coff, int hw, float* pmax) {
+                                                            float* __restrict__ dy, int d_ctot, int d_coff, int hw, float* pmax,
+                                                            const G2Src g2) {
     __shared__ float red[16];
     const int ch = blockIdx.x, n = blockIdx.y;
+    const float* q2 = g2.p ? g2.p + ((size_t)(n * g2.ctot + g2.coff + ch)) * (hw >> 2) : nullptr;
     const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
     const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
     const bf4* gp = reinterpret_cast<const bf4*>(g + ((size_t)(n * g_ctot + g_coff + ch)) * hw);
@@ -719,7 +743,9 @@ __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restr
         u[k] = bf4{0.f, 0.f, 0.f, 0.f};
         yh[k] = bf4{0.f, 0.f, 0.f, 0.f};
         if (i < n4) {
-            const bf4 gv = gp[i], yv = yp[i];
+            bf4 gv = gp[i];
+            const bf4 yv = yp[i];
+            if (q2) gv = g2_add(gv, q2, i, g2.w4, g2.inv_w4, g2.scale);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float t = fmaf(yv[e], s, b);
@@ -765,9 +791,10 @@ __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restr
 __global__ void __launch_bounds__(kThreads)
 bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
                  const float* __restrict__ sc, const float* __restrict__ sh, float slope, int c, int hw, int tiles,
-                 float* __restrict__ part) {
+                 float* __restrict__ part, const G2Src g2) {
     __shared__ float red[8];
     const int t = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const float* q2 = g2.p ? g2.p + ((size_t)(n * g2.ctot + g2.coff + ch)) * (hw >> 2) : nullptr;
     const int chunk = (((hw + tiles - 1) / tiles) + 3) & ~3;       // multiples of 4: every chunk starts 16-byte aligned
     const int lo = t * chunk;
     const int cnt = max(0, min(hw, lo + chunk) - lo);
@@ -779,7 +806,9 @@ bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const floa
     if ((((uintptr_t)gp | (uintptr_t)yp) & 15) == 0) {            // 16-byte loads (chunks of a 4-divisible plane are 4-divisible)
         const int c4 = cnt >> 2;
         for (int i = threadIdx.x; i < c4; i += kThreads) {
-            const bf4 gv = reinterpret_cast<const bf4*>(gp)[i], yv = reinterpret_cast<const bf4*>(yp)[i];
+            bf4 gv = reinterpret_cast<const bf4*>(gp)[i];
+            const bf4 yv = reinterpret_cast<const bf4*>(yp)[i];
+            if (q2) gv = g2_add(gv, q2, (lo >> 2) + i, g2.w4, g2.inv_w4, g2.scale);       // (host: hw % 4 == 0 with g2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float yh = fmaf(yv[e], s, b);
@@ -819,8 +848,10 @@ bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const floa
 __global__ void __launch_bounds__(kThreads)
 act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
                const float* __restrict__ sc, const float* __restrict__ sh, float slope, const float* __restrict__ part,
-               int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, float* pmax) {
+               int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, float* pmax,
+               const G2Src g2) {
     const int ch = blockIdx.y, n = blockIdx.z;
+    const float* q2 = g2.p ? g2.p + ((size_t)(n * g2.ctot + g2.coff + ch)) * (hw >> 2) : nullptr;
     const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
     const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
     float m1 = 0.f, m2 = 0.f;
@@ -840,7 +871,9 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
     float mx = 0.f;
     if ((hw & 3) == 0 && ((((uintptr_t)gp | (uintptr_t)yp | (uintptr_t)dp)) & 15) == 0) {
         for (int i = blockIdx.x * kThreads + threadIdx.x; i < (hw >> 2); i += gridDim.x * kThreads) {
-            const bf4 gv = reinterpret_cast<const bf4*>(gp)[i], yv = reinterpret_cast<const bf4*>(yp)[i];
+            bf4 gv = reinterpret_cast<const bf4*>(gp)[i];
+            const bf4 yv = reinterpret_cast<const bf4*>(yp)[i];
+            if (q2) gv = g2_add(gv, q2, i, g2.w4, g2.inv_w4, g2.scale);
             bf4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1373,7 +1406,7 @@ int san_plane_dot_stats(const float* g, int g_ctot, int g_coff, const float* y, 
     int tiles = san_cdiv(hw, 4096);
     tiles = tiles < 1 ? 1 : (tiles > 32 ? 32 : tiles);
     hipLaunchKernelGGL(bwd_stats_kernel, dim3(tiles, c, n), dim3(kThreads), 0, (hipStream_t)stream, g, g_ctot, g_coff, y,
-                       y_ctot, y_coff, sc, sh, slope, c, hw, tiles, part);
+                       y_ctot, y_coff, sc, sh, slope, c, hw, tiles, part, G2Src{nullptr, 0, 0, 0.f, 1, 1.f});
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
@@ -1387,8 +1420,17 @@ int san_bwd_stat_tiles(int hw) {
 
 static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
                         const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, int n, int c,
-                        int hw, unsigned* amax, float* pmax, void* stream) {
+                        int hw, unsigned* amax, float* pmax, void* stream, const float* g2 = nullptr, int g2_ctot = 0,
+                        int g2_coff = 0, float g2_scale = 0.f, int w = 0) {
     SAN_CHECK_ARG(g && y && dy, "null pointer");
+    G2Src q{nullptr, 0, 0, 0.f, 1, 1.f};
+    if (g2) {
+        SAN_CHECK_ARG(w > 0 && (w & 3) == 0 && hw % w == 0 && ((hw / w) & 1) == 0, "second gradient source: width % 4 == 0, even height");
+        SAN_CHECK_ARG(g2_coff >= 0 && g2_coff + c <= g2_ctot, "bad channel view (second source)");
+        SAN_CHECK_ARG(((((uintptr_t)g | (uintptr_t)y | (uintptr_t)dy)) & 15) == 0 && ((uintptr_t)g2 & 7) == 0 && (hw >> 2) < (1 << 22),
+                      "second gradient source: 16-byte aligned tensors");
+        q = G2Src{g2, g2_ctot, g2_coff, g2_scale, w >> 2, 1.f / (float)(w >> 2)};
+    }
     SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
     SAN_CHECK_ARG((amax == nullptr) == (pmax == nullptr), "amax and its wave-maxima scratch come together");
     SAN_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (affine) or 1 (instance norm)");
@@ -1403,7 +1445,7 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
         // the whole plane fits one workgroup's registers: statistics and gradient in one pass
         const int v = san_cdiv(hw >> 2, 512);
         const dim3 grid(c, n);
-#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw, pmax)
+#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw, pmax, q)
         if (v <= 1) SAN_ABP(1);
         else if (v <= 2) SAN_ABP(2);
         else if (v <= 4) SAN_ABP(4);
@@ -1419,7 +1461,7 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
     }
     if (mode == 1) {
         hipLaunchKernelGGL(bwd_stats_kernel, dim3(tiles, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot,
-                           y_coff, sc, sh, slope, c, hw, tiles, part);
+                           y_coff, sc, sh, slope, c, hw, tiles, part, q);
         SAN_LAUNCH_CHECK();
     }
     int bx = san_cdiv(hw, kThreads * 4);
@@ -1428,7 +1470,7 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
     if (bx > cap) bx = (int)cap;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(bx, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc,
-                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw, pmax);
+                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw, pmax, q);
     SAN_LAUNCH_CHECK();
     if (amax) {
         hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(1024), 0, s, pmax, bx * c * n * 4, amax);
@@ -1448,6 +1490,18 @@ int san_act_bwd_amax(const float* g, int g_ctot, int g_coff, const float* y, int
                      float* wave_max, int n, int c, int hw, void* stream) {
     return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw,
                         static_cast<unsigned*>(amax), wave_max, stream);
+}
+
+// san_act_bwd_amax with g(p) + g2_scale * g2(p / 2) as the incoming gradient (g2 = a [n, g2_ctot, h/2, w/2] tensor, c channels
+// from g2_coff): the U-Net encoder's "skip gradient + average-pool adjoint" sum without materialising it.  hw = h * w, w % 4
+// == 0, h even, 16-byte aligned tensors; amax / wave_max may both be NULL.
+int san_act_bwd_up_amax(const float* g, int g_ctot, int g_coff, const float* g2, int g2_ctot, int g2_coff, float g2_scale,
+                        const float* y, int y_ctot, int y_coff, const float* sc, const float* sh, float slope, int mode,
+                        float* part, float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw,
+                        int w, void* stream) {
+    SAN_CHECK_ARG(g2 != nullptr, "null second source");
+    return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw,
+                        static_cast<unsigned*>(amax), wave_max, stream, g2, g2_ctot, g2_coff, g2_scale, w);
 }
 
 // floats of scratch the _amax forms need for the per-wave maxima

@@ -1072,8 +1072,16 @@ def _wave_max(n: int, c: int, device, arena: "Arena") -> torch.Tensor:
     return arena.get("amax_waves", (lib().query("san_act_bwd_amax_scratch_floats", n, c),), device, _no_wait=True)
 
 
-def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA) -> None:
-    """Gradient through y's lazy (scale, shift, LeakyReLU) read: g = dL/d(activation) -> dy = dL/dy_raw."""
+def act_bwd_up_ok(y: Act) -> bool:
+    """True where act_bwd can take a half-resolution second gradient source (even height, width % 4 == 0)."""
+    return (y.h & 1) == 0 and (y.w & 3) == 0 and y.h * y.w // 4 < (1 << 22)
+
+
+def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA, g2: Optional[Act] = None,
+            g2_scale: float = 0.25) -> None:
+    """Gradient through y's lazy (scale, shift, LeakyReLU) read: g = dL/d(activation) -> dy = dL/dy_raw.
+    g2 (a materialised [n, c, h/2, w/2] view): the incoming gradient is g(p) + g2_scale * g2(p // 2) -- the encoder levels'
+    skip gradient + average-pool adjoint, summed while it is read (act_bwd_up_ok(y) must hold)."""
     assert g.c == y.c == dy.c
     hw = y.h * y.w
     part = None
@@ -1081,6 +1089,13 @@ def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_
         tiles = lib().query("san_bwd_stat_tiles", hw)
         part = arena.get("bwd_part", (y.n, y.c, tiles, 2), y.buf.device)
     dy.amax = AMAX.next(y.buf.device)
+    if g2 is not None:
+        assert g2.c == y.c and (2 * g2.h, 2 * g2.w) == (y.h, y.w) and act_bwd_up_ok(y)
+        wm = None if dy.amax is None else _wave_max(y.n, y.c, y.buf.device, arena)
+        lib().call("san_act_bwd_up_amax", _p(g.buf), g.ctot, g.coff, _p(g2.buf), g2.ctot, g2.coff, float(g2_scale), _p(y.buf),
+                   y.ctot, y.coff, _p(y.scale), _p(y.shift), float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf),
+                   dy.ctot, dy.coff, _p(dy.amax), _p(wm), y.n, y.c, hw, y.w, _stream())
+        return
     if dy.amax is None:
         lib().call("san_act_bwd", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
                    float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, hw, _stream())

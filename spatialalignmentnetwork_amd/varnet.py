@@ -52,13 +52,14 @@ class ConvBlock(nn.Module):
         ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
         return out
 
-    def run_bwd(self, g_out: Act, x: Act, mid: Act, out: Act, g_in: Optional[Act]) -> None:
+    def run_bwd(self, g_out: Act, x: Act, mid: Act, out: Act, g_in: Optional[Act], g_pooled: Optional[Act] = None) -> None:
         """g_out = dL/d(lrelu(IN(out))) (materialised).  Accumulates both weight gradients and,
-        if g_in is given, writes dL/d(T(x)) (gradient wrt the lazily activated block input)."""
+        if g_in is given, writes dL/d(T(x)) (gradient wrt the lazily activated block input).
+        g_pooled: the gradient wrt avg_pool2d(block output), added on the fly as 0.25 * g_pooled(p // 2)."""
         n, h, w, dev = x.n, x.h, x.w, x.buf.device
         wa, wb = self.layers[0].weight, self.layers[3].weight
         dyb = Act(ops.wgrad_dy_buffer("bwd.dy", (n, out.c, h, w), dev, ARENA), 0, out.c)
-        ops.act_bwd(g_out, out, dyb, instance_norm=True)
+        ops.act_bwd(g_out, out, dyb, instance_norm=True, g2=g_pooled)
         ops.conv2d_wgrad(mid, dyb, _grad_of(wb), accumulate=True)
         g_mid = Act(ARENA.get("bwd.gmid", (n, mid.c, h, w), dev), 0, mid.c)
         ops.conv2d_dgrad(dyb, wb, g_mid)
@@ -291,6 +292,11 @@ class Unet(nn.Module):
             bin_, bmid_, bout = tape["blocks"][i]
             ch = bout.c
             # avg-pool backward (x0.25, nearest up-sampling) + the skip connection's gradient
+            if ops.act_bwd_up_ok(bout):                      # summed inside the block's first activation-backward kernel
+                g_next = Act(ARENA.get(f"bwd.gp.{bin_.c}.{bin_.h}.{bin_.w}", (n, bin_.c, bin_.h, bin_.w), dev), 0, bin_.c)
+                self.down_sample_layers[i].run_bwd(skip_g[i], bin_, bmid_, bout, g_next, g_pooled=Act(g_pool.buf, 0, ch))
+                g_pool = g_next
+                continue
             sc, sh = _const_affine("bwd.quarter", n, ch, 0.25, dev)
             up = Act(ARENA.get(f"bwd.pup{i}", (n, ch, bout.h, bout.w), dev), 0, ch)
             if (bout.h | bout.w) & 1:                         # the pooled-away odd row / column gets no gradient

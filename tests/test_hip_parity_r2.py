@@ -831,3 +831,33 @@ def test_f16x2_forward_and_gradients_vs_float64(S, n, cin, cout, h, w, ks, scale
     e_w = rel_err(dw.cpu().double(), w64.grad)
     print(f"f16x2 {cin}->{cout} k{ks} @{h}x{w} scale {scale:g}: data gradient {e_d:.2e}, weight gradient {e_w:.2e}")
     assert e_d < 3e-6 and e_w < 3e-6
+
+
+@pytest.mark.parametrize("n,c,h,w,coff", [(2, 5, 320, 320, 0), (2, 6, 160, 160, 1), (1, 3, 40, 24, 0), (3, 4, 6, 8, 2)])
+def test_act_bwd_second_gradient_source(S, n, c, h, w, coff):
+    """san_act_bwd_up_amax: InstanceNorm + LeakyReLU backward whose incoming gradient is g + 0.25 * nearest_up(g2) (the
+    U-Net encoder's skip gradient + avg_pool2d adjoint, varnet.py:118-134 under autograd), against float64 autograd of
+    the composed expression; both kernel forms (one-pass planes up to 160 x 160, two-kernel above)."""
+    ops = S.ops
+    ct = c + coff + 1
+    gsk, g2 = philox("abu.g", (n, ct, h, w)), philox("abu.g2", (n, ct, h // 2, w // 2)) * 3.0
+    y = philox("abu.y", (n, ct, h, w)) * 2.0 + 0.3
+    yd = y[:, coff:coff + c].double().requires_grad_(True)
+    mu, var = yd.mean((2, 3), keepdim=True), yd.var((2, 3), unbiased=False, keepdim=True)
+    a = torch.nn.functional.leaky_relu((yd - mu) / torch.sqrt(var + 1e-5), 0.2)
+    gt = gsk[:, coff:coff + c].double() + 0.25 * torch.nn.functional.interpolate(g2[:, coff:coff + c].double(), scale_factor=2, mode="nearest")
+    (want,) = torch.autograd.grad(a, yd, gt)
+    sc = (1.0 / torch.sqrt(var + 1e-5)).reshape(n, c).float()
+    sh = (-mu.reshape(n, c).double() * sc.double()).float()
+    scf, shf = torch.ones(n, ct), torch.zeros(n, ct)
+    scf[:, coff:coff + c], shf[:, coff:coff + c] = sc, sh
+    dy = torch.zeros(n, ct, h, w, device=DEV)
+    ops.AMAX.reset(torch.device(DEV))
+    dya = ops.Act(dy, coff, c)
+    ops.act_bwd(ops.Act(g(gsk), coff, c), ops.Act(g(y), coff, c, g(scf), g(shf), 0.2), dya, instance_norm=True,
+                g2=ops.Act(g(g2), coff, c))
+    got = dy[:, coff:coff + c].cpu().double()
+    assert rel_err(got, want) < 5e-6, rel_err(got, want)
+    assert dy[:, :coff].abs().sum().item() == 0.0 and dy[:, coff + c:].abs().sum().item() == 0.0      # the view's neighbours
+    if dya.amax is not None:                               # the recorded maximum is the largest |dy| written
+        assert abs(dya.amax.view(torch.float32).item() - dy.abs().max().item()) <= 1e-6 * dy.abs().max().item()
