@@ -63,10 +63,11 @@ def parse_args(argv=None):
     ap.add_argument("--cascades", type=int, default=12)
     ap.add_argument("--mode", choices=["infer", "train"], default="train",
                     help="train (default): the full optimisation step incl. the gradient all-reduce; infer: forward only")
-    ap.add_argument("--dtype", choices=["fp32", "bf16x2", "bf16"], default="fp32",
+    ap.add_argument("--dtype", choices=["fp32", "bf16x2", "bf16", "fp8"], default="fp32",
                     help="arithmetic of the matrix-core convolutions / weight gradients: fp32 = operands split in three bf16 "
                          "parts, six products per MAC (fp32-equivalent: the parity-checked default); bf16x2 = two parts, three "
-                         "products; bf16 = plain bf16 (BASELINE configs[1] as written).  FFT / DC / norms / losses are fp32 always")
+                         "products; bf16 = plain bf16 (BASELINE configs[1] as written); fp8 = forward convolutions on OCP e4m3 operands "
+                         "(v_mfma_f32_16x16x32_fp8_fp8), gradients on bf16 (BASELINE configs[4]).  FFT / DC / norms / losses are fp32 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--main-only", action="store_true",
@@ -362,8 +363,9 @@ def main(argv=None):
         # neither faster nor more accurate than the default and is left out of this line)
         variants = {}
         vsteps = max(3, args.steps // 2)
-        for mode in ("mixed", "bf16"):
-            # "mixed": fp32-equivalent forward (the parity-checked outputs), backward convolutions on plain bf16 operands
+        for mode in ("mixed", "bf16", "fp8"):
+            # "mixed": fp32-equivalent forward (the parity-checked outputs), backward convolutions on plain bf16 operands;
+            # "fp8" (BASELINE configs[4]): forward convolutions on e4m3 operands, gradients on bf16, FFT / DC fp32
             net.conv_dtype, net.bwd_dtype = ("bf16x3", "bf16") if mode == "mixed" else (mode, None)
             ops.set_conv_precision(net.conv_dtype)
             net.train()
@@ -416,7 +418,10 @@ def main(argv=None):
                       "bf16x2": "bf16x2 (matrix-core convolutions / weight gradients on two bf16 parts per operand, three products per "
                                 "MAC, fp32 accumulate; FFT / DC / norms / losses fp32; PSNR-judged, not parity-checked)",
                       "bf16": "bf16 (matrix-core convolutions / weight gradients on plain bf16 operands, fp32 accumulate; FFT / DC / "
-                              "norms / losses fp32; PSNR-judged, not parity-checked)"}[args.dtype],
+                              "norms / losses fp32; PSNR-judged, not parity-checked)",
+                      "fp8": "fp8 (forward matrix-core convolutions on OCP e4m3 operands, per-tensor power-of-two weight scale, fp32 "
+                             "accumulate; data / weight gradients on plain bf16; FFT / DC / norms / losses fp32; PSNR-judged, not "
+                             "parity-checked)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": ("train step (regime Rec: fwd + hand-written bwd + grad all-reduce + AdamW) " if args.mode == "train"
                                     else "inference pass ") + f"set_input+align+warp+VarNet{args.cascades}+SSIM, "
@@ -454,7 +459,7 @@ def main(argv=None):
                 if key not in tot or (field != "roofline" and key == dom) or tot[key]["sampled_launches"] == 0:
                     continue
                 out[field] = roofline_entry(key, tot[key], dt, args.steps, pmc, match and args.dtype == "fp32",
-                                            {"fp32": 6.0, "bf16x2": 3.0, "bf16": 1.0}[args.dtype])
+                                            {"fp32": 6.0, "bf16x2": 3.0, "bf16": 1.0, "fp8": 1.0}[args.dtype])
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)

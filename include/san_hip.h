@@ -311,6 +311,13 @@ int san_window_copy_fwd(const float* x, int x_ctot, int x_coff, const float* sc,
 int san_set_conv_precision(int parts);
 int san_get_conv_precision(void);
 
+/* fp8 forward operands (BASELINE.json configs[4]: "fp8 (CDNA4 MFMA) U-Net conv path + fp32 FFT/DC").  Pack the weights with
+ * mode + 32 (san_conv_bf16x3_pack_ks / _pack_job_ks): one OCP e4m3 value per weight, multiplied by the per-tensor power of
+ * two S_w = 2^(7 - floor(log2 max |w|)) that the packing computes on the device and keeps behind the image.  With parts = 1
+ * selected, san_conv2d_bf16x3_fwd / _fwd_ws / san_conv1x1_bf16x3_fwd / san_tconv2x2_bf16x3_fwd pick the format up from the
+ * packed image: activations x 8 -> e4m3 (clamped to +-448) while staged, v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulators
+ * x 1 / (8 S_w) before bias / statistics.  Gradients (data, weight) of the mode run on plain bf16 (mode without + 32). */
+
 /* fp16-format gradients (fp32-equivalent mode only).  The matrix-core kernels can run on TWO fp16 parts per operand (22
  * mantissa bits, three products instead of the six of the bf16 split) when their operands fit fp16's range.  Forward
  * operands (normalised activations, weights) do: pack the weights with mode + 16 and the convolution entry points pick

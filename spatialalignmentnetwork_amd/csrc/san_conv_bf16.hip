@@ -52,6 +52,7 @@ union Frag {
     uint4 u;
     bf8 v;
     h8 h;
+    long l[2];                 // l[0]: the 8 fp8 values of the one-part fp8 format
 };
 
 struct BArgs {
@@ -75,6 +76,7 @@ struct BArgs {
     unsigned long long* dbg;   // tuning hook (san_conv_bf16x3_debug_timeline): per workgroup 8 x u64 = 100 MHz clock at start, first
                                // chunk staged, epilogue start, end; HW_ID; XCC_ID -- null in normal use
     const uint32_t* amax;      // fp16 format on a GRADIENT input: bits of max |x| (device scalar); the input is scaled by a power of two
+    const float* f8_tail;      // fp8 format: {S_w, 1 / S_w} behind the packed image (the per-tensor power-of-two weight scale)
 };
 
 // round-to-nearest-even bf16 of f, returned as the fp32 it represents (upper 16 bits)
@@ -136,6 +138,17 @@ __device__ __forceinline__ void split2h(float f, uint32_t& p1, uint32_t& p2) {
     p2 = __builtin_bit_cast(uint16_t, b);
 }
 
+// fp8 operand format ("fp8", BASELINE config 5): ONE OCP e4m3 part per operand on v_mfma_f32_16x16x32_fp8_fp8 (same rate as the
+// bf16 instruction, half the operand bytes).  e4m3 holds 4 significant bits between 2^-6 and 448, so both operands are brought
+// into range by powers of two (exact): activations (normalised by the lazy affine: O(1)) x 8, clamped to +-448; weights x
+// S_w = 2^(7 - floor(log2 max |w|)) per tensor (fp8_wscale_*_kernel, next to the packing); the accumulators get 1 / (8 S_w).
+constexpr float kF8ActScale = 8.f;
+__device__ __forceinline__ uint32_t cvt_f8x4(float f0, float f1, float f2, float f3) {
+    int p = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f0, -448.f, 448.f), __builtin_amdgcn_fmed3f(f1, -448.f, 448.f), 0, false);
+    p = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(f2, -448.f, 448.f), __builtin_amdgcn_fmed3f(f3, -448.f, 448.f), p, true);
+    return (uint32_t)p;
+}
+
 // WD ("weights direct"): the K-steps read their weight operands straight from the packed image in L2 instead of
 // staging each chunk's weights through LDS.  All four waves then fetch the same weights (4x the L1 traffic), but the
 // workgroup needs 49 KB of LDS instead of 92-156 KB, so three of them share a CU: measured +17..30 % for MB <= 4 with
@@ -152,9 +165,11 @@ __device__ __forceinline__ void split2h(float f, uint32_t& p1, uint32_t& p2) {
 // a lane ends with FOUR CONSECUTIVE PIXELS of ONE channel per accumulator tile (D[4 kg + r][nn]), so the epilogue stores 16
 // bytes per lane and the plane statistics are 16 in-lane values + two cross-row steps per channel.  Not for the pixel-shuffle
 // epilogue of the transposed form (there a lane must hold the four virtual channels of one real channel).
-template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16>
+// F8: the one-part fp8 e4m3 format (see kF8ActScale).
+template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16, bool F8>
 __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     static_assert(!F16 || NP == 2, "the fp16 format has two parts");
+    static_assert(!F8 || (NP == 1 && !F16), "the fp8 format has one part");
     constexpr int kSteps = KS == 3 ? 7 : 1;            // (shadows the 3x3 constant)
     static_assert(KS == 3 || WD, "the 1x1 form reads its weights directly");
     constexpr int WCH = kSteps * MB * 3 * 64;          // uint4 per (cg, chunk) weight image
@@ -249,6 +264,10 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
             }
         }
     }
+    if constexpr (F8) {
+        inS = kF8ActScale;
+        inInvS = a.f8_tail[1] * (1.f / kF8ActScale);
+    }
     auto fetch_aff = [&](int chunk) {
         if (tid < 48) {
             const int ci = min(chunk * kCKC + (tid < 24 ? tid : tid - 24), a.cin - 1);
@@ -326,7 +345,10 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
             for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    if constexpr (WD) wq[m][p].u = wsrc[((s * a.nblkp + m) * 3 + p) * 64];
+                    if constexpr (F8) {             // the low 8 bytes of the part-0 slot
+                        if constexpr (WD) wq[m][p].l[0] = *reinterpret_cast<const long*>(&wsrc[((s * a.nblkp + m) * 3 + p) * 64]);
+                        else wq[m][p].l[0] = *reinterpret_cast<const long*>(&lds_w[((s * MB + m) * 3 + p) * 64 + lane]);
+                    } else if constexpr (WD) wq[m][p].u = wsrc[((s * a.nblkp + m) * 3 + p) * 64];
                     else wq[m][p].u = lds_w[((s * MB + m) * 3 + p) * 64 + lane];
                 }
         };
@@ -340,6 +362,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 #pragma unroll
         for (int s = 0; s < kUnits; ++s) {
             uint32_t q1[4], q2[4], q3[4];
+            float vv[8];
             const f4 sc0 = *reinterpret_cast<const f4*>(afc + s_chg[s] * 8), sc1 = *reinterpret_cast<const f4*>(afc + s_chg[s] * 8 + 4);
             const f4 sh0 = *reinterpret_cast<const f4*>(afc + 24 + s_chg[s] * 8), sh1 = *reinterpret_cast<const f4*>(afc + 24 + s_chg[s] * 8 + 4);
 #pragma unroll
@@ -348,14 +371,20 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                 const float sha = i < 4 ? sh0[i] : sh1[i - 4], shb = i < 4 ? sh0[i + 1] : sh1[i - 3];
                 const float v0 = s_in[s] ? san_act(st[s][i], sca, sha, a.in_slope) : 0.f;
                 const float v1 = s_in[s] ? san_act(st[s][i + 1], scb, shb, a.in_slope) : 0.f;
-                if constexpr (F16) {
+                if constexpr (F8) {
+                    vv[i] = v0;
+                    vv[i + 1] = v1;
+                } else if constexpr (F16) {
                     split2h_pair(v0, v1, q1[i >> 1], q2[i >> 1]);
                     q3[i >> 1] = 0u;
                 } else {
                     split3_pair(v0, v1, q1[i >> 1], q2[i >> 1], q3[i >> 1]);
                 }
             }
-            if (s_loff[s] >= 0) {
+            if constexpr (F8) {
+                if (s_loff[s] >= 0)
+                    *reinterpret_cast<uint2*>(lds_a + s_loff[s]) = make_uint2(cvt_f8x4(vv[0], vv[1], vv[2], vv[3]), cvt_f8x4(vv[4], vv[5], vv[6], vv[7]));
+            } else if (s_loff[s] >= 0) {
                 *reinterpret_cast<uint4*>(lds_a + s_loff[s]) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
                 if constexpr (NP > 1) *reinterpret_cast<uint4*>(lds_a + kPartB + s_loff[s]) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
                 if constexpr (NP > 2) *reinterpret_cast<uint4*>(lds_a + 2 * kPartB + s_loff[s]) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
@@ -375,7 +404,10 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
-                for (int p = 0; p < NP; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
+                for (int p = 0; p < NP; ++p) {
+                    if constexpr (F8) xq[b][p].l[0] = *reinterpret_cast<const long*>(lds_a + boff[b] + to);
+                    else xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
+                }
         };
         __syncthreads();
         if (chunk == c0) mark(1);
@@ -396,7 +428,12 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
-                            if constexpr (F16) {
+                            if constexpr (F8) {
+                                if constexpr (SWAP)
+                                    acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(xa[s & 1][b][px].l[0], wa[s & 1][m][pw].l[0], acc[m][b], 0, 0, 0);
+                                else
+                                    acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wa[s & 1][m][pw].l[0], xa[s & 1][b][px].l[0], acc[m][b], 0, 0, 0);
+                            } else if constexpr (F16) {
                                 if constexpr (SWAP)
                                     acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][px].h, wa[s & 1][m][pw].h, acc[m][b], 0, 0, 0);
                                 else
@@ -421,8 +458,8 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         a.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
     }
 #endif
-    if constexpr (F16) {
-        if (a.amax) {
+    if constexpr (F16 || F8) {
+        if (F8 || a.amax) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -711,8 +748,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // One thread per (chunk, step, blk, lane): its 8 values (consecutive input channels of one tap) are gathered once,
 // split three ways and written as three 16-byte vectors (one per part).
 __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t u, int cout,
-                                          int cin, int nblkp, int mode_, int ks) {
+                                          int cin, int nblkp, int mode_, int ks, const float* __restrict__ wscale) {
     const bool f16 = (mode_ & 16) != 0;            // mode + 16: two fp16 parts (parts 0, 1 of the image; part 2 zero)
+    const bool f8 = (mode_ & 32) != 0;             // mode + 32: one fp8 e4m3 part x the tensor's scale (low 8 bytes of the part-0 slot)
+    const float wS = f8 ? wscale[0] : 1.f;
     const int mode = mode_ & 15;
     const int lane = (int)(u & 63);
     size_t r = u >> 6;
@@ -728,6 +767,7 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t*
     const bool live = co < cout && (ks == 1 ? tap == 0 : tap < 9);
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 q[3];
+    float v8[8];
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
         float v[2];
@@ -740,6 +780,8 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t*
                 else v[k] = mode == 2 ? w[((size_t)ci * cout + co) * 9 + (8 - tap)] : w[((size_t)co * cin + ci) * 9 + tap];
             }
         }
+        v8[i] = v[0] * wS;
+        v8[i + 1] = v[1] * wS;
         uint32_t a1, a2, a3 = 0, b1, b2, b3 = 0;
         if (f16) {
             split2h(v[0], a1, a2);
@@ -754,6 +796,10 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t*
     }
     // packed[(((chunk steps + step) nblkp + blk) 3 + part) 64 + lane][8]
     uint16_t* o = packed + ((u >> 6) * 3 * 64 + lane) * 8;
+    if (f8) {
+        q[0] = u32x4{cvt_f8x4(v8[0], v8[1], v8[2], v8[3]), cvt_f8x4(v8[4], v8[5], v8[6], v8[7]), 0u, 0u};
+        q[1] = q[2] = u32x4{0u, 0u, 0u, 0u};
+    }
 #pragma unroll
     for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(o + (size_t)p * 64 * 8) = q[p];
 }
@@ -762,7 +808,7 @@ __global__ void pack_bf16x3_kernel(const float* __restrict__ w, uint16_t* __rest
                                    int cin, int nblkp, int mode, int ks) {
     const size_t units = total / 24;
     for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x)
-        pack_unit(w, packed, u, cout, cin, nblkp, mode, ks);
+        pack_unit(w, packed, u, cout, cin, nblkp, mode, ks, reinterpret_cast<const float*>(packed + total));
 }
 
 // batched: 8 x int64 per job = {w, packed, cout, cin, nblkp, ks (0 = 3), mode, total}
@@ -772,7 +818,54 @@ __global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
     uint16_t* packed = reinterpret_cast<uint16_t*>(j[1]);
     const size_t units = (size_t)j[7] / 24;
     for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x)
-        pack_unit(w, packed, u, (int)j[2], (int)j[3], (int)j[4], (int)j[6], j[5] == 1 ? 1 : 3);
+        pack_unit(w, packed, u, (int)j[2], (int)j[3], (int)j[4], (int)j[6], j[5] == 1 ? 1 : 3, reinterpret_cast<const float*>(packed + (size_t)j[7]));
+}
+
+// fp8 format: the tensor's power-of-two scale {S_w, 1 / S_w}, S_w = 2^(7 - floor(log2 max |w|)) (scaled maximum in [128, 256)),
+// written behind the packed image.  One 1024-thread workgroup per tensor (max is order-independent); launched before the packing kernel.
+__device__ __forceinline__ void fp8_wscale(const float* __restrict__ w, size_t count, float* __restrict__ tail) {
+    __shared__ float red[16];
+    float m = 0.f;
+    if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+        const f4* w4 = reinterpret_cast<const f4*>(w);
+        const size_t n4 = count >> 2;
+#pragma unroll 4
+        for (size_t i = threadIdx.x; i < n4; i += 1024) {
+            const f4 v = w4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        }
+        for (size_t i = (n4 << 2) + threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(w[i]));
+    } else {
+#pragma unroll 4
+        for (size_t i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(w[i]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 16; ++k) m = fmaxf(m, red[k]);
+        int e = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 255u);       // biased exponent of the maximum
+        float S = 1.f, inv = 1.f;
+        if (m > 0.f && m < __builtin_inff()) {
+            e = e < 10 ? 10 : (e > 240 ? 240 : e);
+            S = __builtin_bit_cast(float, (uint32_t)(127 + 7 - (e - 127)) << 23);
+            inv = __builtin_bit_cast(float, (uint32_t)(127 - 7 + (e - 127)) << 23);
+        }
+        tail[0] = S;
+        tail[1] = inv;
+    }
+}
+
+__global__ void __launch_bounds__(1024) fp8_wscale_kernel(const float* __restrict__ w, size_t count, float* __restrict__ tail) {
+    fp8_wscale(w, count, tail);
+}
+
+__global__ void __launch_bounds__(1024) fp8_wscale_batch_kernel(const long long* __restrict__ jobs) {
+    const long long* j = jobs + 8 * (size_t)blockIdx.x;
+    if (((int)j[6] & 32) == 0) return;
+    fp8_wscale(reinterpret_cast<const float*>(j[0]), (size_t)j[2] * (size_t)j[3] * (j[5] == 1 ? 1 : 9),
+               reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(j[1]) + (size_t)j[7]));
 }
 
 int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): force the weights-direct choice
@@ -880,7 +973,8 @@ std::mutex g_fmt_mu;
 std::unordered_map<const void*, int> g_fmt;
 void note_format(const void* packed, int mode) {
     std::lock_guard<std::mutex> lk(g_fmt_mu);
-    if (mode & 16) g_fmt[packed] = 1;
+    if (mode & 32) g_fmt[packed] = 2;
+    else if (mode & 16) g_fmt[packed] = 1;
     else g_fmt.erase(packed);
 }
 int format_of(const void* packed) {
@@ -889,12 +983,12 @@ int format_of(const void* packed) {
     return it == g_fmt.end() ? 0 : it->second;
 }
 
-template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16 = false>
+template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16 = false, bool F8 = false>
 int launch_bfns(const BArgs& a, hipStream_t s) {
     constexpr size_t lds = 3 * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -902,7 +996,7 @@ int launch_bfns(const BArgs& a, hipStream_t s) {
         configured = true;
     }
     const int total = a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16>), dim3(total), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8>), dim3(total), dim3(kT), lds, s, a);
     return SAN_OK;
 }
 
@@ -920,6 +1014,10 @@ int launch_bf(const BArgs& a, hipStream_t s) {
     if (a.fmt == 1) {                               // two fp16 parts (forward operands, fp32-equivalent mode only)
         if (g_b16_swap && !a.shuffle && !FLAT) return launch_bfns<MB, WD, KS, FLAT, 2, true, true>(a, s);
         return launch_bfns<MB, WD, KS, FLAT, 2, false, true>(a, s);
+    }
+    if (a.fmt == 2) {                               // one fp8 part (forward operands of the "fp8" mode)
+        if (g_b16_swap && !a.shuffle && !FLAT) return launch_bfns<MB, WD, KS, FLAT, 1, true, false, true>(a, s);
+        return launch_bfns<MB, WD, KS, FLAT, 1, false, false, true>(a, s);
     }
     switch (g_conv_np) {
         case 1: return launch_bfn<MB, WD, KS, FLAT, 1>(a, s);
@@ -985,7 +1083,8 @@ int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks) {
     return 1;
 }
 
-size_t san_conv_bf16x3_packed_bytes_ks(int cout, int cin, int ks) { return bplan(cout, cin, ks).packed_elems * 2; }
+// (+ 16 bytes behind the image: the fp8 format keeps its per-tensor weight scale there)
+size_t san_conv_bf16x3_packed_bytes_ks(int cout, int cin, int ks) { return bplan(cout, cin, ks).packed_elems * 2 + 16; }
 size_t san_conv_bf16x3_packed_bytes(int cout, int cin) { return san_conv_bf16x3_packed_bytes_ks(cout, cin, 3); }
 
 int san_conv_bf16x3_stat_tiles(int n, int h, int w) {
@@ -996,10 +1095,15 @@ int san_conv_bf16x3_stat_tiles(int n, int h, int w) {
 
 int san_conv_bf16x3_pack_ks(const float* w, void* packed, int cout, int cin, int mode, int ks, void* stream) {
     SAN_CHECK_ARG(w && packed, "null pointer");
-    SAN_CHECK_ARG(cout > 0 && cin > 0 && ((mode & 15) == 0 || (mode & 15) == 2) && (mode & ~16) == (mode & 15) && (ks == 1 || ks == 3), "bad dims / mode / ks");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && ((mode & 15) == 0 || (mode & 15) == 2) && (mode & ~48) == (mode & 15) && (mode & 48) != 48 && (ks == 1 || ks == 3), "bad dims / mode / ks");
     // mode 2: `cout`, `cin` are those of the DATA-GRADIENT convolution (cout = forward cin, cin = forward cout)
     const BPlan p = bplan(cout, cin, ks);
     note_format(packed, mode);
+    if (mode & 32) {
+        hipLaunchKernelGGL(fp8_wscale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (size_t)cout * cin * (ks == 1 ? 1 : 9),
+                           reinterpret_cast<float*>(static_cast<uint16_t*>(packed) + p.packed_elems));
+        SAN_LAUNCH_CHECK();
+    }
     size_t blocks = (p.packed_elems + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w, (uint16_t*)packed,
@@ -1014,7 +1118,7 @@ int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mo
 
 int san_conv_bf16x3_pack_job_ks(long long* job8, const float* w, void* packed, int cout, int cin, int mode, int ks) {
     SAN_CHECK_ARG(job8 && w && packed, "null pointer");
-    SAN_CHECK_ARG(cout > 0 && cin > 0 && ((mode & 15) == 0 || (mode & 15) == 2) && (mode & ~16) == (mode & 15) && (ks == 1 || ks == 3), "bad dims / mode / ks");
+    SAN_CHECK_ARG(cout > 0 && cin > 0 && ((mode & 15) == 0 || (mode & 15) == 2) && (mode & ~48) == (mode & 15) && (mode & 48) != 48 && (ks == 1 || ks == 3), "bad dims / mode / ks");
     const BPlan p = bplan(cout, cin, ks);
     note_format(packed, mode);
     job8[0] = (long long)(uintptr_t)w;
@@ -1034,6 +1138,7 @@ int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int 
 
 int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* stream) {
     SAN_CHECK_ARG(jobs_dev && njobs > 0, "empty job table");
+    hipLaunchKernelGGL(fp8_wscale_batch_kernel, dim3(njobs), dim3(1024), 0, (hipStream_t)stream, jobs_dev);    // (returns at once for other formats)
     hipLaunchKernelGGL(pack_bf16x3_batch_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
@@ -1055,10 +1160,12 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.in_shift = in_shift;
     a.in_slope = in_slope;
     a.wp = (const uint4*)w_packed;
-    a.fmt = g_conv_np == 3 ? format_of(w_packed) : 0;
+    a.fmt = format_of(w_packed);
+    SAN_CHECK_ARG(a.fmt != 1 || g_conv_np == 3, "fp16-format weights are for the fp32-equivalent mode only");
+    SAN_CHECK_ARG(a.fmt != 2 || g_conv_np == 1, "fp8-format weights are for the one-part mode only (san_set_conv_precision(1))");
     a.amax = a.fmt == 1 ? static_cast<const uint32_t*>(amax) : nullptr;
+    a.f8_tail = a.fmt == 2 ? reinterpret_cast<const float*>(static_cast<const uint16_t*>(w_packed) + p.packed_elems) : nullptr;
     a.dbg = g_b16_dbg;
-    SAN_CHECK_ARG(g_conv_np == 3 || format_of(w_packed) == 0, "fp16-format weights are for the fp32-equivalent mode only");
     a.shuffle = shuffle;
     a.bias = bias;
     a.y = y;
@@ -1079,7 +1186,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.th = tg.th;
     a.hp = tg.tw + 2;
     a.npx = (tg.tw + 2) * (tg.th + 2);
-    int mb = a.fmt == 1 && ks == 3 ? pick_mb_f16(cin, cout, a.tiles_x * a.tiles_y * n) : pick_mb(cout, a.tiles_x * a.tiles_y * n);
+    int mb = a.fmt >= 1 && ks == 3 ? pick_mb_f16(cin, cout, a.tiles_x * a.tiles_y * n) : pick_mb(cout, a.tiles_x * a.tiles_y * n);
     if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
     a.cgs = san_cdiv(san_cdiv(cout, 16), mb);
     a.chunks = p.chunks;
@@ -1103,7 +1210,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
         }
     } else {
         int wd = (mb <= 4 && p.chunks <= 6 && h * w >= 1600) ? 1 : 0;        // see the WD note at the kernel
-        if (a.fmt == 1 && mb <= 4) wd = 1;      // fp16 parts: half the matrix work per chunk, residency wins at every depth
+        if (a.fmt >= 1 && mb <= 4) wd = 1;      // fp16 parts: half the matrix work per chunk, residency wins at every depth
         if (g_b16_wd >= 0) wd = g_b16_wd && mb <= 4;
         switch (mb * 2 + wd) {
             case 4: rc = launch_b<2, false>(a, s); break;

@@ -60,7 +60,7 @@ class CSModel(BaseModel):
         self.use_amp = bool(get("use_amp", False))
         # The reference's mixed-precision seam is torch.cuda.amp.autocast(enabled=use_amp) around the forwards
         # (model.py:83-87,104).  Here it selects the arithmetic of the matrix-core convolutions: cfg.conv_dtype in
-        # {"bf16x3" (fp32-equivalent, default), "bf16x2", "bf16"}; use_amp without conv_dtype means plain bf16.  FFT, data
+        # {"bf16x3" (fp32-equivalent, default), "bf16x2", "bf16", "fp8" (e4m3 forward, bf16 gradients)}; use_amp without conv_dtype means plain bf16.  FFT, data
         # consistency, normalisation statistics and losses are fp32 in every mode; no GradScaler is needed (bf16 has
         # fp32's exponent range).
         self.conv_dtype = get("conv_dtype", None)      # None: follow use_amp (which eval.py:41 switches off after loading)

@@ -91,7 +91,7 @@ def _timed(name, work, unit, fn, abytes=0.0, products=0):
 
 
 def _products(f16: bool = False) -> int:
-    return 3 if f16 else {3: 6, 2: 3, 1: 1}[_CONV_NP[0]]
+    return 3 if (f16 and _CONV_NP[0] == 3) else {3: 6, 2: 3, 1: 1}[_CONV_NP[0]]
 
 
 def _conv_abytes(n, h, w, cin, cout, ks):
@@ -501,7 +501,7 @@ class _PackRegistryBf16(_PackRegistry):
     mode 2 data gradient; dims = (cout, cin) of the convolution that will run."""
 
     def _alloc(self, w: torch.Tensor, mode: int):
-        mode &= 15                                      # (+16 = two fp16 parts instead of bf16 parts: same image size)
+        mode &= 15                                      # (+16 = two fp16 parts, +32 = one fp8 part instead of bf16 parts: same image size)
         if mode == 3:                                   # ConvTranspose2d [Cin, Cout, 2, 2] as a 1x1 conv to 4 Cout channels
             return (4 * w.shape[1], w.shape[0], 1), torch.empty(
                 lib().query("san_conv_bf16x3_packed_bytes_ks", 4 * w.shape[1], w.shape[0], 1), device=w.device, dtype=torch.uint8)
@@ -520,8 +520,8 @@ class _PackRegistryBf16(_PackRegistry):
 
     @staticmethod
     def _cmode(mode: int) -> int:
-        """registry mode -> library mode: 3 (transposed) packs like a data gradient (2); bit 4 (fp16 parts) passes through"""
-        return (2 if (mode & 15) == 3 else (mode & 15)) | (mode & 16)
+        """registry mode -> library mode: 3 (transposed) packs like a data gradient (2); bits 4 (fp16 parts) / 5 (fp8) pass through"""
+        return (2 if (mode & 15) == 3 else (mode & 15)) | (mode & 48)
 
     def _batch(self):
         lib().call("san_conv_bf16x3_pack_batch", _p(self.table), len(self.order), _stream())
@@ -539,9 +539,14 @@ PACKS16 = _PackRegistryBf16()
 # is ample.  Gradients (1e-7-sized) keep the three-part bf16 split.  SAN_NO_F16X2=1 switches it off.
 F16_FWD = [os.environ.get("SAN_NO_F16X2", "0") != "1"]
 _CONV_NP = [3]
+# "fp8" mode (BASELINE config 5): FORWARD convolutions on one OCP e4m3 part per operand (per-tensor power-of-two weight scale,
+# activations x 8: csrc/san_conv_bf16.hip "fp8"); data and weight gradients on plain bf16; FFT / DC / norms / losses fp32.
+_FP8_FWD = [False]
 
 
 def _fwd_fmt() -> int:
+    if _FP8_FWD[0] and _CONV_NP[0] == 1:
+        return 32
     return 16 if (F16_FWD[0] and _CONV_NP[0] == 3) else 0
 
 
@@ -581,16 +586,17 @@ AMAX = AmaxPool()
 
 # Arithmetic of the matrix-core convolutions / weight gradients (san_set_conv_precision).  "bf16x3" is the default and the
 # only mode held to the 1e-4 parity bar; "bf16x2" / "bf16" are the narrow-precision modes (PSNR-judged).
-CONV_PRECISIONS = {"bf16x3": 3, "fp32": 3, "bf16x2": 2, "bf16": 1}
+CONV_PRECISIONS = {"bf16x3": 3, "fp32": 3, "bf16x2": 2, "bf16": 1, "fp8": 1}
 
 
 def set_conv_precision(mode: str) -> str:
     """Select the operand parts of every bf16 matrix-core kernel (process-wide); returns the previous mode's name."""
     if mode not in CONV_PRECISIONS:
         raise ValueError(f"conv precision {mode!r}: choose from {sorted(CONV_PRECISIONS)}")
-    prev = {3: "bf16x3", 2: "bf16x2", 1: "bf16"}[lib().query("san_get_conv_precision")]
+    prev = {3: "bf16x3", 2: "bf16x2", 1: "fp8" if _FP8_FWD[0] else "bf16"}[lib().query("san_get_conv_precision")]
     lib().call("san_set_conv_precision", CONV_PRECISIONS[mode])
     _CONV_NP[0] = CONV_PRECISIONS[mode]
+    _FP8_FWD[0] = mode == "fp8"
     return prev
 
 

@@ -861,3 +861,145 @@ def test_act_bwd_second_gradient_source(S, n, c, h, w, coff):
     assert dy[:, :coff].abs().sum().item() == 0.0 and dy[:, coff + c:].abs().sum().item() == 0.0      # the view's neighbours
     if dya.amax is not None:                               # the recorded maximum is the largest |dy| written
         assert abs(dya.amax.view(torch.float32).item() - dy.abs().max().item()) <= 1e-6 * dy.abs().max().item()
+
+
+# ------------------------------------------------------------------ fp8 forward convolutions (BASELINE config 5)
+def _e4m3(t):
+    """OCP e4m3 round-to-nearest-even of a float32 tensor (|t| <= 448), as float64."""
+    return t.clamp(-448.0, 448.0).to(torch.float8_e4m3fn).double()
+
+
+def _w_scale(wt):
+    import math
+    return 2.0 ** (7 - math.floor(math.log2(float(wt.abs().max()))))
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,ks,kind", [
+    (2, 72, 36, 40, 40, 3, "conv"),        # FLAT tile, weights direct
+    (2, 18, 18, 64, 96, 3, "conv"),        # 32 x 8 tiles, half-padded channel blocks, operand-swapped epilogue
+    (1, 96, 160, 24, 40, 3, "conv"),       # five channel blocks
+    (2, 288, 288, 20, 20, 3, "conv"),      # split-K
+    (2, 64, 32, 32, 48, 1, "conv"),        # 1x1 form
+    (2, 72, 36, 16, 24, 1, "tconv"),       # transposed 2x2 s2: pixel-shuffle epilogue
+])
+def test_fp8_forward_matches_quantised_float64(S, n, cin, cout, h, w, ks, kind):
+    """The fp8 mode's forward convolutions against float64 arithmetic on the SAME quantised operands: activations x 8 and
+    weights x S_w = 2^(7 - floor(log2 max |w|)) rounded to OCP e4m3 (torch.float8_e4m3fn on the CPU), products and sums in
+    float64.  This pins the operand layout of v_mfma_f32_16x16x32_fp8_fp8, the hardware conversion (round to nearest
+    even, subnormals kept) and the scale bookkeeping: what is left is the fp8 matrix core's internal accumulation (measured 7.6-8.0e-6 = 2^-17 on every shape, independent of K).  Also
+    printed: the distance to the unquantised float64 result (the format's own error, ~3e-2)."""
+    ops, F = S.ops, torch.nn.functional
+    x = philox("f8.x", (n, cin, h, w)) * 3.0
+    x8 = _e4m3(x * 8.0) / 8.0
+    try:
+        with ops.conv_precision("fp8"):
+            if kind == "conv":
+                wt = philox("f8.w", (cout, cin, ks, ks)) * 0.05
+                Sw = _w_scale(wt)
+                want = F.conv2d(x8, _e4m3(wt * Sw) / Sw, padding=ks // 2)
+                exact = F.conv2d(x.double(), wt.double(), padding=ks // 2)
+                y = torch.empty((n, cout, h, w), device=DEV)
+                part = ops.conv2d(ops.full(g(x)), g(wt), None, ops.full(y), stats=True)
+            else:
+                wt = philox("f8.wt", (cin, cout, 2, 2)) * 0.05
+                Sw = _w_scale(wt)
+                want = F.conv_transpose2d(x8, _e4m3(wt * Sw) / Sw, stride=2)
+                exact = F.conv_transpose2d(x.double(), wt.double(), stride=2)
+                y = torch.empty((n, cout, 2 * h, 2 * w), device=DEV)
+                part = ops.tconv2x2(ops.full(g(x)), g(wt), ops.full(y), stats=True)
+            torch.cuda.synchronize()
+        got = y.cpu().double()
+        e, eq = rel_err(got, want), rel_err(got, exact)
+        print(f"fp8 {kind} {cin}->{cout} @{h}x{w} ks={ks}: vs quantised float64 {e:.2e}; vs exact float64 {eq:.2e}")
+        assert e < 3e-5, e                     # measured 7.6-8.0e-6 (one flipped e4m3 rounding would show as >= 1e-4)
+        assert eq < 8e-2, eq                   # e4m3: 2^-4 per operand, measured ~3-4e-2
+        # the fused plane statistics describe the stored output
+        sc, sh = torch.empty((n, cout), device=DEV), torch.empty((n, cout), device=DEV)
+        ops.norm_finalize(part, 0, 1e-5, sc, sh, 0)
+        mu, var = got.mean((2, 3)), got.var((2, 3), unbiased=False)
+        assert rel_err(sc.cpu().double(), 1.0 / torch.sqrt(var + 1e-5)) < 2e-5
+        assert rel_err((sh / sc).cpu().double(), -mu) < 2e-4
+        # back in the default mode the same call is fp32-equivalent again
+        if kind == "conv":
+            ops.conv2d(ops.full(g(x)), g(wt), None, ops.full(y))
+            assert rel_err(y.cpu().double(), exact) < 3e-6
+    finally:
+        ops.set_conv_precision("bf16x3")
+
+
+def test_fp8_lazy_affine_and_clamp(S):
+    """fp8 staging with the lazy InstanceNorm affine + LeakyReLU in front of the conversion, and activations beyond the
+    e4m3 range (|8 a| > 448 saturates to +-448 instead of turning into NaN)."""
+    ops, F = S.ops, torch.nn.functional
+    n, cin, cout, h, w = 2, 36, 36, 32, 64
+    x = philox("f8a.x", (n, cin, h, w)) * 2.0
+    x[0, 3, 5, 7], x[1, 20, 9, 40] = 500.0, -300.0                     # outliers: 8 * lrelu(.) far outside +-448
+    sc, sh = philox("f8a.sc", (n, cin), lo=0.5, hi=1.5), philox("f8a.sh", (n, cin))
+    wt = philox("f8a.w", (cout, cin, 3, 3)) * 0.05
+    try:
+        with ops.conv_precision("fp8"):
+            act = torch.empty((n, cin, h, w), device=DEV)
+            ops.apply(ops.full(g(x), g(sc), g(sh), 0.2), ops.full(act))           # the device's own fp32 activation values
+            y = torch.empty((n, cout, h, w), device=DEV)
+            ops.conv2d(ops.full(g(x), g(sc), g(sh), 0.2), g(wt), None, ops.full(y))
+            torch.cuda.synchronize()
+        Sw = _w_scale(wt)
+        want = F.conv2d(_e4m3(act.cpu() * 8.0) / 8.0, _e4m3(wt * Sw) / Sw, padding=1)
+        assert torch.isfinite(y).all()
+        e = rel_err(y.cpu().double(), want)
+        print(f"fp8 lazy affine + clamp: vs quantised float64 {e:.2e}")
+        assert e < 2e-4, e                    # measured 1.8e-5; a last-bit difference in the fp32 affine can flip single e4m3 roundings
+    finally:
+        ops.set_conv_precision("bf16x3")
+
+
+def test_fp8_mode_e2e_psnr_and_train_step(S):
+    """Config 5: the 12-cascade network at 320 x 320 with fp8 e4m3 forward convolutions (fp32 FFT / DC / norms / losses),
+    judged by PSNR against the fp32-equivalent output of the same network, and one 'Rec' optimisation step with
+    cfg.conv_dtype = 'fp8' (forward fp8, data / weight gradients bf16)."""
+    gold = load_golden("e2e_full_320.npz")
+    w = 320
+    img_full, img_aux = S.synth.phantom_pair(1, 1, w, w, seed=1234)
+    pruned = as_t(gold["pruned"])
+    net_R = S.varnet.VarNet(num_cascades=12, sens_chans=8, sens_pools=4, chans=18, pools=4, use_ref=True)
+    _load(S, net_R, 1236)
+    net_R.to(DEV).eval()
+    keep = (~pruned).float().to(DEV)
+    k_samp = S.ops.fft2c(g(img_full), colmask_out=keep)
+    warped = g(as_t(gold["img_warped"]))
+    try:
+        with torch.no_grad():
+            ref = net_R(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32)).cpu()
+            with S.ops.conv_precision("fp8"):
+                rec = net_R(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32)).cpu()
+            with S.ops.conv_precision("bf16"):
+                rec16 = net_R(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32)).cpu()
+        psnr, rel = _psnr(ref, rec), rel_err(rec, ref)
+        print(f"fp8: PSNR vs the fp32-equivalent output {psnr:.1f} dB, rel-L2 {rel:.2e} (bf16: {_psnr(ref, rec16):.1f} dB)")
+        assert torch.isfinite(rec).all()
+        assert psnr > 20.0          # measured 30.2 dB (bf16: 45.8 dB); random-init weights amplify rounding noise through 12 cascades (DESIGN 3.3)
+        f, a_ = S.synth.phantom_pair(2, 3, 48, 80, seed=40)
+
+        def one_step(conv_dtype):
+            cfg = S.base.Config(sparsity=0.25, lr=1e-4, shape=80, coils=3, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                                weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, conv_dtype=conv_dtype,
+                                num_cascades=2, chans=18, sens_chans=8, pools=2, sens_pools=2)
+            net = S.model.CSModel(cfg)
+            net.net_mask.pruned = S.synth.equispaced_pruned(80, 0.25, 0)
+            _load(S, net.net_T, 41)
+            _load(S, net.net_R, 42)
+            net.to(DEV).train()
+            before = [p.detach().clone() for p in net.net_R.parameters()]
+            net.set_input(g(f), g(a_))
+            net.update()
+            assert S.ops.lib().query("san_get_conv_precision") == 3          # update() restores the process-wide mode
+            after = list(net.net_R.parameters())
+            assert all(torch.isfinite(p).all() for p in after) and any(not torch.equal(p, q) for p, q in zip(after, before))
+            return torch.cat([p.grad.flatten() for p in net.net_R.parameters() if p.grad is not None]).double().cpu()
+
+        g8, g32 = one_step("fp8"), one_step("bf16x3")
+        cos = float((g8 * g32).sum() / (g8.norm() * g32.norm()))
+        print(f"fp8 train step: gradient cosine vs the fp32-equivalent step {cos:.4f}")
+        assert cos > 0.8            # the fp8 step descends along the fp32 gradient: measured 0.939
+    finally:
+        S.ops.set_conv_precision("bf16x3")
