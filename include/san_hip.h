@@ -322,24 +322,26 @@ int san_get_conv_precision(void);
  * mantissa bits, three products instead of the six of the bf16 split) when their operands fit fp16's range.  Forward
  * operands (normalised activations, weights) do: pack the weights with mode + 16 and the convolution entry points pick
  * the format up from the packed image.  Gradients (1e-7-sized) need a scale: the `_amax` forms of san_act_bwd /
- * san_act_bwd_coef keep the largest |dy| of everything written to a dy tensor in *amax (one uint32 holding float bits,
- * zeroed by the caller; per-wave maxima into `wave_max`, reduced by one more launch: no atomics, deterministic), and the `_amax` forms of the data / weight gradient read it,
- * multiply dy by 2^(13 - floor(log2 max)) while loading and the result by the inverse.  amax == NULL: the plain forms. */
+ * san_act_bwd_coef keep the largest |dy| of everything written to a dy tensor in an AMAX RECORD: san_amax_record_words()
+ * uint32 values (64 lines of 128 bytes, the float bits of a maximum in the first word of each line), zeroed by the caller once
+ * per step; every workgroup folds its maximum into one of the lines with an integer atomic max (order-independent:
+ * deterministic; 64 lines because same-address atomics serialise), and the `_amax` forms of the data / weight gradient take
+ * the maximum over the lines, multiply dy by 2^(13 - floor(log2 max)) while loading and the result by the inverse.  No
+ * finalising launch, nothing synchronises with the host.  amax == NULL: the plain forms. */
+int san_amax_record_words(void);
 int san_act_bwd_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                      const float* sc, const float* sh, float slope, int mode, float* part,
-                     float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw, void* stream);
+                     float* dy, int d_ctot, int d_coff, void* amax, int n, int c, int hw, void* stream);
 /* san_act_bwd_amax with g(p) + g2_scale * g2(p / 2) as the incoming gradient (g2: [n, g2_ctot, h/2, w/2], c channels from
  * g2_coff): the U-Net encoder's "skip-connection gradient + average-pool adjoint" (varnet.py:118-134 under autograd: the
  * avg_pool2d backward and the gradient accumulation at the block output) without materialising the up-sampled tensor or
- * the sum.  hw = h * w, w % 4 == 0, h even, 16-byte aligned tensors; amax and wave_max may both be NULL. */
+ * the sum.  hw = h * w, w % 4 == 0, h even, 16-byte aligned tensors; amax may be NULL. */
 int san_act_bwd_up_amax(const float* g, int g_ctot, int g_coff, const float* g2, int g2_ctot, int g2_coff, float g2_scale,
                         const float* y, int y_ctot, int y_coff, const float* sc, const float* sh, float slope, int mode,
-                        float* part, float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw,
-                        int w, void* stream);
-int san_act_bwd_amax_scratch_floats(int n, int c);     /* floats of `wave_max` scratch (per-wave maxima, reduced by a final launch) */
+                        float* part, float* dy, int d_ctot, int d_coff, void* amax, int n, int c, int hw, int w, void* stream);
 int san_act_bwd_coef_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                           const float* sc, const float* sh, float slope, const float* coef,
-                          float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw, void* stream);
+                          float* dy, int d_ctot, int d_coff, void* amax, int n, int c, int hw, void* stream);
 int san_conv_bf16x3_dgrad_amax(const float* dy, int dy_ctot, int dy_coff, int cin, const void* w_packed, float* dx, int dx_ctot,
                                int dx_coff, int cout, const void* amax, int n, int h, int w, int ks, void* ws, size_t ws_bytes,
                                void* stream);

@@ -53,7 +53,7 @@ for cin, cout, s, cnt in LAYERS:
         dy = torch.randn(N, cout, s, s, device=dev)
         dya = ops.full(dy)
         if ops.F16_BWD[0]:                        # the two-fp16-part form needs the recorded max |dy| (bits of the float)
-            dya.amax = dy.abs().max().reshape(1).view(torch.int32)
+            dya.amax = ops.amax_record(dy.abs().max())
         t = bench(lambda: ops.conv2d_wgrad(xa, dya, dw, accumulate=True))
     fl = 2.0 * N * s * s * cin * cout * 9
     total += t * cnt

@@ -669,16 +669,8 @@ WgradPlan wgrad_plan(int n, int h, int w, int cin, int cout, int ks, bool allow_
 // bwd_stats writes per-chunk (sum u, sum u*yh) partials; act_bwd sums the chunks itself.
 typedef float bf4 __attribute__((ext_vector_type(4)));
 
-// Largest |dy| of a launch, for the fp16-format gradient kernels (they scale dy by a power of two derived from it).
-// Every wave stores its own maximum (no atomics: 16 k atomic maxima on one address cost ~200 us per launch, and per-CU L1
-// copies of that address go stale, so "look before you leap" did not help); amax_finalize_kernel reduces the <= 32 k wave
-// maxima and merges them into *amax (max is order-independent: deterministic).
-__device__ __forceinline__ void record_wave_max(float* pmax, int wave_slot, float mx) {
-    if (!pmax) return;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) pmax[wave_slot] = mx;
-}
+// Largest |dy| of a launch, for the fp16-format gradient kernels (they scale dy by a power of two derived from it): every
+// workgroup folds its maximum into the tensor's amax record (san_common.h: san_amax_record, 64 atomic lines, no finalising launch).
 
 // Optional second source of the incoming gradient: g(p) += scale * g2(p / 2) with g2 a [n, c2, h/2, w/2] view -- the
 // encoder levels of the U-Net backward, where dL/d(block output) = skip-connection gradient + the average pool's adjoint
@@ -702,21 +694,6 @@ __device__ __forceinline__ bf4 g2_add(bf4 gv, const float* __restrict__ q, int i
     return gv;
 }
 
-__global__ void __launch_bounds__(1024) amax_finalize_kernel(const float* __restrict__ pmax, int count, unsigned* __restrict__ amax) {
-    __shared__ float red[16];
-    float mx = 0.f;
-    for (int i = threadIdx.x; i < count; i += 1024) mx = fmaxf(mx, pmax[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
-        const unsigned bits = __builtin_bit_cast(unsigned, mx);
-        if (bits > *amax) *amax = bits;              // (several launches may feed one slot: keep the largest)
-    }
-}
-
 // InstanceNorm + LeakyReLU backward of a whole (sample, channel) plane in ONE pass: the plane's g and y (<= V float4 per
 // thread each, 512 threads) stay in registers between the two reductions and the write of dy, so g and y are read once
 // instead of twice and there is one launch instead of two.  Planes of up to 512 * 4 * V values (V = 13: 160 x 160).
@@ -724,7 +701,7 @@ template <int V>
 __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
                                                             const float* __restrict__ y, int y_ctot, int y_coff,
                                                             const float* __restrict__ sc, const float* __restrict__ sh, float slope,
-                                                            float* __restrict__ dy, int d_ctot, int d_coff, int hw, float* pmax,
+                                                            float* __restrict__ dy, int d_ctot, int d_coff, int hw, unsigned* amax,
                                                             const G2Src g2) {
     __shared__ float red[16];
     const int ch = blockIdx.x, n = blockIdx.y;
@@ -785,7 +762,7 @@ __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restr
             dp[i] = o;
         }
     }
-    record_wave_max(pmax, (blockIdx.y * gridDim.x + blockIdx.x) * 8 + (threadIdx.x >> 6), mx);
+    san_amax_record<8>(amax, blockIdx.y * gridDim.x + blockIdx.x, mx);
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -848,7 +825,7 @@ bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const floa
 __global__ void __launch_bounds__(kThreads)
 act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
                const float* __restrict__ sc, const float* __restrict__ sh, float slope, const float* __restrict__ part,
-               int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, float* pmax,
+               int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, unsigned* amax,
                const G2Src g2) {
     const int ch = blockIdx.y, n = blockIdx.z;
     const float* q2 = g2.p ? g2.p + ((size_t)(n * g2.ctot + g2.coff + ch)) * (hw >> 2) : nullptr;
@@ -884,7 +861,7 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
             }
             reinterpret_cast<bf4*>(dp)[i] = o;
         }
-        record_wave_max(pmax, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6), mx);
+        san_amax_record<kThreads / 64>(amax, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, mx);
         return;
     }
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads) {
@@ -894,7 +871,7 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
         dp[i] = o;
         mx = fmaxf(mx, fabsf(o));
     }
-    record_wave_max(pmax, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6), mx);
+    san_amax_record<kThreads / 64>(amax, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, mx);
 }
 
 
@@ -1098,7 +1075,7 @@ ssim_bwd_gather_kernel(const float* __restrict__ X, const float* __restrict__ Y,
 __global__ void __launch_bounds__(kThreads)
 act_bwd_coef_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot,
                     int y_coff, const float* __restrict__ sc, const float* __restrict__ sh, float slope,
-                    const float* __restrict__ coef, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, float* pmax) {
+                    const float* __restrict__ coef, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, unsigned* amax) {
     const int ch = blockIdx.y, n = blockIdx.z;
     const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
     const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
@@ -1115,7 +1092,7 @@ act_bwd_coef_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const f
         dp[i] = o;
         mx = fmaxf(mx, fabsf(o));
     }
-    record_wave_max(pmax, ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6), mx);
+    san_amax_record<kThreads / 64>(amax, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, mx);
 }
 
 // bilinear warp backward wrt the sampling grid (zeros padding, align_corners = False):
@@ -1420,7 +1397,7 @@ int san_bwd_stat_tiles(int hw) {
 
 static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
                         const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, int n, int c,
-                        int hw, unsigned* amax, float* pmax, void* stream, const float* g2 = nullptr, int g2_ctot = 0,
+                        int hw, unsigned* amax, void* stream, const float* g2 = nullptr, int g2_ctot = 0,
                         int g2_coff = 0, float g2_scale = 0.f, int w = 0) {
     SAN_CHECK_ARG(g && y && dy, "null pointer");
     G2Src q{nullptr, 0, 0, 0.f, 1, 1.f};
@@ -1432,7 +1409,6 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
         q = G2Src{g2, g2_ctot, g2_coff, g2_scale, w >> 2, 1.f / (float)(w >> 2)};
     }
     SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
-    SAN_CHECK_ARG((amax == nullptr) == (pmax == nullptr), "amax and its wave-maxima scratch come together");
     SAN_CHECK_ARG(mode == 0 || mode == 1, "mode must be 0 (affine) or 1 (instance norm)");
     SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
     SAN_CHECK_ARG(mode == 0 || part != nullptr, "instance-norm backward needs the partial buffer");
@@ -1445,7 +1421,7 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
         // the whole plane fits one workgroup's registers: statistics and gradient in one pass
         const int v = san_cdiv(hw >> 2, 512);
         const dim3 grid(c, n);
-#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw, pmax, q)
+#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw, amax, q)
         if (v <= 1) SAN_ABP(1);
         else if (v <= 2) SAN_ABP(2);
         else if (v <= 4) SAN_ABP(4);
@@ -1453,10 +1429,6 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
         else SAN_ABP(13);
 #undef SAN_ABP
         SAN_LAUNCH_CHECK();
-        if (amax) {
-            hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(1024), 0, s, pmax, c * n * 8, amax);
-            SAN_LAUNCH_CHECK();
-        }
         return SAN_OK;
     }
     if (mode == 1) {
@@ -1470,45 +1442,37 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
     if (bx > cap) bx = (int)cap;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(bx, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc,
-                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw, pmax, q);
+                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw, amax, q);
     SAN_LAUNCH_CHECK();
-    if (amax) {
-        hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(1024), 0, s, pmax, bx * c * n * 4, amax);
-        SAN_LAUNCH_CHECK();
-    }
     return SAN_OK;
 }
 
 int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
                 const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, int n, int c,
                 int hw, void* stream) {
-    return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw, nullptr, nullptr, stream);
+    return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw, nullptr, stream);
 }
 
 int san_act_bwd_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
                      const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, void* amax,
-                     float* wave_max, int n, int c, int hw, void* stream) {
+                     int n, int c, int hw, void* stream) {
     return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw,
-                        static_cast<unsigned*>(amax), wave_max, stream);
+                        static_cast<unsigned*>(amax), stream);
 }
 
 // san_act_bwd_amax with g(p) + g2_scale * g2(p / 2) as the incoming gradient (g2 = a [n, g2_ctot, h/2, w/2] tensor, c channels
 // from g2_coff): the U-Net encoder's "skip gradient + average-pool adjoint" sum without materialising it.  hw = h * w, w % 4
-// == 0, h even, 16-byte aligned tensors; amax / wave_max may both be NULL.
+// == 0, h even, 16-byte aligned tensors; amax may be NULL.
 int san_act_bwd_up_amax(const float* g, int g_ctot, int g_coff, const float* g2, int g2_ctot, int g2_coff, float g2_scale,
                         const float* y, int y_ctot, int y_coff, const float* sc, const float* sh, float slope, int mode,
-                        float* part, float* dy, int d_ctot, int d_coff, void* amax, float* wave_max, int n, int c, int hw,
-                        int w, void* stream) {
+                        float* part, float* dy, int d_ctot, int d_coff, void* amax, int n, int c, int hw, int w, void* stream) {
     SAN_CHECK_ARG(g2 != nullptr, "null second source");
     return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw,
-                        static_cast<unsigned*>(amax), wave_max, stream, g2, g2_ctot, g2_coff, g2_scale, w);
+                        static_cast<unsigned*>(amax), stream, g2, g2_ctot, g2_coff, g2_scale, w);
 }
 
-// floats of scratch the _amax forms need for the per-wave maxima
-int san_act_bwd_amax_scratch_floats(int n, int c) {
-    const long planes = (long)n * c;
-    return (int)((planes > 4096 ? planes : 4096) * 8);
-}
+// uint32 words of one amax record (see san_common.h)
+int san_amax_record_words(void) { return SAN_AMAX_WORDS; }
 
 int san_dc_weight_grad(const float* g, const float* k, const float* k0, const float* mask, float* partial, int planes,
                        int h, int w, void* stream) {
@@ -1589,7 +1553,7 @@ int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, i
 
 static int act_bwd_coef_impl(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
                              const float* sh, float slope, const float* coef, float* dy, int d_ctot, int d_coff, int n, int c,
-                             int hw, unsigned* amax, float* pmax, void* stream) {
+                             int hw, unsigned* amax, void* stream) {
     SAN_CHECK_ARG(g && y && dy && coef, "null pointer");
     SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
     SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
@@ -1601,27 +1565,22 @@ static int act_bwd_coef_impl(const float* g, int g_ctot, int g_coff, const float
     if (bx > cap) bx = (int)cap;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(act_bwd_coef_kernel, dim3(bx, c, n), dim3(kThreads), 0, (hipStream_t)stream, g, g_ctot, g_coff, y,
-                       y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, c, hw, pmax);
+                       y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, c, hw, amax);
     SAN_LAUNCH_CHECK();
-    if (amax) {
-        SAN_CHECK_ARG(pmax != nullptr, "amax needs its wave-maxima scratch");
-        hipLaunchKernelGGL(amax_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pmax, bx * c * n * 4, amax);
-        SAN_LAUNCH_CHECK();
-    }
     return SAN_OK;
 }
 
 int san_act_bwd_coef(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
                      const float* sh, float slope, const float* coef, float* dy, int d_ctot, int d_coff, int n, int c,
                      int hw, void* stream) {
-    return act_bwd_coef_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, n, c, hw, nullptr, nullptr, stream);
+    return act_bwd_coef_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, n, c, hw, nullptr, stream);
 }
 
 int san_act_bwd_coef_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
                           const float* sh, float slope, const float* coef, float* dy, int d_ctot, int d_coff, void* amax,
-                          float* wave_max, int n, int c, int hw, void* stream) {
+                          int n, int c, int hw, void* stream) {
     return act_bwd_coef_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, coef, dy, d_ctot, d_coff, n, c, hw,
-                             static_cast<unsigned*>(amax), wave_max, stream);
+                             static_cast<unsigned*>(amax), stream);
 }
 
 int san_warp_bwd_grid(const float* img, const float* grid, const float* g, float* g_off, int n, int c, int h, int w,

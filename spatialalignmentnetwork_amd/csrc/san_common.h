@@ -61,3 +61,43 @@ __device__ __forceinline__ double san_wave_sum_d(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// "amax record" of a gradient tensor (fp16-format gradients: the data / weight gradient kernels scale dy by a power of two
+// derived from its largest magnitude).  A record is SAN_AMAX_LINES uint32 values, one per 128-byte line (SAN_AMAX_WORDS words
+// in all, zeroed by the caller once per step): the kernels that write dy fold each workgroup's maximum into line
+// (workgroup id mod 64) with one integer atomic max (float bits of a non-negative value: order-independent, deterministic),
+// the readers take the maximum over the 64 lines.  64 separate lines: same-line atomics serialise (~12 ns each; 16 k of them
+// on one address cost ~200 us per launch), 64 lines keep that under a microsecond -- and no finalising launch is needed.
+#define SAN_AMAX_LINES 64
+#define SAN_AMAX_STRIDE 32
+#define SAN_AMAX_WORDS (SAN_AMAX_LINES * SAN_AMAX_STRIDE)
+
+// all threads of the workgroup call this at a point every thread reaches; WAVES = waves per workgroup
+template <int WAVES>
+__device__ __forceinline__ void san_amax_record(unsigned* amax, int wg_linear, float mx) {
+    if (!amax) return;                                  // (workgroup-uniform)
+    __shared__ float san_amax_red[WAVES];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) san_amax_red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) mx = fmaxf(mx, san_amax_red[w]);
+        const unsigned bits = __builtin_bit_cast(unsigned, mx);
+        if (bits != 0u)
+            __hip_atomic_fetch_max(amax + (wg_linear & (SAN_AMAX_LINES - 1)) * SAN_AMAX_STRIDE, bits, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// bits of the tensor's largest magnitude (wave-uniform); every lane of the wave must be active
+__device__ __forceinline__ uint32_t san_amax_read(const uint32_t* amax) {
+    uint32_t b = amax[(threadIdx.x & 63) * SAN_AMAX_STRIDE];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t t = (uint32_t)__shfl_xor((int)b, o, 64);
+        b = b > t ? b : t;
+    }
+    return b;
+}

@@ -33,6 +33,23 @@
 
 void san_wgrad_set_parts(int parts);             // san_wgrad_bf16.hip
 
+// Tuning switches, both measured and left off (scratch/README.md, round 2): HALFX = the K-loop's activation operand reads run
+// half a K-step ahead (two of a wave's four pixel blocks per set: 32 operand registers fewer) -- neutral, the register peak is
+// in the staging phase; PIN4 = register allocation pinned to four resident workgroups per CU for the MB = 2 weights-direct
+// forms -- 18->18 @320^2 -3 %, every multi-chunk layer +8..25 % slower.
+#ifndef SAN_B16_HALFX
+#define SAN_B16_HALFX 0
+#endif
+#ifndef SAN_B16_PIN4
+#define SAN_B16_PIN4 0
+#endif
+#if SAN_B16_PIN4
+// resident workgroups per CU the register allocation aims at: four for the small weights-direct forms (<= 128 registers per lane)
+#define SAN_B16_MINWG(MB, WD, KS, NP) (((WD) && (MB) == 2 && (NP) <= 2) ? 4 : 1)
+#else
+#define SAN_B16_MINWG(MB, WD, KS, NP) 1
+#endif
+
 namespace {
 
 constexpr int kT = 256;
@@ -75,7 +92,7 @@ struct BArgs {
     int fmt;                   // operand format of the packed weights / the staging: 0 = bf16 parts, 1 = two fp16 parts
     unsigned long long* dbg;   // tuning hook (san_conv_bf16x3_debug_timeline): per workgroup 8 x u64 = 100 MHz clock at start, first
                                // chunk staged, epilogue start, end; HW_ID; XCC_ID -- null in normal use
-    const uint32_t* amax;      // fp16 format on a GRADIENT input: bits of max |x| (device scalar); the input is scaled by a power of two
+    const uint32_t* amax;      // fp16 format on a GRADIENT input: the tensor's amax record (san_common.h); the input is scaled by a power of two
     const float* f8_tail;      // fp8 format: {S_w, 1 / S_w} behind the packed image (the per-tensor power-of-two weight scale)
 };
 
@@ -167,7 +184,7 @@ __device__ __forceinline__ uint32_t cvt_f8x4(float f0, float f1, float f2, float
 // epilogue of the transposed form (there a lane must hold the four virtual channels of one real channel).
 // F8: the one-part fp8 e4m3 format (see kF8ActScale).
 template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16, bool F8>
-__global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
+__global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3_kernel(const BArgs a) {
     static_assert(!F16 || NP == 2, "the fp16 format has two parts");
     static_assert(!F8 || (NP == 1 && !F16), "the fp8 format has one part");
     constexpr int kSteps = KS == 3 ? 7 : 1;            // (shadows the 3x3 constant)
@@ -176,8 +193,8 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     constexpr int NWU = kSteps * MB * 3;               // ... = NWU wave-wide pieces (64 lanes x 16 B), one per (step, block, part)
     constexpr int WSL = (NWU + kT / 64 - 1) / (kT / 64); // pieces per wave: wave w moves pieces w, w + 4, ...
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* lds_a = smem;                       // 3 parts x kPartB
-    uint4* lds_w = reinterpret_cast<uint4*>(smem + 3 * kPartB);
+    unsigned char* lds_a = smem;                       // NP parts x kPartB
+    uint4* lds_w = reinterpret_cast<uint4*>(smem + NP * kPartB);
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -247,7 +264,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     // The chunk's lazy affine (24 scales + 24 shifts of this sample) travels through a double-buffered LDS
     // table: thread t < 48 fetches ONE value with the tile and stores it during the previous chunk's staging
     // phase (two barriers before anyone reads it) -- not 64 loads per thread per chunk.
-    float* lds_aff = reinterpret_cast<float*>(smem + 3 * kPartB + (WD ? (size_t)0 : (size_t)WCH * 16));
+    float* lds_aff = reinterpret_cast<float*>(smem + NP * kPartB + (WD ? (size_t)0 : (size_t)WCH * 16));
     const bool has_aff = a.in_scale != nullptr;
     float my_aff = 0.f;
     // gradient input in the fp16 format: x S (S = 2^(13 - floor(log2 max |x|)), exact) rides in the affine table, the
@@ -255,7 +272,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     float inS = 1.f, inInvS = 1.f;
     if constexpr (F16) {
         if (a.amax) {
-            const uint32_t b = *a.amax;
+            const uint32_t b = san_amax_read(a.amax);
             int e = (int)((b >> 23) & 255u);
             if (b != 0u) {
                 e = e < 14 ? 14 : (e > 250 ? 250 : e);
@@ -338,7 +355,11 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
     prefetch(c0);
     for (int chunk = c0; chunk < c1; ++chunk) {
         __syncthreads();
+#if SAN_B16_HALFX
+        Frag wa[2][MB][3], xa[2][2][3];              // activations: two half-sets (2 of a wave's 4 pixel blocks each)
+#else
         Frag wa[2][MB][3], xa[2][4][3];
+#endif
         const uint4* wsrc = a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane;      // (WD)
         auto load_w = [&](int s, Frag (&wq)[MB][3]) {
 #pragma unroll
@@ -399,6 +420,19 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
         }
         // ---- 7 K-steps: (MB + 4) x 3 sixteen-byte operand reads feed 6 x MB x 4 MFMAs; the reads of step s+1
         // are issued before the MFMAs of step s (two operand sets, compile-time indices after unrolling)
+#if SAN_B16_HALFX
+        // half-step hq = 2 s + hb: blocks 2 hb, 2 hb + 1 of K-step s
+        auto load_xh = [&](int hq, Frag (&xq)[2][3]) {
+            const int to = tapoff[hq >> 1];
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if constexpr (F8) xq[bb][p].l[0] = *reinterpret_cast<const long*>(lds_a + boff[2 * (hq & 1) + bb] + to);
+                    else xq[bb][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[2 * (hq & 1) + bb] + to);
+                }
+        };
+#else
         auto load_x = [&](int s, Frag (&xq)[4][3]) {
             const int to = tapoff[s];
 #pragma unroll
@@ -409,10 +443,45 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
                     else xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
                 }
         };
+#endif
         __syncthreads();
         if (chunk == c0) mark(1);
         if (chunk + 1 < c1) prefetch(chunk + 1);
         if constexpr (KS == 3) load_w(0, wa[0]);
+#if SAN_B16_HALFX
+        // operand reads run one HALF-step ahead of the MFMAs (two pixel blocks x NP parts: half the operand registers of a
+        // full-step ring), the weights one step ahead as before
+        load_xh(0, xa[0]);
+#pragma unroll
+        for (int hq = 0; hq < 2 * kSteps; ++hq) {
+            const int s = hq >> 1;
+            if ((hq & 1) == 0 && s + 1 < kSteps) load_w(s + 1, wa[(s + 1) & 1]);
+            if (hq + 1 < 2 * kSteps) load_xh(hq + 1, xa[(hq + 1) & 1]);
+#pragma unroll
+            for (int pw = 0; pw < NP; ++pw)
+#pragma unroll
+                for (int px = 0; px < NP - pw; ++px)
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int bb = 0; bb < 2; ++bb) {
+                            const int b = 2 * (hq & 1) + bb;
+                            Frag& X = xa[hq & 1][bb][px];
+                            Frag& Wv = wa[s & 1][m][pw];
+                            if constexpr (F8) {
+                                if constexpr (SWAP) acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(X.l[0], Wv.l[0], acc[m][b], 0, 0, 0);
+                                else acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(Wv.l[0], X.l[0], acc[m][b], 0, 0, 0);
+                            } else if constexpr (F16) {
+                                if constexpr (SWAP) acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(X.h, Wv.h, acc[m][b], 0, 0, 0);
+                                else acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wv.h, X.h, acc[m][b], 0, 0, 0);
+                            } else if constexpr (SWAP)
+                                acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X.v, Wv.v, acc[m][b], 0, 0, 0);
+                            else
+                                acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Wv.v, X.v, acc[m][b], 0, 0, 0);
+                        }
+        }
+    }
+#else
         load_x(0, xa[0]);
 #pragma unroll
         for (int s = 0; s < kSteps; ++s) {
@@ -449,6 +518,7 @@ __global__ void __launch_bounds__(kT) conv_bf16x3_kernel(const BArgs a) {
 #endif
         }
     }
+#endif
 
     // ------------------------------------------------------------ epilogue
     mark(2);
@@ -985,7 +1055,8 @@ int format_of(const void* packed) {
 
 template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16 = false, bool F8 = false>
 int launch_bfns(const BArgs& a, hipStream_t s) {
-    constexpr size_t lds = 3 * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
+    // (only the parts in use are allocated: 33 KB for the two-fp16-part form, 17 KB for one part -- LDS never limits residency)
+    constexpr size_t lds = NP * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8>),

@@ -82,12 +82,12 @@ __device__ __forceinline__ f4 mma(const Frag& x, const Frag& y, f4 c) {
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(x.h, y.h, c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x.v, y.v, c, 0, 0, 0);
 }
-// S = 2^(13 - floor(log2 max)) and 1 / S from the bits of the tensor's largest magnitude (0 -> 1, 1)
+// S = 2^(13 - floor(log2 max)) and 1 / S from the tensor's amax record (san_common.h; all zero -> 1, 1); whole waves call this
 __device__ __forceinline__ void amax_scale(const uint32_t* amax, float& S, float& invS) {
     S = 1.f;
     invS = 1.f;
     if (amax) {
-        const uint32_t b = *amax;
+        const uint32_t b = san_amax_read(amax);
         int e = (int)((b >> 23) & 255u);
         if (b != 0u) {
             e = e < 14 ? 14 : (e > 250 ? 250 : e);

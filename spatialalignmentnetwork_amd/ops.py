@@ -185,7 +185,7 @@ class Act:
     scale: Optional[torch.Tensor] = None
     shift: Optional[torch.Tensor] = None
     slope: float = 1.0
-    amax: Optional[torch.Tensor] = None     # gradients: int32 [1] holding the float bits of max |value| (see AmaxPool)
+    amax: Optional[torch.Tensor] = None     # gradients: the tensor's amax record (int32 words, see AmaxPool)
 
     @property
     def n(self):
@@ -551,22 +551,31 @@ def _fwd_fmt() -> int:
 
 
 # Gradients on two fp16 parts need a per-tensor power-of-two scale: the kernels that WRITE a dy tensor (san_act_bwd*_amax)
-# keep its largest magnitude in one int32 slot of this pool (integer atomic max of the float bits: deterministic), the data /
+# keep its largest magnitude in one amax record of this pool (64 lines, integer atomic max of the float bits: deterministic), the data /
 # weight gradient kernels that READ it derive the scale from that slot.  CSModel.backward() resets the pool once per step.
 F16_BWD = [os.environ.get("SAN_NO_F16X2_BWD", os.environ.get("SAN_NO_F16X2", "0")) != "1"]
 
 
 class AmaxPool:
+    """Amax records (san_hip.h: san_amax_record_words() int32 words each, 64 atomic lines) handed out one per dy tensor per
+    step; ``reset`` (once per step) zeroes the records the previous step used."""
     SLOTS = 4096
 
     def __init__(self):
         self.buf = {}
         self.idx = 0
+        self.words = None
+
+    def _words(self) -> int:
+        if self.words is None:
+            self.words = int(lib().query("san_amax_record_words"))
+        return self.words
 
     def reset(self, device=None) -> None:
+        used = self.idx * self._words()
         for t in self.buf.values():
-            if device is None or t.device == torch.device(device):
-                t.zero_()
+            if used and (device is None or t.device == torch.device(device)):
+                t[:used].zero_()
         self.idx = 0
 
     def next(self, device) -> Optional[torch.Tensor]:
@@ -574,12 +583,24 @@ class AmaxPool:
             return None
         key = str(device)
         t = self.buf.get(key)
+        w = self._words()
         if t is None:
-            t = self.buf[key] = torch.zeros(self.SLOTS, dtype=torch.int32, device=device)
+            t = self.buf[key] = torch.zeros(self.SLOTS * w, dtype=torch.int32, device=device)
         if self.idx >= self.SLOTS:
             self.reset(device)
         self.idx += 1
-        return t[self.idx - 1:self.idx]
+        return t[(self.idx - 1) * w:self.idx * w]
+
+
+def amax_record(value: torch.Tensor) -> torch.Tensor:
+    """An amax record holding ``value`` (a non-negative float32 scalar tensor on the device) in every line (tests, benches)."""
+    w = int(lib().query("san_amax_record_words"))
+    return value.detach().reshape(1).float().view(torch.int32).repeat(w).contiguous()
+
+
+def amax_value(rec: torch.Tensor) -> float:
+    """The maximum an amax record holds."""
+    return float(rec.view(torch.float32).max().item())
 
 
 AMAX = AmaxPool()
@@ -1073,11 +1094,6 @@ def _conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool 
     _timed("wgrad1x1_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin, "FLOP", lambda: lib().call(fn, *args))
 
 
-def _wave_max(n: int, c: int, device, arena: "Arena") -> torch.Tensor:
-    """scratch of the _amax activation-backward forms (stream-ordered reuse: written and reduced within one C-ABI call)"""
-    return arena.get("amax_waves", (lib().query("san_act_bwd_amax_scratch_floats", n, c),), device, _no_wait=True)
-
-
 def act_bwd_up_ok(y: Act) -> bool:
     """True where act_bwd can take a half-resolution second gradient source (even height, width % 4 == 0)."""
     return (y.h & 1) == 0 and (y.w & 3) == 0 and y.h * y.w // 4 < (1 << 22)
@@ -1097,10 +1113,9 @@ def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_
     dy.amax = AMAX.next(y.buf.device)
     if g2 is not None:
         assert g2.c == y.c and (2 * g2.h, 2 * g2.w) == (y.h, y.w) and act_bwd_up_ok(y)
-        wm = None if dy.amax is None else _wave_max(y.n, y.c, y.buf.device, arena)
         lib().call("san_act_bwd_up_amax", _p(g.buf), g.ctot, g.coff, _p(g2.buf), g2.ctot, g2.coff, float(g2_scale), _p(y.buf),
                    y.ctot, y.coff, _p(y.scale), _p(y.shift), float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf),
-                   dy.ctot, dy.coff, _p(dy.amax), _p(wm), y.n, y.c, hw, y.w, _stream())
+                   dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, y.w, _stream())
         return
     if dy.amax is None:
         lib().call("san_act_bwd", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
@@ -1108,7 +1123,7 @@ def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_
     else:
         lib().call("san_act_bwd_amax", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
                    float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax),
-                   _p(_wave_max(y.n, y.c, y.buf.device, arena)), y.n, y.c, hw, _stream())
+                   y.n, y.c, hw, _stream())
 
 
 def unshuffle2(x: Act, y: Act) -> None:
@@ -1226,7 +1241,7 @@ def act_bwd_coef(g: Act, y: Act, coef: torch.Tensor, dy: Act) -> None:
     else:
         lib().call("san_act_bwd_coef_amax", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
                    float(y.slope), _p(_chk(coef, name="coef")), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax),
-                   _p(_wave_max(y.n, y.c, y.buf.device, GLOBAL_ARENA)), y.n, y.c, y.h * y.w, _stream())
+                   y.n, y.c, y.h * y.w, _stream())
 
 
 def warp_bwd_grid(img: torch.Tensor, grid: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
