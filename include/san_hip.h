@@ -352,6 +352,15 @@ int san_conv1x1_wgrad_bf16x3_amax(const float* x, int x_ctot, int x_coff, int ci
                                   float in_slope, const float* dy, int dy_ctot, int dy_coff, int cout, float* dw, int accumulate,
                                   int transposed, void* scratch, const void* dy_amax, int n, int h, int w, void* stream);
 
+/* Deferred weight-gradient reductions (training step: ~320 reduction launches become ~8).  san_wgrad_defer(1): the bf16x3 /
+ * fp16-part weight-gradient entry points above launch only their main kernel and queue the fixed-order reduction of their
+ * partial tiles (so `scratch` must stay untouched and be private to that call until the flush); san_wgrad_defer_flush(stream)
+ * launches the queued reductions, up to 48 layers per launch.  Flush before queueing a second gradient of the same dw.
+ * Results are bit-identical to the immediate form.  san_wgrad_defer returns the previous setting. */
+int san_wgrad_defer(int on);
+int san_wgrad_defer_pending(void);
+int san_wgrad_defer_flush(void* stream);
+
 /* ------------------------------------------- image-domain cascade boundary */
 
 /* out = (i)fft along H only (ortho: scale 1/sqrt(h)) of interleaved complex [planes, h, w].  k0x = ifft_y(k0) is the

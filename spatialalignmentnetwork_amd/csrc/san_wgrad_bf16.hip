@@ -26,6 +26,8 @@
 #include "san_common.h"
 
 #include <cstdint>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -691,36 +693,74 @@ __global__ void __launch_bounds__(kWT) wgrad1x1_bf16x3_kernel(const W1Args a) {
 // pass 3: dw[co][ci][tap] (+)= sum_pp partial[pp][tap][ci][co], fixed order.  64 consecutive output channels per
 // thread row (coalesced partial reads), the partitions dealt to 4 thread rows whose sums meet in LDS in a fixed order.
 // transposed: dw is [ci][co][tap] (the transposed convolution's weight layout).
-__global__ void __launch_bounds__(256) wgrad_bf16x3_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                                   int P, int cin, int cout, int cin_pad, int cout_pad,
-                                                                   int accumulate, int taps, int transposed) {
+struct RJob {
+    const float* partial;
+    float* dw;
+    int P, cin, cout, cin_pad, cout_pad, accumulate, taps, transposed;
+};
+
+__device__ __forceinline__ void wgrad_reduce_body(const RJob& j, int blk) {
     __shared__ float red[3][64];
     const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + lane;
-    const bool live = e < cout * cin * taps;
+    const int e = blk * 64 + lane;
+    const bool live = e < j.cout * j.cin * j.taps;
     const int ec = live ? e : 0;
-    const int co = ec % cout;
-    const int ci = (ec / cout) % cin;
-    const int tap = ec / (cout * cin);
-    const size_t stride = (size_t)taps * cin_pad * cout_pad;
-    const float* p = partial + ((size_t)tap * cin_pad + ci) * cout_pad + co;
+    const int co = ec % j.cout;
+    const int ci = (ec / j.cout) % j.cin;
+    const int tap = ec / (j.cout * j.cin);
+    const size_t stride = (size_t)j.taps * j.cin_pad * j.cout_pad;
+    const float* p = j.partial + ((size_t)tap * j.cin_pad + ci) * j.cout_pad + co;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int pp = row;
-    for (; pp + 12 < P; pp += 16) {
+    for (; pp + 12 < j.P; pp += 16) {
         s0 += p[(size_t)pp * stride];
         s1 += p[(size_t)(pp + 4) * stride];
         s2 += p[(size_t)(pp + 8) * stride];
         s3 += p[(size_t)(pp + 12) * stride];
     }
-    for (; pp < P; pp += 4) s0 += p[(size_t)pp * stride];
+    for (; pp < j.P; pp += 4) s0 += p[(size_t)pp * stride];
     float s = (s0 + s1) + (s2 + s3);
     if (row > 0) red[row - 1][lane] = s;
     __syncthreads();
     if (row == 0 && live) {
         s = ((s + red[0][lane]) + red[1][lane]) + red[2][lane];
-        float* o = transposed ? dw + ((size_t)ci * cout + co) * taps + tap : dw + ((size_t)co * cin + ci) * taps + tap;
-        *o = accumulate ? *o + s : s;
+        float* o = j.transposed ? j.dw + ((size_t)ci * j.cout + co) * j.taps + tap : j.dw + ((size_t)co * j.cin + ci) * j.taps + tap;
+        *o = j.accumulate ? *o + s : s;
     }
+}
+
+__global__ void __launch_bounds__(256) wgrad_bf16x3_reduce_kernel(const RJob j) { wgrad_reduce_body(j, blockIdx.x); }
+
+// Deferred form: up to kRBatch layers' reductions in ONE launch (san_wgrad_defer / san_wgrad_defer_flush).  The jobs ride in
+// the kernel arguments (no table upload: nothing to copy, capture-safe); block b belongs to the job whose block range holds it.
+constexpr int kRBatch = 48;
+struct RBatch {
+    RJob j[kRBatch];
+    int first[kRBatch + 1];    // first block of each job; first[n] = total
+    int n;
+};
+
+__global__ void __launch_bounds__(256) wgrad_reduce_batch_kernel(const RBatch b) {
+    int k = 0;
+    while (k + 1 < b.n && (int)blockIdx.x >= b.first[k + 1]) ++k;
+    wgrad_reduce_body(b.j[k], (int)blockIdx.x - b.first[k]);
+}
+
+std::mutex g_defer_mu;
+std::vector<RJob> g_defer;
+int g_defer_on = 0;
+
+// the reduction of one weight gradient: now, or (deferred mode) queued for the next san_wgrad_defer_flush
+int reduce_or_defer(const RJob& j, hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        if (g_defer_on) {
+            g_defer.push_back(j);
+            return SAN_OK;
+        }
+    }
+    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(j.cout * j.cin * j.taps, 64)), dim3(256), 0, s, j);
+    return SAN_OK;
 }
 
 struct WBPlan {
@@ -1045,8 +1085,8 @@ static int wgrad3_impl(const float* x, int x_ctot, int x_coff, int cin, const fl
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
     const int count = cout * cin * 9;
-    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 64)), dim3(256), 0, s, partial, dw, p.P, cin, cout,
-                       p.cin_pad, p.cout_pad, accumulate, 9, 0);
+    (void)count;
+    reduce_or_defer(RJob{partial, dw, p.P, cin, cout, p.cin_pad, p.cout_pad, accumulate, 9, 0}, s);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
@@ -1112,8 +1152,8 @@ static int wgrad1_impl(const float* x, int x_ctot, int x_coff, int cin, const fl
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
     const int count = cout * cin;
-    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(count, 64)), dim3(256), 0, s, a.partial, dw, p.P, cin, cout,
-                       p.cin_pad, p.cout_pad, accumulate, 1, transposed);
+    (void)count;
+    reduce_or_defer(RJob{a.partial, dw, p.P, cin, cout, p.cin_pad, p.cout_pad, accumulate, 1, transposed}, s);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
@@ -1147,6 +1187,45 @@ int san_conv1x1_wgrad_bf16x3_amax(const float* x, int x_ctot, int x_coff, int ci
                                   int transposed, void* scratch, const void* dy_amax, int n, int h, int w, void* stream) {
     return wgrad1_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, dy, dy_ctot, dy_coff, cout, dw, accumulate, transposed,
                        scratch, n, h, w, dy_amax, stream);
+}
+
+// Deferred reductions.  While on, the bf16x3 / fp16-part weight-gradient entry points launch only their main kernel and queue
+// the fixed-order reduction of their partial tiles; san_wgrad_defer_flush launches the queued reductions, up to 48 layers per
+// launch (the jobs ride in the kernel arguments).  The caller gives every queued weight gradient its own `scratch` and flushes
+// before a second gradient of the same dw is queued (each dw element is written by exactly one thread of one launch, so the
+// result is bit-identical to the immediate form).  ~320 launches per training step become ~8.
+int san_wgrad_defer(int on) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    const int prev = g_defer_on;
+    g_defer_on = on ? 1 : 0;
+    return prev;
+}
+
+int san_wgrad_defer_pending(void) {
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    return (int)g_defer.size();
+}
+
+int san_wgrad_defer_flush(void* stream) {
+    std::vector<RJob> jobs;
+    {
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        jobs.swap(g_defer);
+    }
+    for (size_t at = 0; at < jobs.size(); at += kRBatch) {
+        RBatch b{};
+        b.n = (int)(jobs.size() - at < (size_t)kRBatch ? jobs.size() - at : (size_t)kRBatch);
+        int total = 0;
+        for (int k = 0; k < b.n; ++k) {
+            b.j[k] = jobs[at + k];
+            b.first[k] = total;
+            total += san_cdiv(b.j[k].cout * b.j[k].cin * b.j[k].taps, 64);
+        }
+        b.first[b.n] = total;
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b);
+        SAN_LAUNCH_CHECK();
+    }
+    return SAN_OK;
 }
 
 }  // extern "C"

@@ -944,8 +944,37 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
 #   * allocator-owned operands get record_stream();
 #   * leaving the context joins the side stream back into the main one (before the all-reduce / optimiser).
 # ---------------------------------------------------------------------------
-_WG = {"stream": None, "main": None, "pool": {}, "busy": {}, "rr": {}}
+_WG = {"stream": None, "main": None, "pool": {}, "busy": {}, "rr": {}, "defer": False, "defer_k": 0, "defer_dw": set()}
 WGRAD_OVERLAP = [os.environ.get("SAN_NO_WGRAD_OVERLAP", "0") != "1"]
+# Deferred weight-gradient reductions (san_wgrad_defer): inside wgrad_overlap the side-stream weight gradients queue the
+# fixed-order reduction of their partial tiles, and one launch reduces up to 48 layers (each with its own scratch copy).
+WGRAD_DEFER = [os.environ.get("SAN_NO_WGRAD_DEFER", "0") != "1"]
+_DEFER_BATCH = 48
+
+
+def wgrad_flush() -> None:
+    """Launch the queued weight-gradient reductions (on the side stream)."""
+    if _WG["defer"] and _WG["defer_k"]:
+        with torch.cuda.stream(_WG["stream"]):
+            lib().call("san_wgrad_defer_flush", _stream())
+    _WG["defer_k"] = 0
+    _WG["defer_dw"].clear()
+
+
+def _wgrad_scratch_tag(dw: torch.Tensor, scratch_tag: str):
+    """(scratch tag, restore) for one matrix-core weight gradient.  Deferred mode (side stream, no caller tag): a scratch copy
+    of its own until the flush; in-line callers (their own tag, main stream) reduce at once."""
+    if not _WG["defer"]:
+        return scratch_tag, None
+    if scratch_tag:
+        lib().query("san_wgrad_defer", 0)
+        return scratch_tag, (lambda: lib().query("san_wgrad_defer", 1))
+    if _WG["defer_k"] >= _DEFER_BATCH or dw.data_ptr() in _WG["defer_dw"]:
+        wgrad_flush()
+    k = _WG["defer_k"]
+    _WG["defer_k"] = k + 1
+    _WG["defer_dw"].add(dw.data_ptr())
+    return f"@{k}", None
 
 
 class wgrad_overlap:
@@ -956,11 +985,19 @@ class wgrad_overlap:
                 _WG["pool"][dev] = torch.cuda.Stream(device=dev)
             _WG["stream"] = _WG["pool"][dev]
             _WG["main"] = torch.cuda.current_stream()
+            if WGRAD_DEFER[0]:
+                lib().query("san_wgrad_defer", 1)
+                _WG["defer"], _WG["defer_k"] = True, 0
+                _WG["defer_dw"].clear()
         return self
 
     def __exit__(self, *exc):
         side = _WG["stream"]
         if side is not None:
+            if _WG["defer"]:
+                wgrad_flush()
+                lib().query("san_wgrad_defer", 0)
+                _WG["defer"] = False
             torch.cuda.current_stream().wait_stream(side)
         _WG["stream"] = None
         _WG["main"] = None
@@ -1058,13 +1095,18 @@ def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = F
     if not lib().query("san_conv_wgrad_bf16x3_supported", x.n, x.h, x.w, cin, cout, ks):
         raise RuntimeError("layer too large for the bf16x3 weight gradient")
     nbytes = lib().query("san_conv_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
+    scratch_tag, restore = _wgrad_scratch_tag(dw, scratch_tag)
     scratch = arena.scratch("wgrad_bf16x3" + scratch_tag, nbytes, x.buf.device)
     f16 = dy.amax is not None and _CONV_NP[0] == 3
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
             cout, _p(_chk(dw, name="dw")), int(accumulate), _p(scratch)) + ((_p(dy.amax),) if f16 else ()) + (x.n, x.h, x.w, _stream())
     fn = "san_conv2d_wgrad_bf16x3_amax" if f16 else "san_conv2d_wgrad_bf16x3"
-    _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call(fn, *args),
-           _conv_abytes(x.n, x.h, x.w, cin, cout, 3), _products(f16))
+    try:
+        _timed("wgrad3x3_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin * 9, "FLOP", lambda: lib().call(fn, *args),
+               _conv_abytes(x.n, x.h, x.w, cin, cout, 3), _products(f16))
+    finally:
+        if restore is not None:
+            restore()
 
 
 def wgrad1x1_bf16x3_ok(x: Act, dy: Act) -> bool:
@@ -1085,13 +1127,18 @@ def _conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool 
     assert dw.numel() == cin * cout and x.buf.shape[2:] == dy.buf.shape[2:]
     assert transposed or (dw.shape[0], dw.shape[1]) == (cout, cin)
     nbytes = lib().query("san_conv1x1_wgrad_bf16x3_scratch_bytes", x.n, x.h, x.w, cin, cout)
+    scratch_tag, restore = _wgrad_scratch_tag(dw, scratch_tag)
     scratch = arena.scratch("wgrad_bf16x3" + scratch_tag, nbytes, x.buf.device)
     f16 = dy.amax is not None and _CONV_NP[0] == 3
     args = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(dy.buf), dy.ctot, dy.coff,
             cout, _p(_chk(dw, name="dw")), int(accumulate), int(transposed), _p(scratch)) + ((_p(dy.amax),) if f16 else ()) + (
             x.n, x.h, x.w, _stream())
     fn = "san_conv1x1_wgrad_bf16x3_amax" if f16 else "san_conv1x1_wgrad_bf16x3"
-    _timed("wgrad1x1_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin, "FLOP", lambda: lib().call(fn, *args))
+    try:
+        _timed("wgrad1x1_bf16x3", 2.0 * x.n * x.h * x.w * cout * cin, "FLOP", lambda: lib().call(fn, *args))
+    finally:
+        if restore is not None:
+            restore()
 
 
 def act_bwd_up_ok(y: Act) -> bool:
