@@ -118,6 +118,65 @@ __device__ __forceinline__ void stockham_pass_reg(const float2* __restrict__ src
     }
 }
 
+// Odd prime radix R in registers, with the conjugate symmetry of the DFT matrix: pairing inputs r and R - r,
+//   a_r = v_r + v_(R-r), b_r = v_r - v_(R-r):  out_q = v_0 + sum_r a_r cos_qr + i sum_r b_r sin_qr,  out_(R-q) = v_0 + sum - i sum
+// (r = 1 .. (R-1)/2; cos / sin of 2 pi k / R with the transform direction come from the twiddle table).  (R-1)^2 real
+// multiply-adds per butterfly instead of the 4 (R-1)^2 of the direct form: the radix-23
+// pass of the 368-wide multi-coil planes (368 = 4 x 4 x 23) went from ~45 % of the kernel's time to a few per cent.
+template <int R>
+__device__ __forceinline__ void stockham_pass_odd(const float2* __restrict__ src, float2* __restrict__ dst,
+                                                  const float2* __restrict__ tw, int n, int Ns, int ns_shift,
+                                                  int lane, int tps) {
+    constexpr int HR = (R - 1) / 2;
+    const int m = n / R;
+    const int ts = n / (Ns * R);
+    const int wr = n / R;
+    for (int j = lane; j < m; j += tps) {
+        int kk, jq;
+        if (ns_shift >= 0) {
+            kk = j & (Ns - 1);
+            jq = j >> ns_shift;
+        } else {
+            jq = j / Ns;
+            kk = j - jq * Ns;
+        }
+        float2 a[HR], b[HR];
+        const float2 v0 = src[j];
+        float2 s0 = v0;
+#pragma unroll
+        for (int r = 0; r < HR; ++r) {
+            const float2 lo = cmul(src[j + (r + 1) * m], tw[(r + 1) * kk * ts]);
+            const float2 hi = cmul(src[j + (R - 1 - r) * m], tw[(R - 1 - r) * kk * ts]);
+            a[r] = cadd(lo, hi);
+            b[r] = csub(lo, hi);
+            s0 = cadd(s0, a[r]);
+        }
+        const int j0 = jq * Ns * R + kk;
+        dst[j0] = s0;
+        // one output pair per iteration, NOT unrolled: with all (R-1)/2 independent sums in flight the radix-23 pass alone
+        // takes > 256 registers (one wave per SIMD for every kernel that inlines it).  The coefficients W^(q r) are
+        // wave-uniform LDS reads of the twiddle table (cos, direction * sin).
+#pragma unroll 1
+        for (int q = 1; q <= HR; ++q) {
+            float2 P = v0, Q = make_float2(0.f, 0.f);
+            int qr = 0;
+#pragma unroll
+            for (int r = 0; r < HR; ++r) {
+                qr += q;
+                if (qr >= R) qr -= R;
+                const float2 t = tw[qr * wr];
+                P.x = fmaf(a[r].x, t.x, P.x);
+                P.y = fmaf(a[r].y, t.x, P.y);
+                Q.x = fmaf(b[r].x, t.y, Q.x);
+                Q.y = fmaf(b[r].y, t.y, Q.y);
+            }
+            // i Q = (-Q.y, Q.x)
+            dst[j0 + q * Ns] = make_float2(P.x - Q.y, P.y + Q.x);
+            dst[j0 + (R - q) * Ns] = make_float2(P.x + Q.y, P.y - Q.x);
+        }
+    }
+}
+
 // Any other (prime) radix: twiddle the R inputs in place (each butterfly owns
 // its inputs), then a direct DFT reading them back from LDS.
 __device__ __forceinline__ void stockham_pass_any(float2* __restrict__ src, float2* __restrict__ dst,
@@ -166,6 +225,10 @@ __device__ __forceinline__ float2* run_fft(const FftArgs& a, float2* bufA, float
                 case 3: stockham_pass_reg<3>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, sgn); break;
                 case 4: stockham_pass_reg<4>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, sgn); break;
                 case 5: stockham_pass_reg<5>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps, sgn); break;
+                case 7: stockham_pass_odd<7>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps); break;
+                case 11: stockham_pass_odd<11>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps); break;
+                case 13: stockham_pass_odd<13>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps); break;
+                case 23: stockham_pass_odd<23>(s, d, tw, a.len, Ns, a.ns_shift[p], lane, tps); break;
                 default: stockham_pass_any(s, d, tw, a.len, R, Ns, a.ns_shift[p], lane, tps); break;
             }
         }
@@ -893,7 +956,7 @@ __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
 
 // Any row length: B rows per workgroup staged in LDS, both transforms with the mixed-radix Stockham passes.
 template <int MODE>
-__global__ void __launch_bounds__(kThreads) dc_rows_kernel(const FftArgs a) {
+__global__ void __launch_bounds__(kThreads, 2) dc_rows_kernel(const FftArgs a) {
     float2* twf = reinterpret_cast<float2*>(smem_raw);
     float2* twi = twf + a.len;
     float2* bufA = twi + a.len;
@@ -913,10 +976,6 @@ __global__ void __launch_bounds__(kThreads) dc_rows_kernel(const FftArgs a) {
         twi[i] = make_float2(t.x, -t.y);
     }
     const float dcw = a.dcw[0];
-    constexpr int kMaxAcc = 24;
-    float2 acc[kMaxAcc];
-#pragma unroll
-    for (int i = 0; i < kMaxAcc; ++i) acc[i] = make_float2(0.f, 0.f);
     float wsum = 0.f;
     // multi-coil launches run one coil per workgroup (blockIdx.z) and leave the coil combination to coil_combine_kernel:
     // a serial coil loop left 80 workgroups with 15 planes each at 640 x 368
@@ -954,10 +1013,12 @@ __global__ void __launch_bounds__(kThreads) dc_rows_kernel(const FftArgs a) {
         float2* other = res == bufA ? bufB : bufA;
         float2* res2 = run_fft(a, res, other, twi, seq, lane, tps, seq < rows, -1.f);
         const size_t rbase = ((size_t)n * 2 * H + h0) * W;
-#pragma unroll
-        for (int it = 0; it < kMaxAcc; ++it) {
-            const int e = tid + it * kThreads;
-            if (e < cnt) {
+        // (single-coil launches write the coil combination here; with several coils every workgroup has ONE coil and
+        // coil_combine_kernel follows: no per-thread accumulators across the transforms)
+        const bool comb = a.out_real && !cpar;
+        const size_t rb = ((size_t)n * a.out_ctot * H + h0) * W;
+        for (int e = tid; e < cnt; e += kThreads) {
+            {
                 const float2 xo = a.in[base + e];
                 const float2 s = a.sens[base + e];
                 float2 v = make_float2(xo.x - dcw * (res2[e].x * a.scale), xo.y - dcw * (res2[e].y * a.scale));
@@ -967,20 +1028,11 @@ __global__ void __launch_bounds__(kThreads) dc_rows_kernel(const FftArgs a) {
                     v.y -= rr * s.y + ri * s.x;
                 }
                 if (a.out) a.out[base + e] = v;
-                const float2 q = MODE == 0 ? v : xo;
-                acc[it].x += q.x * s.x + q.y * s.y;
-                acc[it].y += q.y * s.x - q.x * s.y;
-            }
-        }
-    }
-    if (a.out_real && !cpar) {
-        const size_t rb = ((size_t)n * a.out_ctot * H + h0) * W;
-#pragma unroll
-        for (int it = 0; it < kMaxAcc; ++it) {
-            const int e = tid + it * kThreads;
-            if (e < cnt) {
-                a.out_real[rb + e] = acc[it].x * a.m_scale;
-                a.out_real[rb + e + (size_t)H * W] = acc[it].y * a.m_scale;
+                if (comb) {
+                    const float2 q = MODE == 0 ? v : xo;
+                    a.out_real[rb + e] = (q.x * s.x + q.y * s.y) * a.m_scale;
+                    a.out_real[rb + e + (size_t)H * W] = (q.y * s.x - q.x * s.y) * a.m_scale;
+                }
             }
         }
     }
