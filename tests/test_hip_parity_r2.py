@@ -1003,3 +1003,36 @@ def test_fp8_mode_e2e_psnr_and_train_step(S):
         assert cos > 0.8            # the fp8 step descends along the fp32 gradient: measured 0.939
     finally:
         S.ops.set_conv_precision("bf16x3")
+
+
+def test_deferred_weight_gradient_reductions_are_bit_identical(S):
+    """san_wgrad_defer: inside wgrad_overlap the matrix-core weight gradients queue the fixed-order reduction of their partial
+    tiles and one launch reduces up to 48 layers.  Two 'Rec' steps of an 18-channel model (> 48 queued layers per step, so
+    the automatic flush is exercised) leave bit-identical parameters to the immediate form, and nothing stays queued."""
+    ops = S.ops
+    n, c, h, w = 2, 3, 48, 80
+
+    def run(defer: bool):
+        ops.WGRAD_DEFER[0] = defer
+        try:
+            cfg = S.base.Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                                weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=3, chans=18,
+                                sens_chans=8, pools=2, sens_pools=2)
+            net = S.model.CSModel(cfg)
+            net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+            _load(S, net.net_T, 41)
+            _load(S, net.net_R, 42)
+            net.to(DEV).train()
+            img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+            for _ in range(2):
+                net.set_input(g(img_full), g(img_aux))
+                net.update()
+            torch.cuda.synchronize()
+            assert ops.lib().query("san_wgrad_defer_pending") == 0
+            assert ops.lib().query("san_wgrad_defer", 0) == 0            # update() leaves the mode off
+            return [p.detach().cpu().clone() for m in (net.net_R, net.net_T) for p in m.parameters()]
+        finally:
+            ops.WGRAD_DEFER[0] = True
+
+    a, b = run(True), run(False)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)), "deferred reductions change the result"
