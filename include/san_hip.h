@@ -48,6 +48,7 @@ extern "C" {
 #define SAN_NORM_INSTANCE 0 /* InstanceNorm2d: biased var, eps inside sqrt (varnet.py:141) */
 #define SAN_NORM_GROUP 1    /* NormUnet.norm: unbiased std, eps added to std (varnet.py:257-268) */
 #define SAN_NORM_BATCH 2    /* BatchNorm2d training: batch stats over N,H,W (unet.py:125)        */
+#define SAN_NORM_GROUP_BWD 3 /* GROUP + the two per-plane values its backward needs (aux arrays [2][n][c])  */
 
 const char* san_last_error_string(void);
 int san_version(void);
@@ -184,6 +185,10 @@ int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ct
  *   san_ssim_loss_bwd     : gy = gscale * d(1 - mean SSIM(x, y))/dy; ws: fp32 [3*n*(h-6)*(w-6)]  (ssimloss.py:11-40) */
 int san_dc_weight_grad(const float* g, const float* k, const float* k0, const float* mask, float* partial,
                        int planes, int h, int w, void* stream);
+
+/* dst[0] += scale * sum(part[0 .. count)), accumulated in double in a fixed order by one workgroup: a scalar parameter
+ * gradient that arrives as per-workgroup partials (san_dc_rows backward: dc_weight, varnet.py:523) without host-side glue. */
+int san_partials_add(const float* part, int count, float scale, float* dst, void* stream);
 int san_sens_grad_acc(float* gs, const float* r_planar, const float* t1, const float* x, const float* gm_planar,
                       float sign1, int n, int c, int hw, void* stream);
 /* Image-domain cascade backward (san_dc_rows, backward form): the accumulation of san_sens_grad_acc (skipped when gs is
@@ -248,6 +253,9 @@ int san_tconv2x2_fwd(const float* x, int x_ctot, int x_coff, int cin,
  *   INSTANCE: scale = rsqrt(var_b + eps),        shift = -mean*scale   per (n,c)
  *   GROUP   : scale = 1/(std_unbiased + eps),    shift = -mean*scale   per (n,c);
  *             also aux_a[n,c] = std, aux_b[n,c] = mean (for unnorm)
+ *   GROUP_BWD: GROUP with aux_a, aux_b of [2][n][c]: [0] as above, aux_a[1] = std > 0 ? 1/std : 0 and
+ *             aux_b[1] = -mean * aux_a[1] (the affine that recovers the U-Net output from the un-normalised one: the
+ *             training tape of NormUnet, so that its backward needs no element-wise host glue)
  *   BATCH   : stats over all n; scale = gamma*rsqrt(var_b+eps), shift = beta-mean*scale,
  *             broadcast to every n; aux_a[c] = batch mean, aux_b[c] = unbiased
  *             batch var (for the running-stat update).

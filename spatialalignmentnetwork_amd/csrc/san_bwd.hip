@@ -1268,6 +1268,22 @@ __global__ void normunet_bwd_coefs_kernel(const float* __restrict__ partB, const
     }
 }
 
+// dst[0] += scale * sum(part[0 .. count)): double accumulation in a fixed order (thread-strided sums, then a fixed tree), one
+// workgroup.  The scalar parameter gradients that arrive as per-workgroup partials (dc_weight) without host-side glue.
+__global__ void __launch_bounds__(256) partials_add_kernel(const float* __restrict__ part, int count, float scale,
+                                                           float* __restrict__ dst) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += 256) s += (double)part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dst[0] += (float)((double)scale * red[0]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1646,6 +1662,13 @@ int san_bn_update_running(float* rmean, float* rvar, long long* num_batches_trac
     SAN_CHECK_ARG(c > 0, "bad dims");
     hipLaunchKernelGGL(bn_update_running_kernel, dim3(san_cdiv(c, 64)), dim3(64), 0, (hipStream_t)stream, rmean, rvar,
                        num_batches_tracked, bmean, bvar, c, momentum, var_factor);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_partials_add(const float* part, int count, float scale, float* dst, void* stream) {
+    SAN_CHECK_ARG(part && dst && count > 0, "bad arguments");
+    hipLaunchKernelGGL(partials_add_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, count, scale, dst);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

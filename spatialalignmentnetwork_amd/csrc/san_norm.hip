@@ -80,13 +80,19 @@ norm_finalize_kernel(const float* __restrict__ part, int n, int c, int tiles, in
         const float sc = (float)(1.0 / sqrt(var_b + (double)eps));
         scale[blockIdx.y * sc_ctot + sc_coff + ch] = sc;
         shift[blockIdx.y * sc_ctot + sc_coff + ch] = (float)(-mean) * sc;
-    } else if (mode == SAN_NORM_GROUP) {
+    } else if (mode == SAN_NORM_GROUP || mode == SAN_NORM_GROUP_BWD) {
         const float sd = (float)sqrt(var_u);
         const float sc = 1.f / (sd + eps);
         scale[blockIdx.y * sc_ctot + sc_coff + ch] = sc;
         shift[blockIdx.y * sc_ctot + sc_coff + ch] = (float)(-mean) * sc;
         if (aux_a) aux_a[blockIdx.y * c + ch] = sd;
         if (aux_b) aux_b[blockIdx.y * c + ch] = (float)mean;
+        if (mode == SAN_NORM_GROUP_BWD) {
+            // a constant plane (std == 0) gets no d sigma term (torch's std backward masks it to 0)
+            const float isd = sd > 0.f ? 1.f / sd : 0.f;
+            aux_a[(size_t)n * c + blockIdx.y * c + ch] = isd;
+            aux_b[(size_t)n * c + blockIdx.y * c + ch] = -(float)mean * isd;
+        }
     } else {
         const float g = gamma ? gamma[ch] : 1.f;
         const float bt = beta ? beta[ch] : 0.f;
@@ -339,7 +345,8 @@ int san_norm_finalize(const float* part, int n, int c, int tiles, int mode, floa
                       float* aux_b, void* stream) {
     SAN_CHECK_ARG(part && scale && shift, "null pointer");
     SAN_CHECK_ARG(n > 0 && c > 0 && tiles > 0, "bad dims");
-    SAN_CHECK_ARG(mode >= 0 && mode <= 2, "bad mode");
+    SAN_CHECK_ARG(mode >= 0 && mode <= 3, "bad mode");
+    SAN_CHECK_ARG(mode != SAN_NORM_GROUP_BWD || (aux_a && aux_b), "GROUP_BWD needs both aux arrays ([2][n][c])");
     SAN_CHECK_ARG(check_view(sc_ctot, sc_coff, c), "bad scale/shift view");
     dim3 grid(c, mode == SAN_NORM_BATCH ? 1 : n);
     hipLaunchKernelGGL(norm_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, n, c, tiles, mode, eps,

@@ -16,7 +16,7 @@ import torch
 
 from ._lib import lib
 
-NORM_INSTANCE, NORM_GROUP, NORM_BATCH = 0, 1, 2
+NORM_INSTANCE, NORM_GROUP, NORM_BATCH, NORM_GROUP_BWD = 0, 1, 2, 3
 
 
 class KernelTimer:
@@ -307,14 +307,19 @@ def dc_rows(x: torch.Tensor, sens: torch.Tensor, k0x: Optional[torch.Tensor], ma
 
 
 def dc_rows_bwd(g: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, dc_w: torch.Tensor, g_out: torch.Tensor,
-                h_out: torch.Tensor, dk: torch.Tensor) -> torch.Tensor:
+                h_out: torch.Tensor, dk: torch.Tensor, dcw_grad: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Backward form: g_out = g - dc_w ifft_x(mask fft_x(g)); h_out = -sum_c conj(S_c) g_c (planar: the gradient wrt the
-    regulariser output); returns dL/d(dc_w) as a 0-d tensor (fixed-order sum of the per-workgroup partials)."""
+    regulariser output); dL/d(dc_w) = - (fixed-order sum of the per-workgroup partials): added to ``dcw_grad`` (a 1-element
+    fp32 tensor) on the device, or returned as a 0-d tensor."""
     n, c, h, w = g.shape
     part = GLOBAL_ARENA.get("dcw_part", (lib().query("san_dc_rows_partials", n, c, h, w),), g.device)
     lib().call("san_dc_rows", _p(_creal(g, "g")), _p(_creal(sens, "sens")), _p(None), _p(_chk(mask, name="mask")),
                _p(_chk(dc_w, name="dc_w")), _p(None), _p(_creal(g_out, "g_out")), _p(_chk(h_out, name="h_out")),
                int(h_out.shape[1]), _p(None), _p(_creal(dk, "dk")), _p(part), 1, n, c, h, w, _stream())
+    if dcw_grad is not None:
+        assert dcw_grad.numel() == 1 and dcw_grad.dtype == torch.float32 and dcw_grad.is_contiguous()
+        lib().call("san_partials_add", _p(part), int(part.numel()), -1.0, _p(dcw_grad), _stream())
+        return None
     return -(part.double().sum()).float()
 
 

@@ -358,10 +358,13 @@ class NormUnet(nn.Module):
         un-normalised planar output [B,2,H,W]."""
         b, h, w = xin.n, xin.h, xin.w
         dev = xin.buf.device
-        std = ARENA.get(f"{key}.gn_std", (b, 2), dev)
-        mean = ARENA.get(f"{key}.gn_mean", (b, 2), dev)
+        # [0] = std / mean of the planes (the un-normalisation affine), [1] = guarded 1 / std and -mean / std (the backward's
+        # affine that recovers the U-Net output from the un-normalised one): one launch writes all four
+        std2 = ARENA.get(f"{key}.gn_std", (2, b, 2), dev)
+        mean2 = ARENA.get(f"{key}.gn_mean", (2, b, 2), dev)
+        std, mean = std2[0], mean2[0]
         part = ops.plane_stats(xin.view(0, 2), tag="gn")
-        ops.norm_finalize(part, ops.NORM_GROUP, 1e-6, xin.scale, xin.shift, 0, aux_a=std, aux_b=mean)
+        ops.norm_finalize(part, ops.NORM_GROUP_BWD, 1e-6, xin.scale, xin.shift, 0, aux_a=std2, aux_b=mean2)
         top, left, hp, wp = self.pad_sizes(h, w)
         if (hp, wp) == (h, w):
             self.unet.run(xin, ops.full(out_planar), out_scale=std, out_shift=mean, key=key)
@@ -373,7 +376,7 @@ class NormUnet(nn.Module):
             upad = ARENA.get(f"{key}.nu_upad", (b, 2, hp, wp), dev)
             self.unet.run(xpad, ops.full(upad), key=key)
             ops.window_copy(Act(upad, 0, 2, std, mean, 1.0), ops.full(out_planar), -top, -left)
-        self._tapes[key] = (xin, out_planar, std, mean)
+        self._tapes[key] = (xin, out_planar, std, mean, std2[1], mean2[1])
         return out_planar
 
     def run_bwd(self, g_out: torch.Tensor, key: str, want_ref_grad: bool = False):
@@ -386,14 +389,14 @@ class NormUnet(nn.Module):
             dmu     = sum(g_out)   - sum(g_x^)/(sigma+eps)
             dsigma  = sum(g_out*U) - sum(g_x^ * x^)/(sigma+eps)
             dL/dm   = g_x^/(sigma+eps) + dmu/n + dsigma * (m - mu)/((n-1)*sigma)."""
-        xin, out_planar, std, mean = self._tapes[key]
+        xin, out_planar, std, mean, isd, nshift = self._tapes[key]
         b, h, w, dev = xin.n, xin.h, xin.w, xin.buf.device
         nel = h * w
         g_out = g_out.contiguous()
         # a constant plane (e.g. an all-zero slice) has std == 0: U cannot be recovered from U*0 + mean, and torch's
-        # std backward gives that plane no d sigma term at all (san_normunet_bwd_coefs does the same)
-        isd = torch.where(std > 0, 1.0 / std, torch.zeros_like(std)).contiguous()
-        part_b = ops.plane_dot_part(ops.full(g_out), Act(out_planar, 0, 2, isd, (-mean * isd).contiguous(), 1.0), "nu.b")
+        # std backward gives that plane no d sigma term at all (isd = 0 there, written by the forward's finalisation;
+        # san_normunet_bwd_coefs does the same)
+        part_b = ops.plane_dot_part(ops.full(g_out), Act(out_planar, 0, 2, isd, nshift, 1.0), "nu.b")
         zero_sh = ARENA.get("bwd.zero_sh", tuple(std.shape), dev, zero=True)
         top, left, hp, wp = self.pad_sizes(h, w)
         if (hp, wp) == (h, w):
@@ -575,7 +578,7 @@ class VarNetBlock(nn.Module):
         dev = x.device
         g_r = ARENA.get("bwd.g_r", (n, 2, h, w), dev)
         g_d = torch.empty_like(g_xout)
-        _grad_of(self.dc_weight).add_(ops.dc_rows_bwd(g_xout, sens, mask_f, self.dc_weight.detach(), g_d, g_r, self._dk))
+        ops.dc_rows_bwd(g_xout, sens, mask_f, self.dc_weight.detach(), g_d, g_r, self._dk, dcw_grad=_grad_of(self.dc_weight))
         g_m, g_ref = self.model.run_bwd(g_r, key, want_ref_grad)
         ops.sens_grad_prop(g_sens, r, g_xout, x, g_m, g_d, sens)
         return g_d, g_ref
