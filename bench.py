@@ -27,6 +27,9 @@ Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max ran
                    Every 29th launch of a family is bracketed and run alone (an event pair around each of ~1,700
                    launches per step costs ~6 % of the step and would serialise the two streams).
   roofline_*     : the same for the fused FFT + data-consistency kernels (HBM) and the other conv families.
+                   `event_pair_overhead_us` = the elapsed time of an event pair with nothing in between, measured in
+                   the same run, and `frac_net_of_event_overhead` = frac with that subtracted from the launch time
+                   (a 16 us kernel reads ~19.5 us between its events); `achieved` / `frac` are the RAW event figures.
   cpu_baseline   : the CPU oracle (PyTorch CPU restatement of the reference, same ATen kernels) timed on this box's
                    host cores: the same step incl. torch.optim.AdamW, N = 1 and N = 8, all usable cores and 1 thread.
 """
@@ -223,7 +226,7 @@ def launch_test(args):
         dist.destroy_process_group()
 
 
-def roofline_entry(key, d, dt, steps, pmc, match_profile, products=BF16X3_PRODUCTS):
+def roofline_entry(key, d, dt, steps, pmc, match_profile, products=BF16X3_PRODUCTS, ev_us=None):
     """One roofline object from a KernelTimer family record (see the module docstring for the definitions)."""
     sec = d["ms"] * 1e-3                       # rate over the bracketed launches, applied to all launches
     extra = {}
@@ -256,6 +259,13 @@ def roofline_entry(key, d, dt, steps, pmc, match_profile, products=BF16X3_PRODUC
            "launches": d["launches"], "timed_launches": d["sampled_launches"],
            "avg_launch_us": 1e3 * d["sampled_ms"] / d["sampled_launches"],
            "share_of_step": d["ms"] / (1e3 * dt), **extra}
+    if ev_us is not None:
+        # the event pair's own latency (nothing between the two records, measured in this run) and what the figures would be
+        # without it: rocprofv3's per-kernel durations (profiles/) are the cross-check; `achieved` / `frac` stay the raw ones
+        net = out["avg_launch_us"] - ev_us
+        out["event_pair_overhead_us"] = ev_us
+        if net > 0:
+            out["frac_net_of_event_overhead"] = out["frac"] * out["avg_launch_us"] / net
     return out
 
 
@@ -453,13 +463,14 @@ def main(argv=None):
             for v in pmc.values():
                 v.setdefault("source", f"profiles/{pmc_file}")
             match = args.mode == "train" and (n, h, w, c, args.cascades) == (8, 320, 320, 1, 12)
+            ev_us = ops.KernelTimer.event_pair_overhead_us()
             for key, field in ((dom, "roofline"), ("fft_dc", "roofline_fft_dc"), ("conv3x3", "roofline_conv_fp32"),
                                ("conv3x3_bf16x3", "roofline_conv_bf16x3"), ("wgrad3x3_bf16x3", "roofline_wgrad_bf16x3"),
                                ("wgrad3x3", "roofline_wgrad_fp32")):
                 if key not in tot or (field != "roofline" and key == dom) or tot[key]["sampled_launches"] == 0:
                     continue
                 out[field] = roofline_entry(key, tot[key], dt, args.steps, pmc, match and args.dtype == "fp32",
-                                            {"fp32": 6.0, "bf16x2": 3.0, "bf16": 1.0, "fp8": 1.0}[args.dtype])
+                                            {"fp32": 6.0, "bf16x2": 3.0, "bf16": 1.0, "fp8": 1.0}[args.dtype], ev_us)
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)

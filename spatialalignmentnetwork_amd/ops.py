@@ -60,6 +60,19 @@ class KernelTimer:
             other.wait_stream(cur)
         self.recs.append((name, work, e0, e1))
 
+    @staticmethod
+    def event_pair_overhead_us(pairs: int = 64) -> float:
+        """Median elapsed time of an event pair with NOTHING between the two records, on the current stream: the part of
+        every bracket that is the measurement's own (reported next to the raw figures, never subtracted from them)."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(pairs)]
+        torch.cuda.synchronize()
+        for e0, e1 in evs:
+            e0.record()
+            e1.record()
+        torch.cuda.synchronize()
+        t = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
+        return float(t[len(t) // 2])
+
     def totals(self):
         """{family: launches, work (all launches), sampled_launches / sampled_ms / sampled_work (the bracketed ones),
         ms = sampled_ms scaled by work (the estimate for all launches)}"""
