@@ -472,6 +472,14 @@ int san_conv2d_bf16x3_fwd_ws(const float* x, int x_ctot, int x_coff, int cin,
                              const void* w_packed, const float* bias,
                              float* y, int y_ctot, int y_coff, int cout, float* part_stats,
                              int n, int h, int w, void* ws, size_t ws_bytes, void* stream);
+/* The same for a layer followed by InstanceNorm2d (varnet.py:141,144): when the launch is split over K, its second pass sees
+ * every (sample, channel) plane whole and writes the lazy affine itself -- scale / shift views [n, sc_ctot] at channel offset
+ * sc_coff, exactly san_norm_finalize(SAN_NORM_INSTANCE)'s values -- and sets *finalised = 1 (host int; part_stats untouched):
+ * the caller skips its san_norm_finalize launch.  Otherwise *finalised = 0 and part_stats holds the partials as usual. */
+int san_conv2d_bf16x3_fwd_ws_in(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                                float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff,
+                                int cout, float* part_stats, int n, int h, int w, void* ws, size_t ws_bytes, float* scale,
+                                float* shift, int sc_ctot, int sc_coff, float eps, int* finalised, void* stream);
 
 /* The same kernel as a 1x1 convolution (the alignment net's 1x1 layers, unet.py:64-77; the data gradient of
  * the transposed convolutions): weights packed with the _ks entry points (ks = 1 or 3; the plain ones are

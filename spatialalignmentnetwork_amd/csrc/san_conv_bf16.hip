@@ -762,9 +762,12 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
 // ---------------------------------------------------------------- split-K second pass
 // y[n][c][p] = bias[c] + sum_k ws[k][n][c][p] (fixed order), plus the plane's (count, mean, M2) as statistics tile 0
 // (the other tiles of the caller's partials array get count 0).  One workgroup per (n, c) plane of at most 4096 pixels.
+// fin_scale != null: the plane IS the InstanceNorm statistic, so the lazy affine (scale = rsqrt(var_b + eps), shift = -mean scale:
+// exactly san_norm_finalize's arithmetic on a one-tile record) is written here and no finalising launch follows.
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ ws, int S, const float* __restrict__ bias,
                                                              float* __restrict__ y, int y_ctot, int y_coff, float* __restrict__ part,
-                                                             int tiles, int N, int C, int HW) {
+                                                             int tiles, int N, int C, int HW, float* __restrict__ fin_scale,
+                                                             float* __restrict__ fin_shift, int fin_ctot, int fin_coff, float fin_eps) {
     __shared__ float red[2][4];
     const int nc = blockIdx.x, n = nc / C, c = nc - n * C;
     const float bv = bias ? bias[c] : 0.f;
@@ -785,7 +788,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
             s1 += v[i];
         }
     }
-    if (!part) return;
+    if (!part && !fin_scale) return;
     s1 = san_wave_sum(s1);
     if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s1;
     __syncthreads();
@@ -799,6 +802,15 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
     s2 = san_wave_sum(s2);
     if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = s2;
     __syncthreads();
+    if (fin_scale) {
+        if (threadIdx.x == 0) {
+            const double m2 = (double)((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+            const float sc = (float)(1.0 / sqrt(m2 / (double)HW + (double)fin_eps));
+            fin_scale[n * fin_ctot + fin_coff + c] = sc;
+            fin_shift[n * fin_ctot + fin_coff + c] = (float)(-(double)mean) * sc;
+        }
+        return;
+    }
     float* o = part + (size_t)nc * tiles * 3;
     for (int t = threadIdx.x; t < tiles; t += 256) {
         o[3 * t] = t == 0 ? (float)HW : 0.f;
@@ -1218,7 +1230,8 @@ int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* strea
 static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
                            float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
                            float* part_stats, int n, int h, int w, int ks, void* stream, int shuffle = 0,
-                           void* ws = nullptr, size_t ws_bytes = 0, const void* amax = nullptr) {
+                           void* ws = nullptr, size_t ws_bytes = 0, const void* amax = nullptr, float* fin_scale = nullptr,
+                           float* fin_shift = nullptr, int fin_ctot = 0, int fin_coff = 0, float fin_eps = 0.f) {
     SAN_CHECK_ARG(x && w_packed && y, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + (shuffle ? cout / 4 : cout) <= y_ctot, "bad channel view");
@@ -1298,8 +1311,9 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     if (a.S > 1) {
         const TileGeom tgs = tile_geom(h, w);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(n * cout), dim3(256), 0, s, a.ws, a.S, bias, y, y_ctot, y_coff, part_stats,
-                           tgs.tiles_x * tgs.tiles_y * 4, n, cout, h * w);
+                           tgs.tiles_x * tgs.tiles_y * 4, n, cout, h * w, fin_scale, fin_shift, fin_ctot, fin_coff, fin_eps);
         SAN_LAUNCH_CHECK();
+        return fin_scale ? 1 : SAN_OK;                 // 1: the InstanceNorm affine was finalised in the reduction
     }
     return SAN_OK;
 }
@@ -1362,6 +1376,22 @@ int san_conv2d_bf16x3_fwd_ws(const float* x, int x_ctot, int x_coff, int cin, co
                              int cout, float* part_stats, int n, int h, int w, void* ws, size_t ws_bytes, void* stream) {
     return conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout,
                            part_stats, n, h, w, 3, stream, 0, ws, ws_bytes);
+}
+
+// san_conv2d_bf16x3_fwd_ws for a layer followed by InstanceNorm2d: when the launch is split over K, the second pass sees every
+// (sample, channel) plane whole and writes the lazy affine itself (scale / shift views [n, sc_ctot] at channel offset sc_coff,
+// exactly san_norm_finalize(SAN_NORM_INSTANCE)'s values): *finalised = 1 and part_stats is left untouched -- the caller skips
+// its san_norm_finalize launch.  Otherwise *finalised = 0 and part_stats holds the per-tile partials as usual.
+int san_conv2d_bf16x3_fwd_ws_in(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                                float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff,
+                                int cout, float* part_stats, int n, int h, int w, void* ws, size_t ws_bytes, float* scale,
+                                float* shift, int sc_ctot, int sc_coff, float eps, int* finalised, void* stream) {
+    SAN_CHECK_ARG(scale && shift && finalised && part_stats, "null pointer");
+    SAN_CHECK_ARG(sc_coff >= 0 && sc_coff + cout <= sc_ctot, "bad scale/shift view");
+    const int rc = conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout,
+                                   part_stats, n, h, w, 3, stream, 0, ws, ws_bytes, nullptr, scale, shift, sc_ctot, sc_coff, eps);
+    *finalised = rc == 1 ? 1 : 0;
+    return rc == 1 ? SAN_OK : rc;
 }
 
 // Data gradient on fp16-format weights (packed with mode 2 + 16): x = dy [n, cout_fwd, h, w] materialised, amax = device

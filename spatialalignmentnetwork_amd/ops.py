@@ -668,26 +668,37 @@ def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     return PACKS.get(w, 1 if transposed else 0)
 
 
-def _bf16x3_launch(ks: int, bargs, n: int, h: int, w: int, cin: int, cout: int, device, arena: "Arena") -> None:
+def _bf16x3_launch(ks: int, bargs, n: int, h: int, w: int, cin: int, cout: int, device, arena: "Arena", fin=None) -> bool:
     """bargs = the arguments of san_conv2d_bf16x3_fwd (stream last).  3x3 layers that the library wants to split over K
-    (deep K, few tiles: san_conv_bf16x3_ws_bytes > 0) get the scratch for the partial outputs."""
+    (deep K, few tiles: san_conv_bf16x3_ws_bytes > 0) get the scratch for the partial outputs.  fin = (scale, shift, coff,
+    eps) of a following InstanceNorm: a split launch finalises the lazy affine in its reduction pass (returns True)."""
     if ks != 3:
         lib().call("san_conv1x1_bf16x3_fwd", *bargs)
-        return
+        return False
     nbytes = lib().query("san_conv_bf16x3_ws_bytes", n, h, w, cin, cout, 3)
     if nbytes == 0:
         lib().call("san_conv2d_bf16x3_fwd", *bargs)
-        return
+        return False
     ws = arena.scratch("b16_splitk", nbytes, device)
+    if fin is not None and bargs[13] is not None:
+        scale, shift, coff, eps = fin
+        done = ctypes.c_int(0)
+        lib().call("san_conv2d_bf16x3_fwd_ws_in", *bargs[:-1], _p(ws), nbytes, _p(scale), _p(shift), int(scale.shape[1]), int(coff),
+                   float(eps), ctypes.c_void_p(ctypes.addressof(done)), bargs[-1])
+        return bool(done.value)
     lib().call("san_conv2d_bf16x3_fwd_ws", *bargs[:-1], _p(ws), nbytes, bargs[-1])
+    return False
 
 
 def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: bool = False,
            out_scale: Optional[torch.Tensor] = None, out_shift: Optional[torch.Tensor] = None,
-           arena: Arena = GLOBAL_ARENA, tag: str = "", grad_input: bool = False) -> Optional[torch.Tensor]:
+           arena: Arena = GLOBAL_ARENA, tag: str = "", grad_input: bool = False,
+           instance_norm_eps: Optional[float] = None) -> Optional[torch.Tensor]:
     """y.buf[:, y.coff:y.coff+cout] = conv(T(x)) (+bias).  Returns the per-tile
     statistics partials [N, cout, tiles, 3] when ``stats``.  ``grad_input``: x is a gradient (arbitrary magnitude):
-    keep the bf16 operand split, whose exponent range is fp32's."""
+    keep the bf16 operand split, whose exponent range is fp32's.  ``instance_norm_eps``: the layer is followed by
+    InstanceNorm2d on y (y.scale / y.shift): where the launch can finalise that affine itself (split-K layers) it does and
+    None is returned -- the caller runs norm_finalize only on a returned tensor."""
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert cin == x.c and cout == y.c, (cin, x.c, cout, y.c)
     assert x.buf.shape[2:] == y.buf.shape[2:]
@@ -710,10 +721,15 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
             part = arena.get("part" + tag, (n, cout, lib().query("san_conv_bf16x3_stat_tiles", n, h, w), 3), x.buf.device)
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
                  y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
+        fin = (y.scale, y.shift, y.coff, instance_norm_eps) if (instance_norm_eps is not None and stats and y.scale is not None) else None
+        done = [False]
+
+        def _go():
+            done[0] = _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena, fin)
+
         _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
-               lambda: _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena), _conv_abytes(n, h, w, cin, cout, ks),
-               _products(fmt != 0))
-        return part
+               _go, _conv_abytes(n, h, w, cin, cout, ks), _products(fmt != 0))
+        return None if done[0] else part
     wp = packed_weight(weight)
     if stats:
         tiles = lib().query("san_conv_stat_tiles", n, h, w, cin, cout, ks)

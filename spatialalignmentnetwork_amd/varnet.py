@@ -46,10 +46,13 @@ class ConvBlock(nn.Module):
 
     def run(self, x: Act, mid: Act, out: Act, tag: str) -> Act:
         """x -> mid (raw) -> out (raw); fills the scale/shift of mid and out."""
-        part = ops.conv2d(x, self.layers[0].weight, None, mid, stats=True, tag=tag)
-        ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, mid.scale, mid.shift, mid.coff)
-        part = ops.conv2d(mid, self.layers[3].weight, None, out, stats=True, tag=tag)
-        ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
+        # (split-K layers -- deep K on small planes -- finalise the InstanceNorm affine in their reduction pass: None)
+        part = ops.conv2d(x, self.layers[0].weight, None, mid, stats=True, tag=tag, instance_norm_eps=IN_EPS)
+        if part is not None:
+            ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, mid.scale, mid.shift, mid.coff)
+        part = ops.conv2d(mid, self.layers[3].weight, None, out, stats=True, tag=tag, instance_norm_eps=IN_EPS)
+        if part is not None:
+            ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
         return out
 
     def run_bwd(self, g_out: Act, x: Act, mid: Act, out: Act, g_in: Optional[Act], g_pooled: Optional[Act] = None) -> None:
