@@ -54,6 +54,7 @@ class SanLibrary:
             raise RuntimeError(
                 f"{path} is missing: build it with `python -m spatialalignmentnetwork_amd.build` "
                 "(there is no CPU or PyTorch fallback for the hot path)")
+        self._memo = {}
         self._dll = ctypes.CDLL(path)
         self.protos = parse_header()
         for name, (restype, argtypes) in self.protos.items():
@@ -68,8 +69,14 @@ class SanLibrary:
     def last_error(self) -> str:
         return self._san_last_error_string().decode()
 
+    # size / eligibility / geometry queries are pure functions of their integer arguments (and of the tuning hooks, whose
+    # setters clear the cache): memoised, ~2,800 of them per training step otherwise cross ctypes
+    _STATEFUL = frozenset({"san_get_conv_precision", "san_wgrad_defer", "san_wgrad_defer_pending", "san_version"})
+
     def call(self, name: str, *args):
         """Call an int-returning entry point; raise RuntimeError on failure."""
+        if name.startswith("san_set_") or name.endswith("_set_tuning"):
+            self._memo.clear()
         rc = getattr(self, "_" + name)(*args)
         if rc != 0:
             kind = "argument error" if rc < 0 else "hipError_t"
@@ -77,7 +84,16 @@ class SanLibrary:
 
     def query(self, name: str, *args):
         """Call a size/count query (returns its value)."""
-        return getattr(self, "_" + name)(*args)
+        if name in self._STATEFUL:
+            return getattr(self, "_" + name)(*args)
+        key = (name, args)
+        try:
+            return self._memo[key]
+        except KeyError:
+            v = self._memo[key] = getattr(self, "_" + name)(*args)
+            return v
+        except TypeError:                       # an unhashable argument (a ctypes object): not a geometry query
+            return getattr(self, "_" + name)(*args)
 
 
 _LIB = None

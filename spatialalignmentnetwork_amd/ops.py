@@ -48,14 +48,14 @@ class KernelTimer:
         e1 = torch.cuda.Event(enable_timing=True)
         # inside wgrad_overlap two streams share the GPU: a bracketed launch is run alone (the other stream is joined
         # before and held until after it), so that the time is the kernel's own and not the contention's
-        side, cur, other = _WG["stream"], None, None
+        side, other = _WG["stream"], None
+        cur = _launch_stream()
         if side is not None:
-            cur = torch.cuda.current_stream()
             other = _WG["main"] if cur == side else side
             cur.wait_stream(other)
-        e0.record()
+        e0.record(cur)
         fn()
-        e1.record()
+        e1.record(cur)
         if other is not None:
             other.wait_stream(cur)
         self.recs.append((name, work, e0, e1))
@@ -112,14 +112,29 @@ def _conv_abytes(n, h, w, cin, cout, ks):
     return 4.0 * (n * h * w * (cin + cout) + cout * cin * ks * ks)
 
 
-def _stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+# Raw handle of the stream the next launch goes to.  torch.cuda.current_stream() resolves the device through several Python
+# layers (~3 us; ~2,500 launches per training step), the two C calls below take ~0.3 us.  _STREAM_OVERRIDE: the weight-gradient
+# side stream while _on_side_stream runs a launch there (its handle is passed to the C ABI directly instead of switching
+# torch's current stream around every weight gradient).
+_STREAM_OVERRIDE = [None]
 
 
-def _p(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
-    if t is None:
-        return ctypes.c_void_p(0)
-    return ctypes.c_void_p(t.data_ptr())
+def _stream() -> int:
+    ov = _STREAM_OVERRIDE[0]
+    if ov is not None:
+        return ov.cuda_stream
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
+def _launch_stream() -> "torch.cuda.Stream":
+    """The stream object launches currently go to (the side stream inside _on_side_stream, else torch's current stream)."""
+    return _STREAM_OVERRIDE[0] if _STREAM_OVERRIDE[0] is not None else torch.cuda.current_stream()
+
+
+def _p(t: Optional[torch.Tensor]):
+    """Device pointer argument of a C-ABI call: the address as a plain int (ctypes converts it for the c_void_p parameter;
+    ~13,000 of these per training step, a c_void_p object each was measurable), None -> NULL."""
+    return None if t is None else t.data_ptr()
 
 
 def _chk(t: torch.Tensor, dtype=torch.float32, name: str = "tensor") -> torch.Tensor:
@@ -1077,12 +1092,15 @@ def _on_side_stream(dy: Act, x: Act, fn) -> None:
     if side is None:
         fn()
         return
-    main = torch.cuda.current_stream()
+    main = _WG["main"]
     side.wait_stream(main)                      # the operands' producers are queued on main up to here
-    with torch.cuda.stream(side):
+    _STREAM_OVERRIDE[0] = side                  # (launches take the side stream's handle; torch's current stream stays put)
+    try:
         fn()
-        ev = torch.cuda.Event()
-        ev.record(side)
+    finally:
+        _STREAM_OVERRIDE[0] = None
+    ev = torch.cuda.Event()
+    ev.record(side)
     _WG["busy"][dy.buf.data_ptr()] = ev
     dy.buf.record_stream(side)
     x.buf.record_stream(side)
