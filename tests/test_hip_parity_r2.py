@@ -1036,3 +1036,63 @@ def test_deferred_weight_gradient_reductions_are_bit_identical(S):
 
     a, b = run(True), run(False)
     assert all(torch.equal(x, y) for x, y in zip(a, b)), "deferred reductions change the result"
+
+
+# ------------------------------------------------------------------ late round-2 entry points
+def test_group_norm_backward_aux_and_partials_add(S):
+    """SAN_NORM_GROUP_BWD: the NormUnet statistics launch also writes the two per-plane values its backward needs (guarded
+    1 / std and -mean / std; 0 for a constant plane, as torch's std backward masks it), and san_partials_add accumulates a
+    scalar gradient from per-workgroup partials in double."""
+    ops = S.ops
+    n, h, w = 3, 40, 56
+    x = philox("gnb.x", (n, 2, h, w)) * 2.0 + 0.5
+    x[1, 0] = 0.75                                        # a constant plane: std == 0
+    part = ops.plane_stats(ops.full(g(x)), tag="gnb")
+    sc, sh = torch.empty((n, 2), device=DEV), torch.empty((n, 2), device=DEV)
+    std2, mean2 = torch.empty((2, n, 2), device=DEV), torch.empty((2, n, 2), device=DEV)
+    ops.norm_finalize(part, ops.NORM_GROUP_BWD, 1e-6, sc, sh, 0, aux_a=std2, aux_b=mean2)
+    xd = x.double()
+    std, mean = xd.std((2, 3)), xd.mean((2, 3))
+    assert rel_err(std2[0].cpu().double(), std) < 1e-6 and rel_err(mean2[0].cpu().double(), mean) < 1e-6
+    isd = torch.where(std > 1e-12, 1.0 / std.clamp_min(1e-30), torch.zeros_like(std))
+    assert std2[0, 1, 0].item() == 0.0 and std2[1, 1, 0].item() == 0.0 and mean2[1, 1, 0].item() == 0.0
+    assert rel_err(std2[1].cpu().double(), isd) < 1e-6 and rel_err(mean2[1].cpu().double(), -mean * isd) < 1e-6
+    assert rel_err(sc.cpu().double(), 1.0 / (std + 1e-6)) < 1e-6
+    # partials -> scalar gradient
+    p = philox("gnb.p", (641,)) * 3.0
+    dst = torch.full((1,), 0.25, device=DEV)
+    ops.lib().call("san_partials_add", ops._p(g(p)), 641, -1.0, ops._p(dst), ops._stream())
+    torch.cuda.synchronize()
+    assert abs(dst.item() - (0.25 - p.double().sum().item())) < 1e-5
+
+
+def test_splitk_instance_norm_finalised_in_the_reduction_is_bit_identical(S):
+    """A split-K convolution followed by InstanceNorm writes the lazy affine in its reduction pass
+    (san_conv2d_bf16x3_fwd_ws_in): same bits as the separate san_norm_finalize launch on the partials it replaces; a layer
+    that is not split still returns its partials."""
+    ops = S.ops
+    n, cin, cout, h, w = 2, 288, 288, 20, 20
+    x, wt = philox("skin.x", (n, cin, h, w)), philox("skin.w", (cout, cin, 3, 3)) * 0.03
+    assert ops.lib().query("san_conv_bf16x3_ws_bytes", n, h, w, cin, cout, 3) > 0           # this shape is split over K
+
+    def run(eps):
+        y = ops.Act(torch.empty((n, cout, h, w), device=DEV), 0, cout, torch.zeros((n, cout), device=DEV),
+                    torch.zeros((n, cout), device=DEV), 0.2)
+        part = ops.conv2d(ops.full(g(x)), g(wt), None, y, stats=True, instance_norm_eps=eps)
+        if eps is None:
+            assert part is not None
+            ops.norm_finalize(part, ops.NORM_INSTANCE, 1e-5, y.scale, y.shift, 0)
+        else:
+            assert part is None                                                              # finalised in the reduction
+        torch.cuda.synchronize()
+        return y.buf.cpu(), y.scale.cpu(), y.shift.cpu()
+
+    ya, sa, ha = run(None)
+    yb, sb, hb = run(1e-5)
+    assert torch.equal(ya, yb) and torch.equal(sa, sb) and torch.equal(ha, hb)
+    yd = ya.double()
+    assert rel_err(sa.double(), 1.0 / torch.sqrt(yd.var((2, 3), unbiased=False) + 1e-5)) < 1e-5
+    # not split: 18 -> 18 at 64 x 64 keeps the partials + finalising launch
+    x2, w2 = philox("skin.x2", (2, 18, 64, 64)), philox("skin.w2", (18, 18, 3, 3)) * 0.1
+    y2 = ops.Act(torch.empty((2, 18, 64, 64), device=DEV), 0, 18, torch.zeros((2, 18), device=DEV), torch.zeros((2, 18), device=DEV), 0.2)
+    assert ops.conv2d(ops.full(g(x2)), g(w2), None, y2, stats=True, instance_norm_eps=1e-5) is not None
