@@ -202,6 +202,12 @@ int san_rss_bwd(const float* x, const float* y, const float* g, float* gx, int n
                 void* stream);
 int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, int n, int h, int w, float* ws,
                       void* stream);
+/* The same with the upstream gradient also taken from device memory (gscale_dev: fp32 [1] or NULL): the scale
+ * -(gscale * gscale_dev[0]) / (n (h-6) (w-6)) is formed inside the kernel, so autograd's grad_output never visits the host and
+ * (gscale = w, NULL) gives the same bits as (gscale = 1, gscale_dev -> w).  SSIM is symmetric in its arguments: the
+ * gradient wrt x is this call with x and y exchanged.  Replaces autograd through ssimloss.py:11-40. */
+int san_ssim_loss_bwd_dev(const float* x, const float* y, float* gy, float gscale, const float* gscale_dev, int n, int h,
+                          int w, float* ws, void* stream);
 
 /* san_act_bwd_coef: dy = sc*(u - m1 - (p*yh + q)*m2) with coef[n, c, 4] = (m1, m2, p, q) given by
  *   the caller (BatchNorm training backward: statistics over N,H,W reduced on the host from
@@ -234,6 +240,9 @@ int san_warp_bwd_grid(const float* img, const float* grid, const float* g, float
                       int n, int c, int h, int w, void* stream);
 int san_gradient_loss_bwd(const float* offset, float* g, float gscale, int accumulate, int n, int h, int w,
                           void* stream);
+/* The same with the upstream gradient also taken from device memory (see san_ssim_loss_bwd_dev). */
+int san_gradient_loss_bwd_dev(const float* offset, float* g, float gscale, const float* gscale_dev, int accumulate, int n,
+                              int h, int w, void* stream);
 
 /* ConvTranspose2d 2x2 stride 2, no bias: y [n, cout, 2h, 2w].
  * w_packed from san_conv_pack_weights(..., ks=2, transposed=1).
@@ -405,6 +414,11 @@ int san_warp_fwd(const float* img, const float* offset, float* out, float* grid_
 /* Generic sampler: explicit NHWC grid [n, ho, wo, 2]. */
 int san_grid_sample_fwd(const float* img, const float* grid, float* out,
                         int n, int c, int h, int w, int ho, int wo, int padding, void* stream);
+/* Its gradient wrt the IMAGE (zeros padding): gimg [n,c,h,w] = scatter of g [n,c,ho,wo] over the four texels each output
+ * read (gimg is zeroed here; float atomics -- the only ones in the library; the training step never asks for this,
+ * autograd callers of SpatialTransformer.warp with img.requires_grad do; cross.py:32-34). */
+int san_grid_sample_bwd_img(const float* grid, const float* g, float* gimg,
+                            int n, int c, int h, int w, int ho, int wo, void* stream);
 
 /* The same sampler on interleaved complex planes (img, out: [n,c,h,w] float2): real and imaginary
  * parts sampled with one grid, as augment.py:62-63 does with two grid_sample calls. */
@@ -428,10 +442,21 @@ int san_ssim_loss_fwd(const float* x, const float* y, float* loss, int n, int h,
 int san_lncc_loss_fwd(const float* i, const float* j, float* loss, int n, int h, int w, int win,
                       float* ws, void* stream);
 
+/* Backward of san_lncc_loss_fwd (replaces autograd through lnccloss.py:7-56): gi = gscale [* gscale_dev[0]] * d loss / d i,
+ * gj alike (either may be NULL; accumulate != 0 adds to what they hold).  Two launches (window coefficients, LDS-tiled
+ * gather), no float atomics.  ws: fp32 [san_lncc_bwd_workspace_floats(n, h, w)] = five coefficient planes. */
+size_t san_lncc_bwd_workspace_floats(int n, int h, int w);
+int san_lncc_loss_bwd(const float* i, const float* j, float* gi, float* gj, float gscale, const float* gscale_dev,
+                      int accumulate, int n, int h, int w, int win, float* ws, void* stream);
+
 /* y [planes, h/2, w/2] = avg_pool2(conv2d(x, kern[ksize x ksize], zero pad ksize/2)):
  * the Gaussian(sigma=3, 13 taps) + 2x average-pool step between the scales of
  * ms_lncc_loss (lnccloss.py:58-65, miloss.py:6-24).  kern: device fp32 [ksize*ksize]. */
 int san_smooth_pool_fwd(const float* x, const float* kern, float* y, int planes, int h, int w, int ksize,
+                        void* stream);
+/* Its adjoint: gx [planes, h, w] (+)= d/dx of <gy, smooth_pool(x)> (the chain between the scales of ms_lncc_loss,
+ * lnccloss.py:58-65). */
+int san_smooth_pool_bwd(const float* gy, const float* kern, float* gx, int accumulate, int planes, int h, int w, int ksize,
                         void* stream);
 
 /* loss[0] = (mean(dW^2) + mean(dH^2))/2 of an offset field given as NCHW

@@ -26,14 +26,23 @@ class SpatialTransformer(torch.nn.Module):
 
     def forward(self, moving, fixed, features=None):
         """Returns (offset [N,H,W,2], grid [N,H,W,2]) like cross.py:23-30.  The
-        offset is a permuted view of the head's NCHW output, as in the reference."""
+        offset is a permuted view of the head's NCHW output, as in the reference.  With autograd recording both carry
+        a ``grad_fn`` (autograd._AlignFn) whose backward is ``SpatialTransformer.backward``."""
+        from . import autograd
+        with ops.use_arena(ops.owner_arena(self), outer_only=True):
+            offset_nchw, grid = autograd.align_forward(self, moving, fixed)
+        return offset_nchw.permute(0, 2, 3, 1), grid
+
+    def _forward_impl(self, moving, fixed, retain: bool):
+        moving, fixed = moving.detach(), fixed.detach()
+        self._fwd_id = getattr(self, "_fwd_id", 0) + 1
         n, c, h, w = moving.shape
         dev = moving.device
         xin = Act(ARENA.get("align.in", (n, 2 * c, h, w), dev), 0, 2 * c)
         ops.apply(ops.full(moving.contiguous()), xin.view(0, c))      # torch.cat([moving, fixed], 1)
         ops.apply(ops.full(fixed.contiguous()), xin.view(c, c))
         feat = Act(ARENA.get("align.feat", (n, 32, h, w), dev), 0, 32, None, None, 0.01)   # LeakyReLU read lazily
-        self.net[0].run(xin, feat)
+        self.net[0].run(xin, feat, retain=retain)
         head = self.net[2]
         offset_nchw = torch.empty((n, 2, h, w), device=dev)
         ops.conv2d(feat, head.weight, head.bias, ops.full(offset_nchw))
@@ -41,13 +50,17 @@ class SpatialTransformer(torch.nn.Module):
         # grid = affine_grid(identity) + offset (cross.py:24-29): c == 0 asks the warp kernel for the grid only
         ops.lib().call("san_warp_fwd", ops._p(None), ops._p(offset_nchw), ops._p(None), ops._p(grid), n, 0, h, w, 0,
                        ops._stream())
-        self._last_offset_nchw = offset_nchw
+        self._last_offset_nchw = offset_nchw.detach()
         self._feat = feat
-        return offset_nchw.permute(0, 2, 3, 1), grid
+        return offset_nchw, grid
 
     def backward(self, g_offset_nchw: torch.Tensor) -> None:
         """dL/d(offset) (NCHW [N,2,H,W]: the sum of the warp's grid gradient and the smoothness
         term) -> gradients of every alignment-network parameter (training-mode forward required)."""
+        with ops.use_arena(ops.owner_arena(self), outer_only=True), ops.backward_scope(g_offset_nchw.device):
+            self._backward_impl(g_offset_nchw)
+
+    def _backward_impl(self, g_offset_nchw: torch.Tensor) -> None:
         from .unet import _grad_of
         head, feat = self.net[2], self._feat
         dy = ops.full(g_offset_nchw.contiguous())
@@ -59,5 +72,7 @@ class SpatialTransformer(torch.nn.Module):
         self.net[0].run_bwd(feat, g_feat)
 
     def warp(self, img, grid, interp=False):
-        """Bilinear, zeros padding, align_corners=False; inputs forced to fp32 (cross.py:32-38)."""
-        return ops.grid_sample(img.float().contiguous(), grid.float().contiguous())
+        """Bilinear, zeros padding, align_corners=False; inputs forced to fp32 (cross.py:32-38).  Differentiable wrt the
+        grid (and, with float atomics, the image) through autograd._WarpFn."""
+        from . import autograd
+        return autograd.warp(img.float(), grid.float())

@@ -1051,8 +1051,10 @@ ssim_bwd_coef_kernel(const float* __restrict__ X, const float* __restrict__ Y, f
 // stage 2: g_Y[q] = scale/49 * sum_{windows p containing q} (d_uy[p] + 2 Y[q] d_uyy[p] + X[q] d_uxy[p])
 __global__ void __launch_bounds__(kThreads)
 ssim_bwd_gather_kernel(const float* __restrict__ X, const float* __restrict__ Y, const float* __restrict__ coef,
-                       float* __restrict__ gY, int N, int H, int W, int OH, int OW, float scale) {
+                       float* __restrict__ gY, int N, int H, int W, int OH, int OW, float num, const float* __restrict__ num_dev,
+                       float denom) {
     const int n = blockIdx.y;
+    const float scale = -(num * (num_dev ? num_dev[0] : 1.f)) / denom;       // loss = 1 - mean(S)
     const size_t plane = (size_t)N * OH * OW;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < H * W; i += gridDim.x * kThreads) {
         const int qy = i / W, qx = i - qy * W;
@@ -1129,9 +1131,11 @@ warp_bwd_grid_kernel(const float* __restrict__ img, const float* __restrict__ gr
 
 // d/ds of gscale * (mean(dW^2) + mean(dH^2))/2 for an NCHW [n,2,h,w] field; accumulates into g
 __global__ void __launch_bounds__(kThreads)
-gradient_loss_bwd_kernel(const float* __restrict__ off, float* __restrict__ g, int H, int W, float cx, float cy,
-                         int accumulate) {
+gradient_loss_bwd_kernel(const float* __restrict__ off, float* __restrict__ g, int H, int W, float num,
+                         const float* __restrict__ num_dev, float den_x, float den_y, int accumulate) {
     const int plane = blockIdx.y;
+    const float gs = num * (num_dev ? num_dev[0] : 1.f);
+    const float cx = gs / den_x, cy = gs / den_y;
     const float* p = off + (size_t)plane * H * W;
     float* gp = g + (size_t)plane * H * W;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < H * W; i += gridDim.x * kThreads) {
@@ -1551,6 +1555,11 @@ int san_rss_bwd(const float* x, const float* y, const float* g, float* gx, int n
 
 int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, int n, int h, int w, float* ws,
                       void* stream) {
+    return san_ssim_loss_bwd_dev(x, y, gy, gscale, nullptr, n, h, w, ws, stream);
+}
+
+int san_ssim_loss_bwd_dev(const float* x, const float* y, float* gy, float gscale, const float* gscale_dev, int n, int h,
+                          int w, float* ws, void* stream) {
     SAN_CHECK_ARG(x && y && gy && ws, "null pointer");
     SAN_CHECK_ARG(n > 0 && h >= 7 && w >= 7, "image smaller than the 7x7 window");
     const int oh = h - 6, ow = w - 6;
@@ -1560,9 +1569,10 @@ int san_ssim_loss_bwd(const float* x, const float* y, float* gy, float gscale, i
     SAN_LAUNCH_CHECK();
     int bx = san_cdiv(h * w, kThreads);
     if (bx > 512) bx = 512;
-    // loss = 1 - mean(S)  ->  dL/dS = -gscale / (n*oh*ow)
-    hipLaunchKernelGGL(ssim_bwd_gather_kernel, dim3(bx, n), dim3(kThreads), 0, s, x, y, ws, gy, n, h, w, oh, ow,
-                       -gscale / ((float)n * oh * ow));
+    // loss = 1 - mean(S)  ->  dL/dS = -gscale [* gscale_dev[0]] / (n*oh*ow), formed in the kernel so that the host-scalar and
+    // the device-scalar (autograd grad_output) forms give the same bits
+    hipLaunchKernelGGL(ssim_bwd_gather_kernel, dim3(bx, n), dim3(kThreads), 0, s, x, y, ws, gy, n, h, w, oh, ow, gscale,
+                       gscale_dev, (float)n * oh * ow);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
@@ -1613,15 +1623,18 @@ int san_warp_bwd_grid(const float* img, const float* grid, const float* g, float
 
 int san_gradient_loss_bwd(const float* offset, float* g, float gscale, int accumulate, int n, int h, int w,
                           void* stream) {
+    return san_gradient_loss_bwd_dev(offset, g, gscale, nullptr, accumulate, n, h, w, stream);
+}
+
+int san_gradient_loss_bwd_dev(const float* offset, float* g, float gscale, const float* gscale_dev, int accumulate, int n,
+                              int h, int w, void* stream) {
     SAN_CHECK_ARG(offset && g, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 1 && w > 1, "bad dims");
     // loss = gscale/2 * (sum dx^2 / cnt_x + sum dy^2 / cnt_y);  d(dx^2)/ds = 2 dx
-    const float cx = gscale / ((float)n * h * (w - 1) * 2);
-    const float cy = gscale / ((float)n * (h - 1) * w * 2);
     int bx = san_cdiv(h * w, kThreads);
     if (bx > 256) bx = 256;
     hipLaunchKernelGGL(gradient_loss_bwd_kernel, dim3(bx, n * 2), dim3(kThreads), 0, (hipStream_t)stream, offset, g, h, w,
-                       cx, cy, accumulate);
+                       gscale, gscale_dev, (float)n * h * (w - 1) * 2, (float)n * (h - 1) * w * 2, accumulate);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -1,8 +1,10 @@
-"""Host-side mirror of the reference's lnccloss.py on the fused HIP window kernel.
-Reference: lnccloss.py:7-65."""
+"""Host-side mirror of the reference's lnccloss.py on the fused HIP window kernels.
+Reference: lnccloss.py:7-65.  Both losses are differentiable wrt both images: lncc_loss through
+san_lncc_loss_bwd, ms_lncc_loss additionally through the adjoint of the Gaussian + average-pool
+down-sampler (san_smooth_pool_bwd); see autograd.py."""
 import torch
 
-from . import ops
+from . import autograd
 
 
 def lncc_loss(I: torch.Tensor, J: torch.Tensor, win=None) -> torch.Tensor:
@@ -11,7 +13,7 @@ def lncc_loss(I: torch.Tensor, J: torch.Tensor, win=None) -> torch.Tensor:
     if win is None:
         win = [9] * ndims
     assert win[0] == win[1]
-    return ops.lncc_loss(I.contiguous(), J.contiguous(), int(win[0]))
+    return autograd.lncc_loss(I, J, int(win[0]))
 
 
 _GAUSS = {}
@@ -36,9 +38,8 @@ def ms_lncc_loss(I: torch.Tensor, J: torch.Tensor, win=None, ms=3, sigma=3) -> t
     """Multi-scale LNCC: LNCC at `ms` scales, Gaussian smoothing + 2x average pooling in
     between, averaged.  lnccloss.py:58-65."""
     k = _gaussian_kernel_2d(sigma, I.device)
-    I, J = I.contiguous(), J.contiguous()
     loss = lncc_loss(I, J, win)
     for _ in range(ms - 1):
-        I, J = ops.smooth_pool(I, k), ops.smooth_pool(J, k)
+        I, J = autograd.smooth_pool(I, k), autograd.smooth_pool(J, k)
         loss = loss + lncc_loss(I, J, win)
     return loss / ms

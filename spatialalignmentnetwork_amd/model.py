@@ -15,7 +15,7 @@ import math
 
 import torch
 
-from . import ops
+from . import autograd, ops
 from .basemodel import BaseModel, Config  # noqa: F401
 from .cross import SpatialTransformer
 from . import metrics
@@ -30,16 +30,25 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
     """Smoothness of an NHWC offset field (model.py:21-28).  ``s`` must be the
     permuted view SpatialTransformer.forward returns (NCHW storage)."""
     assert s.shape[-1] == 2, "not 2D grid?"
-    nchw = s.permute(0, 3, 1, 2)
-    if not nchw.is_contiguous():
-        nchw = nchw.contiguous()
-    return ops.gradient_loss_nchw(nchw)
+    return autograd.gradient_loss_nchw(s.permute(0, 3, 1, 2))     # differentiable (autograd._GradientLossFn)
+
+
+def _own_arena(fn):
+    """Run a CSModel method with the model's own arena current (ops.use_arena): two models in one process never share
+    activation tapes."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        with ops.use_arena(ops.owner_arena(self)):
+            return fn(self, *a, **k)
+    return wrapped
 
 
 class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype"}
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -75,6 +84,7 @@ class CSModel(BaseModel):
         self.device = torch.device("cpu")
 
     # ------------------------------------------------------------------ inputs
+    @_own_arena
     def set_input(self, img_full, img_aux=None):
         """fft2 -> drop pruned columns -> ifft2 -> rss x3.  model.py:89-121."""
         for name in [k for k in self.__dict__ if k.startswith(("loss_", "img_", "metric_"))]:
@@ -96,6 +106,7 @@ class CSModel(BaseModel):
         self.img_mask = vis
 
     # ---------------------------------------------------------------- forwards
+    @_own_arena
     def forwardT(self):
         """model.py:142-155."""
         aux_abs = ops.cabs(self.img_aux)
@@ -106,6 +117,7 @@ class CSModel(BaseModel):
         self.loss_smooth = gradient_loss(self.img_offset)
         self.loss_all = self.loss_all + self.loss_smooth * self.cfg.weight_smooth
 
+    @_own_arena
     def forwardR(self):
         """model.py:157-169."""
         self.img_rec = self.net_R(
@@ -116,11 +128,16 @@ class CSModel(BaseModel):
         self.loss_sim = ssimloss(self.img_full_rss, self.img_rec)
         self.loss_all = self.loss_all + self.loss_sim * self.cfg.weight_sim
 
+    @_own_arena
     def backward(self, train_T: bool) -> None:
         """Hand-written backward of loss_all = weight_smooth*loss_smooth + weight_sim*loss_sim through
         forwardR (VarNet) and, when train_T, through the warp into forwardT (alignment network).
-        Replaces ``scalar.scale(loss_all).backward()`` (model.py:203-214)."""
-        ops.AMAX.reset(self.device)             # one memset: the per-tensor gradient maxima of this step (ops.AmaxPool)
+        Replaces ``scalar.scale(loss_all).backward()`` (model.py:203-214); ``loss_all.backward()`` itself works too
+        (autograd.py) and gives the same bits."""
+        with ops.backward_scope(self.device):   # gradient-maximum records zeroed, weight gradients on the side stream
+            self._backward(train_T)
+
+    def _backward(self, train_T: bool) -> None:
         g_rec = ops.ssim_loss_bwd(self.img_full_rss, self.img_rec, float(self.cfg.weight_sim))
         g_warped = self.net_R.backward(g_rec, want_ref_grad=train_T)
         if not train_T:
@@ -131,6 +148,7 @@ class CSModel(BaseModel):
         ops.gradient_loss_bwd(off, g_off, float(self.cfg.weight_smooth), True)
         self.net_T.backward(g_off)
 
+    @_own_arena
     def update(self):
         with ops.conv_precision(self._conv_mode()):
             return self._update()
@@ -160,7 +178,7 @@ class CSModel(BaseModel):
         opts = [self.optim_R] + ([self.optim_T] if train_T else [])
         for o in opts:
             o.zero_grad()                       # one memset of the flat gradient buffer per network
-        with ops.wgrad_overlap(), ops.conv_precision(self.bwd_dtype or self._conv_mode()):
+        with ops.conv_precision(self.bwd_dtype or self._conv_mode()):
             self.backward(train_T)              # weight gradients on a side stream, joined before the exchange / step
         dist = _active_dist()
         scale = 1.0
@@ -228,6 +246,7 @@ class CSModel(BaseModel):
         """Flat per-network buffers (p.data / p.grad are views, see dist.ParamBucket)."""
         return {"R": self.optim_R.bucket(), "T": self.optim_T.bucket()}
 
+    @_own_arena
     def test(self):
         """model.py:265-286 without the GAN branch; returns -PSNR."""
         assert self.training is False

@@ -168,7 +168,7 @@ class Arena:
         self._retired = []
 
     def get(self, name: str, shape, device, dtype=torch.float32, zero: bool = False, _no_wait: bool = False) -> torch.Tensor:
-        key = (name, tuple(int(s) for s in shape), str(device), dtype)
+        key = (name, tuple(int(s) for s in shape), _dev_key(device), dtype)
         t = self._bufs.get(key)
         if t is None:
             t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
@@ -179,7 +179,7 @@ class Arena:
 
     def scratch(self, name: str, nbytes: int, device) -> torch.Tensor:
         """One grow-only byte buffer per name (launches on one stream are ordered, so successive users may share it)."""
-        key = (name, "scratch", str(device))
+        key = (name, "scratch", _dev_key(device))
         t = self._bufs.get(key)
         if t is None or t.numel() < nbytes:
             if t is not None:
@@ -195,11 +195,67 @@ class Arena:
         self._bufs.clear()
 
 
-# One process-wide arena: every model instance in a process shares the activation / tape buffers (they are keyed by name
-# and shape), so run ONE model's forward + backward at a time -- a forward of model B between A.forward and A.backward
-# overwrites A's tape.  Buffers of shapes that are no longer used stay allocated until Arena.clear() (the last partial
-# batch of an epoch costs a second set of per-cascade buffers; 288 GB of HBM make that a non-issue for this workload).
-GLOBAL_ARENA = Arena()
+def _dev_key(device) -> str:
+    """'cuda' and 'cuda:0' name the same device: buffers and pools are keyed by the resolved form."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
+# Arenas have OWNERS.  Every CSModel (and every VarNet / SpatialTransformer used on its own) keeps its activation tapes in an
+# arena of its own, entered for the duration of its forward / backward (``use_arena``): a second model in the process (a
+# validation copy, an EMA) can run between A.forward and A.backward without touching A's tape.  Code that asks
+# ``GLOBAL_ARENA`` gets whichever arena is current (the process-wide default outside any owner's scope).  Buffers of shapes
+# that are no longer used stay allocated until Arena.clear() (the last partial batch of an epoch costs a second set of
+# per-cascade buffers; 288 GB of HBM make that a non-issue for this workload).
+_DEFAULT_ARENA = Arena()
+_ARENA_STACK = [_DEFAULT_ARENA]
+
+
+class _CurrentArena:
+    """Forwards to the arena of the innermost ``use_arena`` scope."""
+
+    def get(self, *a, **k):
+        return _ARENA_STACK[-1].get(*a, **k)
+
+    def scratch(self, *a, **k):
+        return _ARENA_STACK[-1].scratch(*a, **k)
+
+    def bytes(self) -> int:
+        return _ARENA_STACK[-1].bytes()
+
+    def clear(self):
+        _ARENA_STACK[-1].clear()
+
+
+GLOBAL_ARENA = _CurrentArena()
+
+
+class use_arena:
+    """``with use_arena(owner_arena):`` -- arena requests inside the block go to ``owner_arena``.  ``outer_only``: keep the
+    current arena when some owner's scope is already active (a VarNet inside a CSModel uses the CSModel's arena)."""
+
+    def __init__(self, arena: Arena, outer_only: bool = False):
+        self.arena, self.outer_only = arena, outer_only
+
+    def __enter__(self):
+        top = _ARENA_STACK[-1]
+        _ARENA_STACK.append(top if (self.outer_only and top is not _DEFAULT_ARENA) else self.arena)
+        return _ARENA_STACK[-1]
+
+    def __exit__(self, *exc):
+        _ARENA_STACK.pop()
+        return False
+
+
+def owner_arena(owner) -> Arena:
+    """The arena that belongs to ``owner`` (created on first use)."""
+    a = owner.__dict__.get("_san_arena")
+    if a is None:
+        a = Arena()
+        object.__setattr__(owner, "_san_arena", a)
+    return a
 
 
 @dataclass
@@ -605,21 +661,29 @@ class AmaxPool:
         return self.words
 
     def reset(self, device=None) -> None:
+        """Zero the records handed out since the last reset (one memset) and start over.  ``device`` may be given with or
+        without an index ('cuda' == the current device)."""
         used = self.idx * self._words()
-        for t in self.buf.values():
-            if used and (device is None or t.device == torch.device(device)):
+        want = None if device is None else _dev_key(device)
+        for key, t in self.buf.items():
+            if used and (want is None or key == want):
                 t[:used].zero_()
         self.idx = 0
 
     def next(self, device) -> Optional[torch.Tensor]:
         if not (F16_BWD[0] and _CONV_NP[0] == 3):
             return None
-        key = str(device)
+        key = _dev_key(device)
         t = self.buf.get(key)
         w = self._words()
         if t is None:
             t = self.buf[key] = torch.zeros(self.SLOTS * w, dtype=torch.int32, device=device)
         if self.idx >= self.SLOTS:
+            # wrap-around without a per-step reset (a caller driving module.backward in a loop): side-stream weight
+            # gradients may still be reading the records about to be zeroed -- join them first
+            side = _WG["stream"]
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
             self.reset(device)
         self.idx += 1
         return t[(self.idx - 1) * w:self.idx * w]
@@ -652,6 +716,11 @@ def set_conv_precision(mode: str) -> str:
     _CONV_NP[0] = CONV_PRECISIONS[mode]
     _FP8_FWD[0] = mode == "fp8"
     return prev
+
+
+def current_precision() -> str:
+    """The mode set_conv_precision last selected."""
+    return {3: "bf16x3", 2: "bf16x2", 1: "fp8" if _FP8_FWD[0] else "bf16"}[_CONV_NP[0]]
 
 
 class conv_precision:
@@ -1055,6 +1124,33 @@ class wgrad_overlap:
         return False
 
 
+class backward_scope:
+    """Everything one backward pass needs around it, entered by whoever starts it (CSModel.update, VarNet.backward,
+    SpatialTransformer.backward, the autograd Functions): the gradient-maximum records of the previous pass are zeroed
+    (AmaxPool.reset) and the weight gradients go to the side stream (wgrad_overlap), joined on exit.  Nested scopes are
+    no-ops, so a module-level backward inside CSModel.update shares the step's scope."""
+    _depth = [0]
+
+    def __init__(self, device):
+        self.device = device
+        self.ov = None
+
+    def __enter__(self):
+        self._depth[0] += 1
+        if self._depth[0] == 1:
+            AMAX.reset(self.device)
+            self.ov = wgrad_overlap()
+            self.ov.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self._depth[0] -= 1
+        if self.ov is not None:
+            self.ov.__exit__(*exc)
+            self.ov = None
+        return False
+
+
 def _wait_if_busy(t: torch.Tensor) -> None:
     ev = _WG["busy"].pop(t.data_ptr(), None)
     if ev is not None:
@@ -1320,14 +1416,65 @@ def rss_bwd(x: torch.Tensor, y: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     return gx
 
 
-def ssim_loss_bwd(x: torch.Tensor, y: torch.Tensor, gscale: float = 1.0) -> torch.Tensor:
-    """gscale * d ssimloss(x, y) / dy."""
+def _gdev(g: Optional[torch.Tensor]):
+    """An upstream gradient scalar kept on the device (autograd's grad_output): fp32, one element."""
+    if g is None:
+        return None
+    assert g.numel() == 1 and g.is_cuda
+    return g.detach().reshape(1).to(torch.float32).contiguous()
+
+
+def ssim_loss_bwd(x: torch.Tensor, y: torch.Tensor, gscale: float = 1.0, gdev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gscale [* gdev] * d ssimloss(x, y) / dy  (gdev: a one-element device tensor, e.g. autograd's grad_output).  SSIM is
+    symmetric: d / dx is ssim_loss_bwd(y, x)."""
     n, c, h, w = x.shape
     ws = GLOBAL_ARENA.get("ssim_bwd_ws", (3 * n * (h - 6) * (w - 6),), x.device)
     gy = torch.empty_like(y)
-    lib().call("san_ssim_loss_bwd", _p(_chk(x, name="x")), _p(_chk(y, name="y")), _p(gy), float(gscale), n, h, w, _p(ws),
-               _stream())
+    gd = _gdev(gdev)
+    lib().call("san_ssim_loss_bwd_dev", _p(_chk(x, name="x")), _p(_chk(y, name="y")), _p(gy), float(gscale), _p(gd), n, h, w,
+               _p(ws), _stream())
     return gy
+
+
+def lncc_loss_bwd(i: torch.Tensor, j: torch.Tensor, want_i: bool = True, want_j: bool = True, gscale: float = 1.0,
+                  gdev: Optional[torch.Tensor] = None, win: int = 9, gi: Optional[torch.Tensor] = None,
+                  gj: Optional[torch.Tensor] = None):
+    """(gscale [* gdev] * d lncc_loss / d i, ... / d j) (None where not wanted).  Passing gi / gj accumulates into them."""
+    _chk(i, name="i")
+    _chk(j, name="j")
+    n, c, h, w = i.shape
+    assert c == 1 and j.shape == i.shape and (want_i or want_j)
+    acc = gi is not None or gj is not None
+    if not acc:
+        gi = torch.empty_like(i) if want_i else None
+        gj = torch.empty_like(j) if want_j else None
+    ws = GLOBAL_ARENA.get("lncc_bwd_ws", (lib().query("san_lncc_bwd_workspace_floats", n, h, w),), i.device)
+    lib().call("san_lncc_loss_bwd", _p(i), _p(j), _p(gi), _p(gj), float(gscale), _p(_gdev(gdev)), int(acc), n, h, w, int(win),
+               _p(ws), _stream())
+    return gi, gj
+
+
+def smooth_pool_bwd(gy: torch.Tensor, kern: torch.Tensor, gx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Adjoint of smooth_pool: gx [N,1,2h,2w] (accumulated into when given)."""
+    _chk(gy, name="gy")
+    _chk(kern, name="kern")
+    n, c, oh, ow = gy.shape
+    acc = gx is not None
+    if gx is None:
+        gx = torch.empty((n, c, 2 * oh, 2 * ow), device=gy.device, dtype=torch.float32)
+    lib().call("san_smooth_pool_bwd", _p(gy), _p(kern), _p(_chk(gx, name="gx")), int(acc), n * c, 2 * oh, 2 * ow,
+               int(kern.shape[-1]), _stream())
+    return gx
+
+
+def grid_sample_bwd_img(grid: torch.Tensor, g: torch.Tensor, img_shape) -> torch.Tensor:
+    """d <g, grid_sample(img, grid)> / d img (zeros padding): a scatter with float atomics (san_grid_sample_bwd_img)."""
+    n, c, h, w = img_shape
+    ho, wo = grid.shape[1:3]
+    gimg = torch.empty((n, c, h, w), device=g.device, dtype=torch.float32)
+    lib().call("san_grid_sample_bwd_img", _p(_chk(grid, name="grid")), _p(_chk(g, name="g")), _p(gimg), n, c, h, w, ho, wo,
+               _stream())
+    return gimg
 
 
 def act_bwd_coef(g: Act, y: Act, coef: torch.Tensor, dy: Act) -> None:
@@ -1352,7 +1499,8 @@ def warp_bwd_grid(img: torch.Tensor, grid: torch.Tensor, g: torch.Tensor) -> tor
     return out
 
 
-def gradient_loss_bwd(offset_nchw: torch.Tensor, g: torch.Tensor, gscale: float, accumulate: bool) -> None:
+def gradient_loss_bwd(offset_nchw: torch.Tensor, g: torch.Tensor, gscale: float, accumulate: bool,
+                      gdev: Optional[torch.Tensor] = None) -> None:
     n, two, h, w = offset_nchw.shape
-    lib().call("san_gradient_loss_bwd", _p(_chk(offset_nchw, name="offset")), _p(_chk(g, name="g")), float(gscale),
-               int(accumulate), n, h, w, _stream())
+    lib().call("san_gradient_loss_bwd_dev", _p(_chk(offset_nchw, name="offset")), _p(_chk(g, name="g")), float(gscale),
+               _p(_gdev(gdev)), int(accumulate), n, h, w, _stream())

@@ -2,10 +2,11 @@
 Reference: ssimloss.py:11-40."""
 import torch
 
-from . import ops
+from . import autograd
 
 
 def ssimloss(X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
     assert not torch.is_complex(X)
     assert not torch.is_complex(Y)
-    return ops.ssim_loss(X.contiguous(), Y.contiguous())
+    """1 - mean SSIM; differentiable wrt both images (autograd._SsimLossFn -> san_ssim_loss_bwd_dev)."""
+    return autograd.ssimloss(X, Y)

@@ -183,14 +183,16 @@ class UNet(torch.nn.Module):
         ops.upsample2(u, up_out)
         self._record(("up", u, up_out), up_out)
 
-    def run(self, x: Act, out: Act, key: str = "align") -> Act:
-        """x: materialised [N, in_channels, H, W]; out: raw [N, out_channels, H, W]."""
+    def run(self, x: Act, out: Act, key: str = "align", retain: Optional[bool] = None) -> Act:
+        """x: materialised [N, in_channels, H, W]; out: raw [N, out_channels, H, W].  retain: record the tape run_bwd()
+        replays (default: training mode with autograd recording)."""
         s = self.unet
         n, h, w, dev = x.n, x.h, x.w, x.buf.device
         depth = len(self.layer_channels) - 1
         if (h % (1 << depth)) or (w % (1 << depth)):
             raise NotImplementedError(f"alignment U-Net needs H, W divisible by {1 << depth}, got {h}x{w}")
-        retain = self.training and torch.is_grad_enabled()
+        if retain is None:
+            retain = self.training and torch.is_grad_enabled()
         self._tape = [] if retain else None
         self._produced = {}
         c0 = s[0][0].weight.shape[0]
@@ -259,7 +261,7 @@ class UNet(torch.nn.Module):
                 else:
                     ops.act_bwd(g, o, dy, instance_norm=False)   # eval BN / plain activation read
                     if bn is not None:
-                        raise NotImplementedError("backward through eval-mode BatchNorm parameters")
+                        _bn_eval_param_grads(g, o, bn)
                 ops.bias_grad_acc(ops.plane_stats(dy, tag="abwd.b"), _grad_of(conv.bias))
                 ops.conv2d_wgrad(x, dy, _grad_of(conv.weight), accumulate=True)
                 if self._produced.get(x.buf.data_ptr()):
@@ -299,6 +301,18 @@ class UNet(torch.nn.Module):
         y = torch.empty((n, self.out_channels, h, w), device=x.device)
         self.run(ops.full(x.contiguous()), ops.full(y))
         return y
+
+
+def _bn_eval_param_grads(g: Act, o: Act, bn) -> None:
+    """Eval-mode BatchNorm (running statistics: a fixed per-channel affine yh = gamma xn + beta): d beta = sum u and
+    d gamma = sum u xn = (sum u yh - beta sum u) / gamma over (N, H, W), from the two plane sums of san_plane_dot_stats.
+    Rare path (a backward through a network in eval mode): the per-channel arithmetic is a handful of tiny torch ops."""
+    part = ops.plane_dot_part(g, o, "bn.eval").double()
+    su, suy = part[..., 0].sum(dim=(0, 2)), part[..., 1].sum(dim=(0, 2))
+    gamma, beta = bn.weight.detach().double(), bn.bias.detach().double()
+    safe = torch.where(gamma != 0, gamma, torch.ones_like(gamma))
+    _grad_of(bn.bias).add_(su.float())
+    _grad_of(bn.weight).add_(torch.where(gamma != 0, (suy - beta * su) / safe, torch.zeros_like(su)).float())
 
 
 def _grad_of(p: torch.Tensor) -> torch.Tensor:

@@ -611,16 +611,26 @@ class VarNet(nn.Module):
 
     def forward(self, masked_kspace: torch.Tensor, mask: torch.Tensor, ref: Optional[torch.Tensor],
                 num_low_frequencies: int) -> torch.Tensor:
-        masked_kspace = masked_kspace.contiguous()
+        """varnet.py:465-486.  With autograd recording and parameters that require gradients the result carries a
+        ``grad_fn`` (autograd._VarNetFn) whose backward is ``VarNet.backward``: ``ssimloss(net(...), target).backward()``
+        fills every ``p.grad`` (varnet.py:559-560)."""
+        from . import autograd
+        with ops.use_arena(ops.owner_arena(self), outer_only=True):
+            return autograd.varnet_forward(self, masked_kspace, mask, ref, num_low_frequencies)
+
+    def _forward_impl(self, masked_kspace: torch.Tensor, mask: torch.Tensor, ref: Optional[torch.Tensor],
+                      num_low_frequencies: int, retain: bool) -> torch.Tensor:
+        """retain: keep every cascade's activations, state and data-consistency residual for backward()."""
+        masked_kspace = masked_kspace.detach().contiguous()
         n, c, h, w = masked_kspace.shape
         dev = masked_kspace.device
-        retain = self.training and torch.is_grad_enabled()
+        self._fwd_id = getattr(self, "_fwd_id", 0) + 1
         sens = self.sens_net(masked_kspace, num_low_frequencies)
         mask_f = mask.reshape(-1).to(torch.float32).contiguous()
         assert mask_f.numel() == w, "mask must be a [W] column mask (broadcast like the reference's [1,1,1,W])"
         ref1 = None
         if self.use_ref:
-            ref = ref.contiguous()
+            ref = ref.detach().contiguous()
             ref1 = ops.rss(ref)                          # varnet.py:475-476
         # The cascades run on the IMAGE-domain state x_j = ifft2(k_j) (VarNetBlock.run_img): k0x = ifft_y(k0) is the data
         # term, x_0 = ifft2(k0), m_0 = sum_c conj(S_c) x_0; every cascade is then ONE row-local launch besides its U-Net,
@@ -656,13 +666,17 @@ class VarNet(nn.Module):
             dk = ARENA.get(f"{key}.dk", (n, c, h, w), dev, dtype=torch.complex64)
             x = cascade.run_img(x, k0x, mask_f, sens, xins[j], x_out, key, xins[j + 1].buf if j + 1 < T else None, dk)
         out = ops.rss(x)
-        self._train_state = (x, out, ref, ref1)
+        self._train_state = (x, out.detach(), ref, ref1)      # (a detached alias: the returned tensor will carry the grad_fn)
         return out
 
     def backward(self, g_img: torch.Tensor, want_ref_grad: bool = False) -> Optional[torch.Tensor]:
         """Backward of the last training-mode forward().  g_img = dL/d(output image) [N,1,H,W].
         Accumulates every parameter gradient (cascades, dc weights, sensitivity net) and returns
         dL/d(ref) (the `ref` argument of forward) when asked."""
+        with ops.use_arena(ops.owner_arena(self), outer_only=True), ops.backward_scope(g_img.device):
+            return self._backward_impl(g_img, want_ref_grad)
+
+    def _backward_impl(self, g_img: torch.Tensor, want_ref_grad: bool) -> Optional[torch.Tensor]:
         x_last, out, ref, ref1 = self._train_state
         g_x = ops.rss_bwd(x_last, out, g_img.contiguous())          # dL/dx_T: the state is already in the image domain
         g_sens = torch.zeros_like(x_last)

@@ -613,6 +613,49 @@ def make_multicoil():
     save("multicoil_640x368.npz", **out)
 
 
+def make_autograd():
+    """Gradients the reference's autograd produces through the free functions of the path (lnccloss.py:7-65,
+    ssimloss.py:11-40, model.py:21-28, signal_utils.py:4-26, cross.py:32-34): the targets of the hand-written backward
+    kernels behind spatialalignmentnetwork_amd/autograd.py.  Inputs are Philox streams the tests regenerate."""
+    out = {}
+    a0 = philox("loss.a", (2, 1, 40, 56), lo=0.0, hi=1.0)
+    b0 = (a0 + 0.1 * philox("loss.b", (2, 1, 40, 56))).clamp(0, 1)
+    for name, fn in (("lncc", R_lncc.lncc_loss), ("ms_lncc", R_lncc.ms_lncc_loss), ("ssim", R_ssim.ssimloss)):
+        a, b = a0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        loss = fn(a, b)
+        (loss * 1.7).backward()                       # a non-trivial upstream gradient
+        out[f"{name}.loss"], out[f"{name}.ga"], out[f"{name}.gb"] = npy(loss), npy(a.grad), npy(b.grad)
+        # the reference itself in float64: the arbiter (the coarse scales of ms_lncc divide by near-zero window variances of
+        # smoothed images; the reference's own fp32 gradient is 1e-4 away from this)
+        a, b = a0.double().requires_grad_(True), b0.double().requires_grad_(True)
+        (fn(a, b) * 1.7).backward()
+        out[f"{name}.ga64"], out[f"{name}.gb64"] = npy(a.grad), npy(b.grad)
+    # a bigger, less correlated pair (window statistics far from the cc = 1 plateau), odd sizes for the tile edges
+    a1 = philox("lncc.a1", (1, 1, 37, 70), lo=0.0, hi=1.0)
+    b1 = philox("lncc.b1", (1, 1, 37, 70), lo=0.0, hi=1.0)
+    a, b = a1.clone().requires_grad_(True), b1.clone().requires_grad_(True)
+    R_lncc.lncc_loss(a, b).backward()
+    out["lncc_odd.ga"], out["lncc_odd.gb"] = npy(a.grad), npy(b.grad)
+    # LNCC through the warp: d lncc(fixed, warp(moving, identity + offset)) / d offset   (cross.py:24-34)
+    st = R_cross.SpatialTransformer(1)
+    moving = philox("lw.moving", (2, 1, 40, 56), lo=0.0, hi=1.0)
+    fixed = philox("lw.fixed", (2, 1, 40, 56), lo=0.0, hi=1.0)
+    theta = torch.tensor([[[1.0, 0, 0], [0, 1, 0]]])
+    ident = torch.nn.functional.affine_grid(theta, (1, 1, 40, 56), align_corners=False)
+    off = (philox("lw.off", (2, 40, 56, 2)) * 0.08).requires_grad_(True)
+    mv = moving.clone().requires_grad_(True)
+    loss = R_lncc.lncc_loss(fixed, st.warp(mv, ident + off)) + 3.0 * R_gradient_loss(off)
+    loss.backward()
+    out["lw.loss"], out["lw.g_off"], out["lw.g_moving"] = npy(loss), npy(off.grad), npy(mv.grad)
+    # fft2 / ifft2 / rss
+    x = cplx("ag.x", (2, 3, 24, 40)).requires_grad_(True)
+    wgt = philox("ag.w", (2, 1, 24, 40))
+    loss = (R_sig.rss(R_sig.ifft2(R_sig.fft2(x) * philox("ag.m", (1, 1, 1, 40)))) * wgt).sum()
+    loss.backward()
+    out["fft.loss"], out["fft.gx"] = npy(loss), npy(x.grad)
+    save("autograd_ops.npz", **out)
+
+
 def run_pair_full(n, c, h, w, sparsity, num_cascades, seed, training):
     """run_pair at the full network width (chans 18, sens_chans 8, 4 pooling levels)."""
     return run_pair(n, c, h, w, sparsity, num_cascades, 18, 8, 4, seed=seed, training=training)
@@ -620,7 +663,7 @@ def run_pair_full(n, c, h, w, sparsity, num_cascades, seed, training):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "small", "full", "augment", "metrics", "ckpt", "layers", "pad", "scalars", "train_full",
-                             "multicoil"]
+                             "multicoil", "autograd"]
     with torch.no_grad():
         if "ops" in which:
             make_ops()
@@ -645,3 +688,5 @@ if __name__ == "__main__":
         make_train_full()
     if "multicoil" in which:
         make_multicoil()
+    if "autograd" in which:
+        make_autograd()

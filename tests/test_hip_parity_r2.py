@@ -446,7 +446,7 @@ def test_cascade_checksums_full_320(S):
     want = gold["cascade_checksums"]
     for j in range(12):
         # the cascades keep the image-domain state x_j = ifft2(k_j): transform it back for the k-space checksums
-        xj = S.ops.GLOBAL_ARENA.get(f"cas{j}.xout", (1, 1, w, w), torch.device(DEV), dtype=torch.complex64)
+        xj = S.ops.owner_arena(net_R).get(f"cas{j}.xout", (1, 1, w, w), torch.device(DEV), dtype=torch.complex64)
         k = S.ops.fft2c(xj).cpu()
         got = np.array([k.real.double().sum().item(), k.imag.double().sum().item(), k.abs().double().pow(2).sum().sqrt().item()])
         l2 = want[j, 2]
@@ -502,7 +502,7 @@ def test_e2e_multicoil_640x368_golden(S):
     assert np.all(np.abs(got[:, :2] - want[:, :2]) < 2e-3 * want[:, 2:3])
     cs = gold["cascade_checksums"]
     for j in range(12):
-        xj = S.ops.GLOBAL_ARENA.get(f"cas{j}.xout", (n, c, h, w), torch.device(DEV), dtype=torch.complex64).cpu()
+        xj = S.ops.owner_arena(net_R).get(f"cas{j}.xout", (n, c, h, w), torch.device(DEV), dtype=torch.complex64).cpu()
         # ortho transforms: the k-space L2 norm is the image-domain L2 norm
         assert abs(xj.abs().double().pow(2).sum().sqrt().item() - cs[j, 2]) < 1e-4 * cs[j, 2], j
 

@@ -1,0 +1,383 @@
+"""Round-3 GPU parity tests (through the C ABI): the LNCC backward, the autograd-visible entry points (the reference's
+``loss.backward()`` idiom, varnet.py:559-560 / model.py:203-214) against the direct ``CSModel.update()`` chain and the
+reference's own gradients, per-model arenas, and the device-normalisation fix of the gradient-maximum pool.
+Tolerances are written next to each assertion together with what was measured."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import as_t, cplx, philox, rel_err, load_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def S():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spatialalignmentnetwork_amd import (ops, synth, varnet, cross, unet, signal_utils, ssimloss, lnccloss, masks, model,
+                                             basemodel, autograd)
+    from oracle import cpu_ref as O
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.ops, ns.synth, ns.varnet, ns.cross, ns.unet, ns.sig, ns.ssim, ns.lncc = ops, synth, varnet, cross, unet, signal_utils, ssimloss, lnccloss
+    ns.masks, ns.model, ns.base, ns.O, ns.autograd = masks, model, basemodel, O, autograd
+    return ns
+
+
+def g(t):
+    return t.to(DEV).contiguous()
+
+
+def _fill(S, m, seed, damp=1.0):
+    m.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=seed, damp=damp))
+
+
+def _pair():
+    a = philox("loss.a", (2, 1, 40, 56), lo=0.0, hi=1.0)
+    b = (a + 0.1 * philox("loss.b", (2, 1, 40, 56))).clamp(0, 1)
+    return a, b
+
+
+# ------------------------------------------------------------------------------------------- losses: backward kernels
+def test_loss_backward_vs_reference_autograd(S):
+    """lncc_loss / ms_lncc_loss / ssimloss .backward() (san_lncc_loss_bwd, san_smooth_pool_bwd, san_ssim_loss_bwd_dev) against
+    the gradients the REFERENCE's autograd produced (lnccloss.py:7-65, ssimloss.py:11-40), both arguments, with a
+    non-trivial upstream gradient kept on the device.  Bar 2e-5."""
+    gold = load_golden("autograd_ops.npz")
+    for name, fn in (("lncc", S.lncc.lncc_loss), ("ms_lncc", S.lncc.ms_lncc_loss), ("ssim", S.ssim.ssimloss)):
+        a, b = _pair()
+        a, b = g(a).requires_grad_(True), g(b).requires_grad_(True)
+        loss = fn(a, b)
+        assert loss.grad_fn is not None
+        (loss * 1.7).backward()
+        assert abs(loss.item() - float(gold[f"{name}.loss"])) < 2e-6
+        ea, eb = rel_err(a.grad.cpu(), as_t(gold[f"{name}.ga"])), rel_err(b.grad.cpu(), as_t(gold[f"{name}.gb"]))
+        # the reference's float64 run arbitrates where fp32 itself is ill-conditioned: the coarse scales of ms_lncc divide by
+        # near-zero window variances of smoothed images, the reference's own fp32 gradient is 1.0-1.2e-4 from its fp64 one
+        ra, rb = rel_err(as_t(gold[f"{name}.ga"]), as_t(gold[f"{name}.ga64"])), rel_err(as_t(gold[f"{name}.gb"]), as_t(gold[f"{name}.gb64"]))
+        ea64, eb64 = rel_err(a.grad.cpu(), as_t(gold[f"{name}.ga64"])), rel_err(b.grad.cpu(), as_t(gold[f"{name}.gb64"]))
+        print(name, "gradient rel-L2 vs reference fp32", ea, eb, "vs fp64", ea64, eb64, "(reference fp32 vs fp64:", ra, rb, ")")
+        # measured: lncc 2.9e-6, ssim 1e-6 vs fp32; ms_lncc 7e-5 vs fp32 with the reference's own fp32-fp64 distance at 1.1e-4
+        assert ea < max(2e-5, ra) and eb < max(2e-5, rb), (name, ea, eb)
+        assert ea64 < max(2e-5, 1.5 * ra) and eb64 < max(2e-5, 1.5 * rb), (name, ea64, eb64)
+    # ragged tiles (37 x 70), uncorrelated pair
+    a = g(philox("lncc.a1", (1, 1, 37, 70), lo=0.0, hi=1.0)).requires_grad_(True)
+    b = g(philox("lncc.b1", (1, 1, 37, 70), lo=0.0, hi=1.0)).requires_grad_(True)
+    S.lncc.lncc_loss(a, b).backward()
+    assert rel_err(a.grad.cpu(), as_t(gold["lncc_odd.ga"])) < 2e-5 and rel_err(b.grad.cpu(), as_t(gold["lncc_odd.gb"])) < 2e-5
+    # only one side requires a gradient
+    a2, b2 = g(philox("lncc.a1", (1, 1, 37, 70), lo=0.0, hi=1.0)), g(philox("lncc.b1", (1, 1, 37, 70), lo=0.0, hi=1.0)).requires_grad_(True)
+    S.lncc.lncc_loss(a2, b2).backward()
+    assert torch.equal(b2.grad, b.grad) and a2.grad is None
+
+
+def test_lncc_backward_full_size_vs_oracle_autograd(S):
+    """The bench batch (N = 8, 320 x 320): LNCC gradients vs oracle autograd (float64), plus symmetry of the kernel pair."""
+    x = philox("fs.x", (8, 1, 320, 320), lo=0.0, hi=1.0)
+    y = (0.6 * x + 0.4 * philox("fs.y", (8, 1, 320, 320), lo=0.0, hi=1.0))
+    x64, y64 = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    S.O.lncc_loss(x64, y64).backward()
+    gi, gj = S.ops.lncc_loss_bwd(g(x), g(y))
+    assert rel_err(gi.cpu(), x64.grad.float()) < 2e-5 and rel_err(gj.cpu(), y64.grad.float()) < 2e-5
+    gj2, gi2 = S.ops.lncc_loss_bwd(g(y), g(x))                  # symmetric up to the rounding of the two variance formulas
+    assert rel_err(gi2, gi) < 1e-5 and rel_err(gj2, gj) < 1e-5
+    # accumulate form
+    acc = torch.ones_like(gi)
+    S.ops.lncc_loss_bwd(g(x), g(y), gi=acc, gj=None, want_j=False)
+    assert torch.allclose(acc, gi + 1.0, rtol=0, atol=1e-6)
+
+
+def test_lncc_through_warp_and_fft_autograd_vs_reference(S):
+    """lncc_loss(fixed, net_T.warp(moving, grid)).backward() -> d / d offset incl. the smoothness term, and
+    d / d moving (the scatter with float atomics); fft2 / ifft2 / rss adjoints.  Against the reference's autograd."""
+    gold = load_golden("autograd_ops.npz")
+    st = S.cross.SpatialTransformer(1).to(DEV)
+    moving = g(philox("lw.moving", (2, 1, 40, 56), lo=0.0, hi=1.0)).requires_grad_(True)
+    fixed = g(philox("lw.fixed", (2, 1, 40, 56), lo=0.0, hi=1.0))
+    off = g(philox("lw.off", (2, 40, 56, 2)) * 0.08).requires_grad_(True)
+    ident = g(S.O.identity_grid(40, 56))
+    loss = S.lncc.lncc_loss(fixed, st.warp(moving, ident + off)) + 3.0 * S.model.gradient_loss(off)
+    loss.backward()
+    assert abs(loss.item() - float(gold["lw.loss"])) < 2e-6
+    e_off, e_mov = rel_err(off.grad.cpu(), as_t(gold["lw.g_off"])), rel_err(moving.grad.cpu(), as_t(gold["lw.g_moving"]))
+    print("through-warp gradient errors", e_off, e_mov)
+    assert e_off < 2e-5 and e_mov < 2e-5
+    x = g(cplx("ag.x", (2, 3, 24, 40))).requires_grad_(True)
+    wgt, m = g(philox("ag.w", (2, 1, 24, 40))), g(philox("ag.m", (1, 1, 1, 40)))
+    loss = (S.sig.rss(S.sig.ifft2(S.sig.fft2(x) * m)) * wgt).sum()
+    loss.backward()
+    assert abs(loss.item() - float(gold["fft.loss"])) < 1e-4 * abs(float(gold["fft.loss"]))
+    assert rel_err(x.grad.cpu(), as_t(gold["fft.gx"], True)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------- the reference's smoke idiom
+@pytest.mark.parametrize("tag,shape", [("32", (2, 1, 32, 32)), ("48x80c3", (2, 3, 48, 80))])
+def test_reference_smoke_idiom_matches_direct_chain(S, tag, shape):
+    """``result = varnet(...); ssimloss(result, target).backward()`` (the reference's own smoke block, varnet.py:546-560):
+    every p.grad (a) equals the direct VarNet.backward chain bit for bit and (b) matches the gradients the reference
+    produced for the same weights and inputs."""
+    gold = load_golden(f"e2e_small_{tag}.npz")
+    n, c, h, w = shape
+    pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+    k_samp, warped = g(as_t(gold["train.img_k_sampled"], True)), g(as_t(gold["train.img_warped"]))
+    full_rss = g(as_t(gold["train.img_full_rss"]))
+
+    def build():
+        net = S.varnet.VarNet(num_cascades=2, sens_chans=2, sens_pools=2, chans=4, pools=2, use_ref=True)
+        _fill(S, net, 42)
+        return net.to(DEV).train()
+
+    net_a = build()
+    result = net_a(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32))
+    assert result.grad_fn is not None and result.requires_grad
+    S.ssim.ssimloss(full_rss, result).backward()
+    net_b = build()
+    rec = net_b(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32))
+    net_b.backward(S.ops.ssim_loss_bwd(full_rss, rec.detach(), 1.0), want_ref_grad=False)
+    assert torch.equal(result, rec)
+    worst = 0.0
+    for (name, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+        assert pa.grad is not None and torch.equal(pa.grad, pb.grad), name
+        want = as_t(gold["grad.R." + name])
+        scale = want.abs().max().item()
+        if scale > 1e-12:
+            worst = max(worst, (pa.grad.cpu() - want).abs().max().item() / scale)
+    print("autograd route: worst relative gradient error vs the reference", worst)
+    assert worst < 2e-4, worst
+    # a second backward through the same (stale once a new forward ran) graph is refused
+    result2 = net_a(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32))
+    net_a(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32))
+    with pytest.raises(RuntimeError, match="no longer the module's latest"):
+        S.ssim.ssimloss(full_rss, result2).backward()
+
+
+def _rec_model(S, w, c, seed_T=41, seed_R=42, **kw):
+    from spatialalignmentnetwork_amd.basemodel import Config
+    from spatialalignmentnetwork_amd.model import CSModel
+    cfg = Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                 weight_gan=0.0, weight_gan_sim=0.0, weight_sim=kw.pop("weight_sim", 1.0), use_amp=False, num_cascades=2,
+                 chans=4, sens_chans=2, pools=2, sens_pools=2, **kw)
+    net = CSModel(cfg)
+    net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+    _fill(S, net.net_T, seed_T)
+    _fill(S, net.net_R, seed_R)
+    return net
+
+
+def _grads(net):
+    return [p.grad.detach().clone() for m in (net.net_R, net.net_T) for p in m.parameters()]
+
+
+@pytest.mark.parametrize("shape,weight_sim", [((2, 1, 32, 32), 1.0), ((2, 3, 48, 80), 0.37)])
+def test_loss_all_backward_matches_update_chain_bitwise(S, shape, weight_sim):
+    """CSModel 'Rec': forwardT(); forwardR(); loss_all.backward() (the reference's model.py:203-214 idiom, through
+    autograd: SSIM -> VarNet -> ref -> warp -> grid -> offset (+ smoothness) -> alignment U-Net) fills every p.grad of
+    BOTH networks with the same bits as the direct CSModel.backward chain, also with loss weights != 1."""
+    n, c, h, w = shape
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    res = []
+    for route in ("autograd", "direct"):
+        net = _rec_model(S, w, c, weight_sim=weight_sim).to(DEV).train()
+        net.set_input(g(img_full), g(img_aux))
+        net.loss_all = 0
+        net.forwardT()
+        net.forwardR()
+        for o in (net.optim_R, net.optim_T):
+            o.zero_grad()
+        if route == "autograd":
+            assert net.loss_all.grad_fn is not None
+            net.loss_all.backward()
+        else:
+            net.backward(train_T=True)
+        torch.cuda.synchronize()
+        res.append((_grads(net), net.loss_all.detach().clone(), [b.detach().clone() for b in net.net_T.buffers()]))
+    (ga, la, ba), (gd, ld, bd) = res
+    assert torch.equal(la, ld)
+    assert all(torch.equal(x, y) for x, y in zip(ba, bd))
+    bad = [i for i, (x, y) in enumerate(zip(ga, gd)) if not torch.equal(x, y)]
+    assert not bad, f"{len(bad)} of {len(ga)} parameter gradients differ between loss_all.backward() and the direct chain"
+    assert any(x.abs().max().item() > 0 for x in ga)
+
+
+def test_autograd_route_trains_like_update(S):
+    """Three optimisation steps written the reference's way (zero_grad; loss_all.backward(); optim.step()) give
+    bit-identical parameters to three CSModel.update() calls."""
+    n, c, h, w = 2, 1, 32, 32
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    outs = []
+    for route in ("autograd", "update"):
+        net = _rec_model(S, w, c).to(DEV).train()
+        for _ in range(3):
+            net.set_input(g(img_full), g(img_aux))
+            if route == "update":
+                net.update()
+                continue
+            net.loss_all = 0
+            net.forwardT()
+            net.forwardR()
+            net.optim_T.zero_grad()
+            net.optim_R.zero_grad()
+            net.loss_all.backward()
+            net.optim_T.step()
+            net.optim_R.step()
+            del net.loss_all
+        torch.cuda.synchronize()
+        outs.append([p.detach().clone() for m in (net.net_R, net.net_T) for p in m.parameters()])
+    assert all(torch.equal(x, y) for x, y in zip(*outs))
+
+
+def test_regime_none_through_autograd(S):
+    """Regime 'None' (model.py:195-204): forwardT under no_grad, only net_R trains; loss_all.backward() leaves net_T's
+    gradients untouched and equals the direct chain."""
+    n, c, h, w = 2, 1, 32, 32
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    res = []
+    for route in ("autograd", "direct"):
+        net = _rec_model(S, w, c).to(DEV).train()
+        net.set_input(g(img_full), g(img_aux))
+        net.loss_all = 0
+        with torch.no_grad():
+            net.forwardT()
+        net.loss_all = 0
+        net.forwardR()
+        net.optim_R.zero_grad()
+        net.optim_T.zero_grad()
+        if route == "autograd":
+            assert not net.img_warped.requires_grad
+            net.loss_all.backward()
+        else:
+            net.backward(train_T=False)
+        torch.cuda.synchronize()
+        res.append(_grads(net))
+        assert all(p.grad.abs().max().item() == 0 for p in net.net_T.parameters())
+    assert all(torch.equal(x, y) for x, y in zip(*res))
+
+
+# ------------------------------------------------------------------------------------------- arenas / pools
+def test_two_models_interleaved_do_not_share_tapes(S):
+    """A.forward, B.forward, A.backward (a validation copy or an EMA next to the trained model): every
+    model owns its arena, so A's gradients are bit-identical to the un-interleaved run."""
+    n, c, h, w = 2, 1, 32, 32
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    img_b, aux_b = S.synth.phantom_pair(n, c, h, w, seed=77)
+
+    def run(interleave: bool):
+        A = _rec_model(S, w, c).to(DEV).train()
+        B = _rec_model(S, w, c, seed_T=51, seed_R=52).to(DEV).train()
+        A.set_input(g(img_full), g(img_aux))
+        A.loss_all = 0
+        A.forwardT()
+        A.forwardR()
+        if interleave:
+            B.set_input(g(img_b), g(aux_b))
+            B.loss_all = 0
+            B.forwardT()
+            B.forwardR()
+        A.optim_R.zero_grad()
+        A.optim_T.zero_grad()
+        A.backward(train_T=True)
+        torch.cuda.synchronize()
+        return _grads(A), A.img_rec.detach().clone()
+
+    (g0, r0), (g1, r1) = run(False), run(True)
+    assert torch.equal(r0, r1)
+    assert all(torch.equal(x, y) for x, y in zip(g0, g1)), "model B's forward changed model A's backward"
+    # stand-alone modules own arenas too
+    va, vb = S.varnet.VarNet(2, 2, 2, 4, 2, use_ref=False).to(DEV).train(), S.varnet.VarNet(2, 2, 2, 4, 2, use_ref=False).to(DEV).train()
+    _fill(S, va, 42)
+    _fill(S, vb, 43)
+    k = g(cplx("arena.k", (2, 1, 32, 32)))
+    mask = (~S.synth.equispaced_pruned(32, 0.25, 0)).to(DEV)
+    gimg = g(philox("arena.g", (2, 1, 32, 32)))
+    va(k, mask, None, 2)
+    va.backward(gimg)
+    want = [p.grad.clone() for p in va.parameters()]
+    for p in va.parameters():
+        p.grad.zero_()
+    va(k, mask, None, 2)
+    vb(k * 0.5, mask, None, 2)
+    va.backward(gimg)
+    assert all(torch.equal(p.grad, t) for p, t in zip(va.parameters(), want))
+
+
+def test_vis_images_survive_the_next_step(S):
+    """get_vis('images') hands out tensors the next step does not overwrite (the reference returns fresh tensors)."""
+    n, c, h, w = 2, 1, 32, 32
+    net = _rec_model(S, w, c).to(DEV).train()
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    net.set_input(g(img_full), g(img_aux))
+    net.update()
+    vis = net.get_vis("images")["images"]
+    keep = {k: v.clone() for k, v in vis.items()}
+    img2, aux2 = S.synth.phantom_pair(n, c, h, w, seed=78)
+    net.set_input(g(img2), g(aux2))
+    net.update()
+    torch.cuda.synchronize()
+    assert {"img_rec", "img_warped", "img_full_rss"} <= set(vis)
+    for k, v in vis.items():
+        assert torch.equal(v, keep[k]), k
+
+
+def test_amax_pool_resets_on_an_unindexed_device(S):
+    """net.to(torch.device('cuda')) -- what the reference's train.py / eval.py do -- must still zero
+    the gradient-maximum records every step ('cuda' == 'cuda:0').  A poisoned record (exponent 250) would otherwise scale
+    every later gradient to zero."""
+    ops = S.ops
+    ops.AMAX.reset(torch.device("cuda"))
+    rec = ops.AMAX.next(torch.device("cuda"))
+    rec.fill_(0x7F000000)                                   # a huge recorded maximum
+    assert ops.AMAX.idx == 1
+    ops.AMAX.reset(torch.device("cuda"))                   # unindexed
+    assert ops.AMAX.idx == 0 and int(rec.abs().max().item()) == 0
+    rec = ops.AMAX.next(DEV)
+    rec.fill_(0x7F000000)
+    ops.AMAX.reset("cuda")
+    assert int(rec.abs().max().item()) == 0
+    # and a whole model moved with the unindexed device trains to the same bits as one moved to cuda:0
+    n, c, h, w = 2, 1, 32, 32
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    outs = []
+    for dev in (torch.device("cuda"), torch.device(DEV)):
+        net = _rec_model(S, w, c).to(dev).train()
+        for _ in range(2):
+            net.set_input(img_full.to(dev), img_aux.to(dev))
+            net.update()
+        torch.cuda.synchronize()
+        outs.append([p.detach().clone() for m in (net.net_R, net.net_T) for p in m.parameters()])
+    assert all(torch.equal(x, y) for x, y in zip(*outs))
+
+
+def test_alignment_backward_in_eval_mode_vs_oracle_autograd(S):
+    """Backward through the alignment network in eval mode (BatchNorm on running statistics): every
+    parameter gradient incl. gamma / beta against oracle autograd."""
+    n, c, h, w = 2, 1, 32, 48
+    st = S.cross.SpatialTransformer(c)
+    p = S.synth.fill_params([(k, tuple(v.shape)) for k, v in st.state_dict().items()], seed=61)
+    st.load_state_dict(p)
+    st.to(DEV).eval()
+    moving, fixed = philox("ev.m", (n, c, h, w), lo=0.0, hi=1.0), philox("ev.f", (n, c, h, w), lo=0.0, hi=1.0)
+    wgt = philox("ev.w", (n, h, w, 2))
+    off, grid = st(g(moving), g(fixed))
+    assert off.grad_fn is not None
+    (off * g(wgt)).sum().backward()
+    p64 = {k: v.double().requires_grad_(v.dtype.is_floating_point) for k, v in p.items()}
+    off64, _ = S.O.spatial_transformer_forward(p64, moving.double(), fixed.double(), training=False)
+    (off64 * wgt.double()).sum().backward()
+    assert rel_err(off.detach().cpu(), off64.detach().float()) < 1e-4
+    worst, wname = 0.0, ""
+    for name, prm in st.named_parameters():
+        want = p64[name].grad
+        scale = want.abs().max().item()
+        if scale < 1e-9:
+            continue
+        err = (prm.grad.cpu().double() - want).abs().max().item() / scale
+        if err > worst:
+            worst, wname = err, name
+    print("eval-mode alignment backward: worst relative gradient error", worst, wname)
+    assert worst < 2e-3, (worst, wname)
