@@ -77,6 +77,7 @@ def parse_args(argv=None):
                     help="only the timed steps of --mode: no inference / narrow-precision legs after them (profiling runs)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step into a hipGraph and time replays (no per-kernel timer in that mode)")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own share of the host cores")
     ap.add_argument("--launch-test", action="store_true",
                     help="(CPU) exercise only the launcher: rendezvous over gloo, barrier, max-over-ranks, one JSON line")
     return ap.parse_args(argv)
@@ -97,6 +98,21 @@ def self_launch(args, argv):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
     return subprocess.call(cmd, env=env)
+
+
+def pin_cores(local_rank, local_world):
+    """Give every rank of the node its own contiguous share of the usable host cores (the eager step needs most of one
+    core per GPU for launching; eight unpinned Python processes migrate over each other).  Returns the cores taken."""
+    if not hasattr(os, "sched_setaffinity") or local_world <= 1:
+        return None
+    cores = sorted(os.sched_getaffinity(0))
+    k = len(cores) // local_world
+    if k < 1:
+        return None
+    mine = cores[local_rank * k:(local_rank + 1) * k]
+    os.sched_setaffinity(0, mine)
+    torch.set_num_threads(max(1, min(k, 4)))
+    return mine
 
 
 def build_model(n_per_gpu, h, w, num_cascades, dev, seed=0, coils=1, sparsity=0.25):
@@ -213,7 +229,9 @@ def launch_test(args):
     """CPU check of the launcher contract: env rendezvous, barrier, max-over-ranks, rank 0 prints one line."""
     from spatialalignmentnetwork_amd import dist as sdist
     rank, local_rank, world = sdist.env_rank_world()
+    mine = None if args.no_pin else pin_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     dist = sdist.init("gloo")
+    ncores = sdist.sum_over_ranks(float(len(mine) if mine else 0), dist)
     lo, hi = sdist.shard_bounds(args.batch * world, rank, world)
     t = sdist.max_over_ranks(1.0 + rank, dist)
     tot = sdist.sum_over_ranks(float(hi - lo), dist)
@@ -221,7 +239,7 @@ def launch_test(args):
         dist.barrier()
     if rank == 0:
         print(json.dumps({"launch_test": True, "n_gpus": world, "backend": sdist.BACKEND, "max_over_ranks": t,
-                          "global_batch": tot}))
+                          "global_batch": tot, "pinned_cores_total": int(ncores)}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -259,6 +277,14 @@ def roofline_entry(key, d, dt, steps, pmc, match_profile, products=BF16X3_PRODUC
            "launches": d["launches"], "timed_launches": d["sampled_launches"],
            "avg_launch_us": 1e3 * d["sampled_ms"] / d["sampled_launches"],
            "share_of_step": d["ms"] / (1e3 * dt), **extra}
+    if d["unit"] == "FLOP":
+        # these kernels are also HBM consumers, and the 18- / 36-channel levels are HBM-bound by arithmetic intensity
+        # (~40 FLOP/B): report the HBM side next to the MFMA fraction.  bytes = PMC traffic per launch when a committed
+        # PMC pass of this workload exists, else the algorithmic bytes (inputs + outputs + weights once)
+        nbytes = p.get("hbm_bytes_per_launch") or out["algorithmic_bytes"]
+        if nbytes:
+            out["hbm_frac"] = nbytes / (out["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            out["hbm_frac_bytes"] = "pmc" if p.get("hbm_bytes_per_launch") else "algorithmic"
     if ev_us is not None:
         # the event pair's own latency (nothing between the two records, measured in this run) and what the figures would be
         # without it: rocprofv3's per-kernel durations (profiles/) are the cross-check; `achieved` / `frac` stay the raw ones
@@ -285,6 +311,7 @@ def main(argv=None):
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    my_cores = None if (args.no_pin or world == 1) else pin_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     dist = sdist.init("nccl", dev)      # RCCL; None when world == 1; raises (rc != 0) if RCCL cannot come up
     nccl_ranks = None
     if dist is not None:
@@ -310,12 +337,14 @@ def main(argv=None):
 
     if args.mode == "train":
         net.train()
+        net.time_exchange = dist is not None        # HIP events around the gradient all-reduces (communication stream)
         step = lambda: train_step(net, img_full, img_aux)
     else:
         step = lambda: one_step(net, img_full, img_aux)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    graph = None
     if args.graph:
         # the arena, packed weights, twiddles and masks exist after warm-up, so the step neither
         # allocates through the library nor synchronises: it is capture-safe
@@ -340,15 +369,27 @@ def main(argv=None):
     if not args.no_kernel_timer:
         timer = ops.KernelTimer()
         ops.TIMER = timer
+    if args.mode == "train" and dist is not None:
+        torch.cuda.synchronize()
+        net.exchange_ms()                           # drop the warm-up steps' records
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host_s = 0.0
+    cpu0 = time.process_time()
     for _ in range(args.steps):
-        step()
+        h0 = time.perf_counter()
+        step()                                      # returns when the step is ENQUEUED: the host's share of a step
+        host_s += time.perf_counter() - h0
+    host_cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps      # CPU time of this process (all threads) per step
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER = None
     dt = sdist.max_over_ranks(dt, dist, dev)
+    host_ms = 1e3 * sdist.max_over_ranks(host_s, dist, dev) / args.steps
+    allreduce_ms = None
+    if args.mode == "train" and dist is not None and not args.graph:
+        allreduce_ms = sdist.max_over_ranks(net.exchange_ms(), dist, dev) / args.steps
 
     infer = None
     if args.mode == "train" and not args.main_only:
@@ -441,7 +482,16 @@ def main(argv=None):
                        "parallelism": f"dp{world} (independent slice shards; one RCCL all-reduce of the flat gradient "
                                       f"buffers per step)" if args.mode == "train" else
                                       f"dp{world} (independent slice shards, no data-path collective)",
-                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks, "hip_graph": bool(args.graph)},
+                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks, "hip_graph": bool(args.graph),
+                       "hip_graph_mode": getattr(graph, "mode", None) if args.graph else None,
+                       "cores_per_rank": len(my_cores) if my_cores else None},
+            # the host's share of a step (time until step() returns = everything is enqueued; max over ranks): a value close
+            # to ms_per_step means the eager step is HOST-bound on this box (then run --graph: one launch per step)
+            "host_enqueue_ms": host_ms,
+            "host_cpu_ms": host_cpu_ms,             # rank 0's CPU time per step over the same loop (all its threads)
+            # HIP events around the gradient all-reduces on the communication stream (per step, max over ranks; net_R's
+            # bucket overlaps the alignment network's backward); null on one GPU and in --graph mode
+            "allreduce_ms": allreduce_ms,
         }
         if infer is not None:
             out["inference"] = infer
@@ -453,7 +503,7 @@ def main(argv=None):
             # HBM bytes per launch, algorithmic bytes and MFMA-busy fractions from the committed PMC passes of THIS workload
             # (separate rocprofv3 --pmc runs, corrected as the file states); bench.py itself cannot run the profiler
             pmc, pmc_file = {}, None
-            for cand in ("r02_pmc.json", "r01_pmc_traffic.json"):
+            for cand in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
                     pmc_file = cand

@@ -581,6 +581,12 @@ int san_adamw_step(float* p, const float* g, float* m, float* v, size_t count, f
  * then advances it), so that a captured hipGraph of the training step replays correctly. */
 int san_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
                        float beta2, float eps, float weight_decay, long long* step_dev, float grad_scale, void* stream);
+/* ... and with (lr, weight_decay, grad_scale) read from device memory too when hyper_dev (fp32 [3]) is given: a captured
+ * step then follows a learning-rate schedule (the caller refreshes the three floats between replays; param_groups['lr'] of
+ * torch.optim.AdamW, model.py:72-81).  hyper_dev == NULL: the scalar arguments, as san_adamw_step_dev. */
+int san_adamw_step_hyper(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, long long* step_dev, float grad_scale,
+                         const float* hyper_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -68,11 +68,24 @@ def ckpt_save(ckpt: dict, folder: str) -> None:
 
 
 def _torch_load(path: str):
-    """Legacy torch-pickle checkpoints (basemodel.py:17-41 accepts them): tensors / state_dicts load with
-    weights_only=True; a pickled Config object needs the full unpickler, which executes code -- only for files you trust."""
+    """Legacy torch-pickle checkpoints (basemodel.py:17-41 accepts them).  Tensors / state_dicts load with the safe
+    unpickler (weights_only=True); a pickled ``Config`` object is allow-listed for it.  Anything else the safe loader
+    rejects is NOT retried with the full unpickler (which executes code from the file) unless the caller opts in with
+    SAN_TRUST_CHECKPOINTS=1 -- and then with a warning that names the first error."""
+    import pickle
+    import warnings
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError as first:
+        try:
+            with torch.serialization.safe_globals([Config]):
+                return torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError:
+            pass
+        if os.environ.get("SAN_TRUST_CHECKPOINTS", "0") != "1":
+            raise RuntimeError(f"{path}: the safe loader refused this checkpoint ({first}); set SAN_TRUST_CHECKPOINTS=1 to "
+                               "unpickle it with full code execution if you trust its origin") from first
+        warnings.warn(f"{path}: unpickling with full code execution (SAN_TRUST_CHECKPOINTS=1); safe loader said: {first}")
         return torch.load(path, map_location="cpu", weights_only=False)
 
 

@@ -58,7 +58,13 @@ __global__ void __launch_bounds__(256) adamw_kernel(const AdamArgs a) {
 
 // The same step with the step count in DEVICE memory (hipGraph replays cannot change kernel arguments): every thread
 // derives the bias corrections from *step + 1; adamw_count_kernel then advances the counter.
-__global__ void __launch_bounds__(256) adamw_dev_kernel(AdamArgs a, float lr, const long long* __restrict__ step) {
+__global__ void __launch_bounds__(256) adamw_dev_kernel(AdamArgs a, float lr, const long long* __restrict__ step,
+                                                        const float* __restrict__ hyper) {
+    if (hyper) {            // (lr, weight_decay, grad_scale) in device memory: a captured launch follows a learning-rate schedule
+        lr = hyper[0];
+        a.decay = 1.f - lr * hyper[1];
+        a.grad_scale = hyper[2];
+    }
     const double t = (double)(step[0] + 1);
     a.step_size = (float)((double)lr / (1.0 - pow((double)a.beta1, t)));
     a.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)a.beta2, t)));
@@ -92,6 +98,12 @@ __global__ void adamw_count_kernel(long long* step) { step[0] += 1; }
 extern "C" int san_adamw_step_dev(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
                                   float beta2, float eps, float weight_decay, long long* step_dev, float grad_scale,
                                   void* stream) {
+    return san_adamw_step_hyper(p, g, m, v, count, lr, beta1, beta2, eps, weight_decay, step_dev, grad_scale, nullptr, stream);
+}
+
+extern "C" int san_adamw_step_hyper(float* p, const float* g, float* m, float* v, size_t count, float lr, float beta1,
+                                    float beta2, float eps, float weight_decay, long long* step_dev, float grad_scale,
+                                    const float* hyper_dev, void* stream) {
     SAN_CHECK_ARG(p && g && m && v && step_dev, "null pointer");
     SAN_CHECK_ARG(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) == 0, "buffers must be 16-byte aligned");
     AdamArgs a{};
@@ -108,7 +120,7 @@ extern "C" int san_adamw_step_dev(float* p, const float* g, float* m, float* v, 
     size_t blocks = (count / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
-    if (count) hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lr, step_dev);
+    if (count) hipLaunchKernelGGL(adamw_dev_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, lr, step_dev, hyper_dev);
     hipLaunchKernelGGL(adamw_count_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     SAN_LAUNCH_CHECK();
     return SAN_OK;

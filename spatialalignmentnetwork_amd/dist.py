@@ -156,6 +156,73 @@ class GradBucket:
         self.flat.div_(dist.get_world_size())
 
 
+class GradExchange:
+    """The data-parallel gradient exchange of one training step, off the main stream.
+
+    ``launch(bucket, after)`` starts the summing all-reduce of a flat gradient buffer on a communication stream as soon
+    as its producers are done (the main stream up to the call + the streams in ``after``, i.e. the weight-gradient side
+    stream); ``wait()`` joins everything back into the main stream in front of the optimiser.  net_R's 119.8 MB go out
+    right after ``VarNet.backward`` returns and hide behind the alignment network's backward; net_T's 2.9 MB follow.
+    RCCL collectives are stream-ordered, so both calls are capturable into a hipGraph.  With gloo (CPU tests, debugging)
+    the buffer is staged through the host synchronously -- same call sites, no overlap."""
+
+    _streams = {}
+
+    def __init__(self, dist, timed: bool = False):
+        self.dist = dist
+        self.works = []
+        self.timed = timed
+        self.events = []
+        self.comm = None
+
+    def _comm(self, device):
+        key = str(device)
+        if key not in GradExchange._streams:
+            GradExchange._streams[key] = torch.cuda.Stream(device=device)
+        return GradExchange._streams[key]
+
+    def launch(self, bucket: "GradBucket", after=()) -> None:
+        if self.dist is None:
+            return
+        flat = bucket.flat
+        if not flat.is_cuda or BACKEND == "gloo":
+            if flat.is_cuda:
+                cur = torch.cuda.current_stream()
+                for s in after:
+                    if s is not None:
+                        cur.wait_stream(s)
+            bucket.allreduce_sum(self.dist)
+            return
+        cur = torch.cuda.current_stream()
+        comm = self.comm = self._comm(flat.device)
+        comm.wait_stream(cur)
+        for s in after:
+            if s is not None:
+                comm.wait_stream(s)
+        timed = self.timed and not torch.cuda.is_current_stream_capturing()
+        with torch.cuda.stream(comm):
+            e0 = e1 = None
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(comm)
+            work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True)
+            work.wait()                         # stream-level: the communication stream waits for the collective
+            if timed:
+                e1.record(comm)
+                self.events.append((e0, e1))
+        flat.record_stream(comm)
+        self.works.append(work)
+
+    def wait(self) -> None:
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+        self.works.clear()
+
+    def elapsed_ms(self) -> float:
+        """Sum of the collectives' durations on the communication stream (needs a prior synchronisation)."""
+        return float(sum(e0.elapsed_time(e1) for e0, e1 in self.events))
+
+
 class ParamBucket(GradBucket):
     """GradBucket plus flat parameter and AdamW moment buffers: every ``p.data`` becomes a view into
     ``flat_p`` (same Parameter objects, same state_dict keys and shapes), so one fused kernel

@@ -48,7 +48,8 @@ def _own_arena(fn):
 class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
-        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena"}
+        self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena", "_exchange",
+                                                         "_exchange_events", "_split_capture", "time_exchange"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -140,11 +141,17 @@ class CSModel(BaseModel):
     def _backward(self, train_T: bool) -> None:
         g_rec = ops.ssim_loss_bwd(self.img_full_rss, self.img_rec, float(self.cfg.weight_sim))
         g_warped = self.net_R.backward(g_rec, want_ref_grad=train_T)
+        exch = getattr(self, "_exchange", None)
+        if exch is not None:
+            # net_R's gradients are final (its deferred weight-gradient reductions are flushed here): their all-reduce
+            # starts now, on the communication stream, and hides behind the alignment network's backward
+            ops.wgrad_flush()
+            exch.launch(self.optim_R.bucket(), after=(ops._WG["stream"],))
         if not train_T:
             return
         off = self.net_T._last_offset_nchw
         # dL/d(offset): through warp -> rss is already folded by VarNet.backward (returns dL/d warped)
-        g_off = ops.warp_bwd_grid(self._aux_abs, self.img_grid, g_warped)
+        g_off = ops.warp_bwd_grid(self._aux_abs, self.img_grid.detach(), g_warped)
         ops.gradient_loss_bwd(off, g_off, float(self.cfg.weight_smooth), True)
         self.net_T.backward(g_off)
 
@@ -156,52 +163,96 @@ class CSModel(BaseModel):
     def _conv_mode(self) -> str:
         return self.conv_dtype or ("bf16" if self.use_amp else "bf16x3")
 
-    def _update(self):
+    def _update(self, part: str = "all"):
         """One optimisation step.  Regimes 'None' (train R, T frozen) and 'Rec' (train T and R through
         the warp), model.py:193-216; the GAN regimes are out of scope.  fp32 throughout: the
-        GradScaler of the reference's AMP path is a no-op here."""
+        GradScaler of the reference's AMP path is a no-op here.
+        part: "all", or "front" (forward + backward [+ exchange launched inside a capture]) / "back" (exchange joined,
+        optimiser steps) -- the two halves capture_update() records separately when the exchange cannot be captured."""
         assert self.training is True
         reg = self.cfg.reg
         if reg not in ("None", "Rec"):
             raise NotImplementedError(f"regime {reg!r}: the GAN branch (Mixed / GAN-Only) is out of scope")
         train_T = reg == "Rec"
-        if _active_dist() is not None and not getattr(self, "_replicas_synced", False):
-            self.sync_replicas()                # first data-parallel step: every rank starts from rank 0's state
-        self.loss_all = 0
-        if train_T:
-            self.forwardT()
-        else:
-            with torch.no_grad():
-                self.forwardT()
-            self.loss_all = 0
-        self.forwardR()
         opts = [self.optim_R] + ([self.optim_T] if train_T else [])
-        for o in opts:
-            o.zero_grad()                       # one memset of the flat gradient buffer per network
-        with ops.conv_precision(self.bwd_dtype or self._conv_mode()):
-            self.backward(train_T)              # weight gradients on a side stream, joined before the exchange / step
         dist = _active_dist()
-        scale = 1.0
-        if dist is not None:                    # data parallel: one in-place RCCL all-reduce per network;
-            for o in opts:                      # the 1/world factor rides in the optimiser kernel
-                o.bucket().allreduce_sum(dist)
-            scale = 1.0 / dist.get_world_size()
-        for o in opts:
-            o.step(grad_scale=scale)
-        del self.loss_all
+        if part in ("all", "front"):
+            if dist is not None and not getattr(self, "_replicas_synced", False):
+                # first data-parallel step: every rank starts from rank 0's state, and the inputs are rebuilt with rank 0's
+                # column mask (set_input ran before the broadcast with this rank's own draw)
+                self.sync_replicas()
+                self.set_input(self.img_full, self.img_aux)
+            self.loss_all = 0
+            if train_T:
+                self.forwardT()
+            else:
+                with torch.no_grad():
+                    self.forwardT()
+                self.loss_all = 0
+            self.forwardR()
+            for o in opts:
+                o.zero_grad()                       # one memset of the flat gradient buffer per network
+            from . import dist as sdist
+            self._exchange = None
+            if dist is not None and not getattr(self, "_split_capture", False):
+                self._exchange = sdist.GradExchange(dist, timed=getattr(self, "time_exchange", False))
+            with ops.conv_precision(self.bwd_dtype or self._conv_mode()):
+                self.backward(train_T)              # weight gradients on a side stream, joined before the exchange / step
+            if self._exchange is not None and train_T:
+                self._exchange.launch(self.optim_T.bucket())
+            del self.loss_all
+        if part in ("all", "back"):
+            exch = getattr(self, "_exchange", None)
+            if exch is not None:
+                exch.wait()
+                if exch.events:
+                    self._exchange_events = getattr(self, "_exchange_events", []) + exch.events
+                self._exchange = None
+            scale = 1.0 / dist.get_world_size() if dist is not None else 1.0   # the 1/world factor rides in the optimiser kernel
+            for o in opts:
+                o.step(grad_scale=scale)
 
-    def capture_update(self, img_full, img_aux=None, warmup: int = 3):
-        """Capture ``set_input(img_full, img_aux); update()`` into a hipGraph and return it (``graph.replay()`` runs one
-        optimisation step on whatever the two input tensors hold at that time: refill them in place between replays).
-        ~3,000 launches per step then cost one graph launch on the host.  The step count of both optimisers moves to
-        device memory (FusedAdamW.device_step); the weight gradients' side stream is captured as a fork / join.
-        Single-process only: the data-parallel all-reduce is not captured."""
+    def _exchange_eager(self):
+        """The gradient exchange between the two graphs of a split capture (gloo staging / a collective that refused to be
+        captured): both buckets, on the main stream."""
+        dist = _active_dist()
+        if dist is None:
+            return
+        for o in [self.optim_R] + ([self.optim_T] if self.cfg.reg == "Rec" else []):
+            o.bucket().allreduce_sum(dist)
+
+    def exchange_ms(self, reset: bool = True) -> float:
+        """Duration of the gradient all-reduces recorded since the last call (``time_exchange = True``; synchronise first)."""
+        ev = getattr(self, "_exchange_events", [])
+        ms = float(sum(e0.elapsed_time(e1) for e0, e1 in ev))
+        if reset:
+            self._exchange_events = []
+        return ms
+
+    def capture_update(self, img_full, img_aux=None, warmup: int = 3, restore: bool = True):
+        """Capture ``set_input(img_full, img_aux); update()`` into a hipGraph and return an object whose ``replay()`` runs
+        one optimisation step on whatever the two input tensors hold at that time (refill them in place between
+        replays).  ~2,500 launches per step then cost one graph launch on the host -- the form to use when eight ranks
+        share one host.  The step count and (lr, weight decay, gradient scale) of both optimisers move to device
+        memory (FusedAdamW.device_step / sync_hyper: change ``param_groups[0]['lr']``, call ``optim.sync_hyper()``, and
+        the next replay uses it); the weight gradients' side stream is captured as a fork / join.
+
+        Under a process group the RCCL all-reduces (stream-ordered) are captured INSIDE the graph, on the
+        communication stream.  Where that is impossible (gloo staging through the host; a collective that refuses
+        capture) the step is recorded as two graphs -- forward + backward, optimiser -- with the exchange issued eagerly
+        between them; ``replay()`` hides the difference (``.mode`` says which one it is).
+
+        ``restore`` (default): parameters, AdamW moments, step counts and BatchNorm buffers are put back to their
+        values from before the ``warmup`` real steps the capture needs (arena, packed weights, twiddles), so capturing
+        does not train on duplicated data."""
         assert self.training is True
-        if _active_dist() is not None:
-            raise NotImplementedError("capture_update with an active process group")
+        dist = _active_dist()
+        if dist is not None and not getattr(self, "_replicas_synced", False):
+            self.sync_replicas()
         for o in (self.optim_R, self.optim_T):
             o.device_step = True
             o.bucket()                          # parameters move into the flat buffers now: their addresses are final
+        snap = self._snapshot_state() if restore else None
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -211,18 +262,87 @@ class CSModel(BaseModel):
                 self.update()
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        if snap is not None:
+            self._restore_state(snap)
+            torch.cuda.synchronize()
         for reg in (ops.PACKS, ops.PACKS16):   # job tables are uploaded now, not inside the capture
             reg.ensure_table(self.device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        from . import dist as sdist
+
+        def _capture(fn):
+            graph = torch.cuda.CUDAGraph()
+            # thread_local: RCCL's watchdog thread may touch the runtime while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                fn()
+            return graph
+
+        def _whole():
             self.set_input(img_full, img_aux)
             self.update()
-        return graph
+
+        split = dist is not None and sdist.BACKEND != "nccl"
+        if not split:
+            try:
+                return CapturedStep([_capture(_whole)], None, "single-graph" + (" (RCCL all-reduce captured)" if dist is not None else ""))
+            except RuntimeError:
+                if dist is None:
+                    raise
+                split = True                    # the collective refused capture: record the two halves around it
+                torch.cuda.synchronize()
+        self._split_capture = True
+        try:
+            def _front():
+                self.set_input(img_full, img_aux)
+                with ops.use_arena(ops.owner_arena(self)), ops.conv_precision(self._conv_mode()):
+                    self._update("front")
+
+            def _back():
+                with ops.use_arena(ops.owner_arena(self)), ops.conv_precision(self._conv_mode()):
+                    self._update("back")
+
+            g1, g2 = _capture(_front), _capture(_back)
+        finally:
+            self._split_capture = False
+        return CapturedStep([g1, g2], self._exchange_eager, "two graphs around an eager exchange")
+
+    def _state_tensors(self):
+        ts = []
+        for o in (self.optim_R, self.optim_T):
+            b = o.bucket()
+            ts += [b.flat_p, b.exp_avg, b.exp_avg_sq]
+            if b.step_dev is not None:
+                ts.append(b.step_dev)
+        for mod in (self.net_T, self.net_R):
+            ts += list(mod.buffers())
+        return ts
+
+    def _snapshot_state(self):
+        return ([t.detach().clone() for t in self._state_tensors()], [o.bucket().steps for o in (self.optim_R, self.optim_T)],
+                [o.bucket().step_dev is not None for o in (self.optim_R, self.optim_T)])
+
+    def _restore_state(self, snap):
+        saved, steps, had_dev = snap
+        it = iter(saved)
+        for o, st, hd in zip((self.optim_R, self.optim_T), steps, had_dev):
+            b = o.bucket()
+            for t in (b.flat_p, b.exp_avg, b.exp_avg_sq):
+                t.copy_(next(it))
+            if hd:
+                b.step_dev.copy_(next(it))
+            elif b.step_dev is not None:
+                b.step_dev.fill_(st)            # created by the warm-up steps: back to the host count
+            b.steps = st
+        for mod in (self.net_T, self.net_R):
+            for buf in mod.buffers():
+                buf.copy_(next(it))
+        ops.bump_weight_epoch()                 # packed weight images are stale
 
     def sync_replicas(self, dist=None) -> None:
-        """Broadcast rank 0's parameters, AdamW moments, BatchNorm buffers and column mask to every rank (what DDP does
-        at construction).  Without it replicas built from per-process RNG streams would average gradients of DIFFERENT
-        models.  update() calls it before the first data-parallel step; call it again after load()."""
+        """Broadcast rank 0's parameters, AdamW moments, step counts, BatchNorm buffers and column mask to every rank
+        (what DDP does at construction).  Without it replicas built from per-process RNG streams would average
+        gradients of DIFFERENT models.  Call it BEFORE the first set_input (the sampling mask it broadcasts shapes the
+        inputs); update() calls it on the first data-parallel step if nobody did, and then re-runs set_input.  Call it
+        again after load()."""
         dist = dist or _active_dist()
         if dist is None:
             return
@@ -231,9 +351,12 @@ class CSModel(BaseModel):
             b = o.bucket()
             for t in (b.flat_p, b.exp_avg, b.exp_avg_sq):
                 sdist.broadcast0(t, dist)
-            steps = torch.tensor([b.steps], dtype=torch.int64, device=b.flat_p.device)
+            have = b.steps if b.step_dev is None else int(b.step_dev.item())
+            steps = torch.tensor([have], dtype=torch.int64, device=b.flat_p.device)
             sdist.broadcast0(steps, dist)
             b.steps = int(steps.item())
+            if b.step_dev is not None:
+                b.step_dev.fill_(b.steps)
         for mod in (self.net_T, self.net_R, self.net_mask):
             for buf in mod.buffers():
                 sdist.broadcast0(buf, dist)
@@ -283,6 +406,20 @@ class CSModel(BaseModel):
         if content in (None, "histograms"):
             vis["histograms"] = {"weights": {"values": self.net_mask.weight.detach()}}
         return vis
+
+
+class CapturedStep:
+    """What CSModel.capture_update returns: ``replay()`` runs one optimisation step."""
+
+    def __init__(self, graphs, between, mode: str):
+        self.graphs, self.between, self.mode = graphs, between, mode
+
+    def replay(self) -> None:
+        self.graphs[0].replay()
+        for g in self.graphs[1:]:
+            if self.between is not None:
+                self.between()
+            g.replay()
 
 
 def _active_dist():

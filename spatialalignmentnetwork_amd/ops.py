@@ -475,13 +475,17 @@ def adamw_step(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tenso
 
 
 def adamw_step_dev(p: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float,
-                   eps: float, weight_decay: float, step_dev: torch.Tensor, grad_scale: float = 1.0) -> None:
-    """adamw_step with the step count in device memory (int64 [1]): capture-safe (san_adamw_step_dev)."""
+                   eps: float, weight_decay: float, step_dev: torch.Tensor, grad_scale: float = 1.0,
+                   hyper_dev: Optional[torch.Tensor] = None) -> None:
+    """adamw_step with the step count in device memory (int64 [1]): capture-safe (san_adamw_step_hyper).  hyper_dev (fp32 [3]
+    = lr, weight_decay, grad_scale on the device) overrides the scalar arguments: a captured step follows a schedule."""
     for t, name in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, name=name)
     _chk(step_dev, torch.int64, "step_dev")
-    lib().call("san_adamw_step_dev", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
-               _p(step_dev), grad_scale, _stream())
+    if hyper_dev is not None:
+        assert _chk(hyper_dev, name="hyper_dev").numel() == 3
+    lib().call("san_adamw_step_hyper", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+               _p(step_dev), grad_scale, _p(hyper_dev), _stream())
 
 
 class _PackRegistry:

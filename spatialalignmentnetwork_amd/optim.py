@@ -19,6 +19,8 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW keeps one flat buffer: a single parameter group")
         self._bucket = None
         self.device_step = False      # True: keep the step count on the device (set it BEFORE capturing update() into a hipGraph)
+        self._hyper = None            # device fp32 [3] = (lr, weight_decay, grad_scale) of the graph-safe form
+        self._hyper_host = None
 
     def _params(self):
         return self.param_groups[0]["params"]
@@ -49,13 +51,33 @@ class FusedAdamW(torch.optim.Optimizer):
             if b.step_dev is None:
                 b.step_dev = torch.tensor([b.steps], dtype=torch.int64, device=b.flat_p.device)
             self.device_step = True
+            # lr / weight decay / gradient scale live in device memory too, so that a captured launch follows
+            # param_groups['lr'] (sync_hyper() refreshes them; an eager step calls it itself)
+            if not torch.cuda.is_current_stream_capturing():
+                self.sync_hyper(grad_scale)
+            elif self._hyper is None:
+                raise RuntimeError("FusedAdamW: run one eager step (or sync_hyper()) before capturing")
             ops.adamw_step_dev(b.flat_p, b.flat, b.exp_avg, b.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
-                               float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), b.step_dev, float(grad_scale))
+                               float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), b.step_dev, float(grad_scale),
+                               self._hyper)
         else:
             b.steps += 1
             ops.adamw_step(b.flat_p, b.flat, b.exp_avg, b.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),
                            float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), b.steps, float(grad_scale))
         ops.bump_weight_epoch()
+
+    def sync_hyper(self, grad_scale: float = None) -> None:
+        """Copy (lr, weight_decay, grad_scale) to the device if they changed (a stream-ordered 12-byte copy, never inside
+        a capture).  Call it after changing ``param_groups[0]['lr']`` between replays of a captured step."""
+        g = self.param_groups[0]
+        gs = self._hyper_host[2] if (grad_scale is None and self._hyper_host is not None) else float(1.0 if grad_scale is None else grad_scale)
+        want = (float(g["lr"]), float(g["weight_decay"]), gs)
+        if self._hyper is None or self._hyper.device != self.bucket().flat_p.device:
+            self._hyper = torch.empty(3, dtype=torch.float32, device=self.bucket().flat_p.device)
+            self._hyper_host = None
+        if self._hyper_host != want:
+            self._hyper.copy_(torch.tensor(want, dtype=torch.float32), non_blocking=False)
+            self._hyper_host = want
 
     def steps_taken(self) -> int:
         """Optimisation steps so far (reads the device counter in the graph-safe form: a host synchronisation)."""

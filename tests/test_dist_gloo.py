@@ -148,7 +148,9 @@ def test_bench_self_launches_under_torch_distributed_run():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
-    assert out == {"launch_test": True, "n_gpus": 2, "backend": "gloo", "max_over_ranks": 2.0, "global_batch": 16.0}
+    ncores = len(os.sched_getaffinity(0))
+    assert out == {"launch_test": True, "n_gpus": 2, "backend": "gloo", "max_over_ranks": 2.0, "global_batch": 16.0,
+                   "pinned_cores_total": 2 * (ncores // 2)}          # every rank pinned to its own share of the cores
     # the driver's own form (torch.distributed.run around bench.py) gives the same line
     port = _free_port()
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
@@ -156,6 +158,45 @@ def test_bench_self_launches_under_torch_distributed_run():
                          "--batch", "8"], env=env, capture_output=True, text=True, timeout=600)
     assert r2.returncode == 0, r2.stdout + r2.stderr
     assert [json.loads(ln) for ln in r2.stdout.splitlines() if ln.startswith("{")] == [out]
+
+
+def test_bench_launches_eight_ranks():
+    """The driver's 8-GPU form of the launcher on the CPU (gloo): eight ranks rendezvous, every rank pins itself to a
+    disjoint core set, rank 0 prints one line for the global batch of 64 (BASELINE configs[2])."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-test", "--batch", "8"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    ncores = len(os.sched_getaffinity(0))
+    assert lines == [{"launch_test": True, "n_gpus": 8, "backend": "gloo", "max_over_ranks": 8.0, "global_batch": 64.0,
+                      "pinned_cores_total": 8 * (ncores // 8)}]
+
+
+def test_pin_cores_gives_disjoint_shares():
+    import importlib.util
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    before = os.sched_getaffinity(0)
+    try:
+        world = min(4, len(before))
+        shares = []
+        for r in range(world):
+            os.sched_setaffinity(0, before)
+            shares.append(set(bench.pin_cores(r, world) or []))
+            assert os.sched_getaffinity(0) == shares[-1] or world == 1
+        if world > 1:
+            assert all(shares) and sum(len(x) for x in shares) == len(set().union(*shares))
+    finally:
+        os.sched_setaffinity(0, before)
+        torch.set_num_threads(max(1, min(len(before), 8)))
 
 
 def test_bench_refuses_a_world_size_mismatch():

@@ -727,18 +727,21 @@ def test_captured_update_matches_eager(S):
     img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
     xf, xa = g(img_full), g(img_aux)
     eager = make()
-    for _ in range(5):                                   # capture_update(warmup=2) + 3 replays = 5 steps
+    for _ in range(3):
         eager.set_input(xf, xa)
         eager.update()
     torch.cuda.synchronize()
     want = {k: v.detach().cpu().clone() for m in (eager.net_R, eager.net_T) for k, v in m.state_dict().items()}
-    assert eager.optim_R.steps_taken() == 5
+    assert eager.optim_R.steps_taken() == 3
     cap = make()
-    graph = cap.capture_update(xf, xa, warmup=2)          # 2 warm-up steps; the capture itself does not execute
+    # 2 warm-up steps, undone again (restore=True, round 3: capturing must not train on duplicated data); the capture
+    # itself does not execute
+    graph = cap.capture_update(xf, xa, warmup=2)
+    assert graph.mode.startswith("single-graph") and cap.optim_R.steps_taken() == 0
     for _ in range(3):
         graph.replay()
     torch.cuda.synchronize()
-    assert cap.optim_R.steps_taken() == 5 and cap.optim_T.steps_taken() == 5
+    assert cap.optim_R.steps_taken() == 3 and cap.optim_T.steps_taken() == 3
     got = {k: v.detach().cpu() for m in (cap.net_R, cap.net_T) for k, v in m.state_dict().items()}
     bad = [k for k in want if not torch.equal(want[k], got[k])]
     assert not bad, bad[:5]
@@ -751,6 +754,17 @@ def test_captured_update_matches_eager(S):
     eager.update()
     torch.cuda.synchronize()
     assert all(torch.equal(p.cpu(), q.cpu()) for p, q in zip(eager.net_R.parameters(), cap.net_R.parameters()))
+    # a learning-rate change between replays: lr lives in device memory next to the step count (FusedAdamW.sync_hyper)
+    for net_ in (eager, cap):
+        for o in (net_.optim_R, net_.optim_T):
+            o.param_groups[0]["lr"] = 3e-5
+            o.sync_hyper()
+    graph.replay()
+    eager.set_input(xf, xa)
+    eager.update()
+    torch.cuda.synchronize()
+    assert all(torch.equal(p.cpu(), q.cpu()) for m1, m2 in ((eager.net_R, cap.net_R), (eager.net_T, cap.net_T))
+               for p, q in zip(m1.parameters(), m2.parameters()))
 
 
 def test_mixed_backward_precision_full_320(S):
