@@ -47,7 +47,15 @@ void san_wgrad_set_parts(int parts);             // san_wgrad_bf16.hip
 // resident workgroups per CU the register allocation aims at: four for the small weights-direct forms (<= 128 registers per lane)
 #define SAN_B16_MINWG(MB, WD, KS, NP) (((WD) && (MB) == 2 && (NP) <= 2) ? 4 : 1)
 #else
-#define SAN_B16_MINWG(MB, WD, KS, NP) 1
+// SAN_B16_VGPRFORM=1: promise two resident workgroups for the weights-direct forms, so that (register budget <= 256 per lane)
+// the compiler selects the VGPR form of the MFMAs and the accumulators never visit AGPRs.  Measured (round 3, same box, N = 8):
+// 5-18 % SLOWER on every layer (18->18 @320^2 54.5 -> 57.4 us, 128->64 @160^2 123.6 -> 145.7) although the wave executes 17 % fewer
+// VALU instructions: with the accumulators in AGPRs the matrix pipe does not compete with the other waves' VALU operand
+// reads for VGPR ports.  Left off; the epilogue's redundant AGPR passes were removed at the source instead.
+#ifndef SAN_B16_VGPRFORM
+#define SAN_B16_VGPRFORM 0
+#endif
+#define SAN_B16_MINWG(MB, WD, KS, NP) ((SAN_B16_VGPRFORM && (WD) && (MB) <= 4) ? 2 : 1)
 #endif
 
 namespace {
@@ -146,7 +154,9 @@ __device__ __forceinline__ uint32_t cvt_pk_h(float f0, float f1) {
 __device__ __forceinline__ void split2h_pair(float f0, float f1, uint32_t& p1, uint32_t& p2) {
     p1 = cvt_pk_h(f0, f1);
     const hf2 h = __builtin_bit_cast(hf2, p1);
-    p2 = cvt_pk_h(f0 - (float)h[0], f1 - (float)h[1]);
+    // f - (float)h as fma((float)h, -1, f): exact either way (the difference of two floats 2^-11 apart is representable),
+    // but this form selects v_fma_mix_f32, which reads the fp16 half directly: one instruction instead of convert + subtract
+    p2 = cvt_pk_h(__builtin_fmaf((float)h[0], -1.f, f0), __builtin_fmaf((float)h[1], -1.f, f1));
 }
 __device__ __forceinline__ void split2h(float f, uint32_t& p1, uint32_t& p2) {
     const _Float16 a = (_Float16)f;
@@ -231,7 +241,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
     // ---- staging units (pixel p, channel group chg): slots 0..2 = pixel tid of group s (the group, hence the
     // lazy-affine entries, is wave-uniform there), slot 3 = the remaining 84 pixels x 3 groups
     int s_goff[kUnits], s_loff[kUnits], s_chg[kUnits];
-    bool s_in[kUnits];
+    bool s_in[kUnits], s_used[kUnits];
 #pragma unroll
     for (int s = 0; s < kUnits; ++s) {
         int p, chg;
@@ -250,22 +260,33 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
         if (KS == 1) used = used && pr >= 1 && pr <= th && pc >= 1 && pc <= tw;       // no halo
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
         s_in[s] = used && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        s_used[s] = used;
         s_goff[s] = s_in[s] ? gy * W + gx : 0;
         s_loff[s] = used ? p * kPS + chg * 16 : -1;
         s_chg[s] = chg;
     }
+    // The zero frame (halo pixels outside the image) is the same for every chunk: written ONCE here, and the staging
+    // loop below stores in-image units only -- no per-element select (8 per unit per chunk before).
+#pragma unroll
+    for (int s = 0; s < kUnits; ++s)
+        if (s_used[s] && !s_in[s]) {
+            if constexpr (F8) {
+                *reinterpret_cast<uint2*>(smem + s_loff[s]) = make_uint2(0u, 0u);
+            } else {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(smem + p * kPartB + s_loff[s]) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
 
     float st[kUnits][8];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 wst[WSL];                                   // (a plain vector type: the struct uint4 copy kept this array in scratch)
-    const float* xs[kUnits];                          // slot's pixel in channel 0 of this sample's view
-#pragma unroll
-    for (int s = 0; s < kUnits; ++s) xs[s] = a.x + (size_t)(n * a.x_ctot + a.x_coff) * HWp + s_goff[s];
     // The chunk's lazy affine (24 scales + 24 shifts of this sample) travels through a double-buffered LDS
     // table: thread t < 48 fetches ONE value with the tile and stores it during the previous chunk's staging
     // phase (two barriers before anyone reads it) -- not 64 loads per thread per chunk.
     float* lds_aff = reinterpret_cast<float*>(smem + NP * kPartB + (WD ? (size_t)0 : (size_t)WCH * 16));
     const bool has_aff = a.in_scale != nullptr;
+    const float lrelu_c = a.in_slope <= 1.f ? __builtin_inff() : -__builtin_inff();     // see the staging loop
     float my_aff = 0.f;
     // gradient input in the fp16 format: x S (S = 2^(13 - floor(log2 max |x|)), exact) rides in the affine table, the
     // accumulators get 1 / S at the end
@@ -292,12 +313,35 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             my_aff = has_aff ? src[n * a.x_ctot + a.x_coff + ci] * inS : (tid < 24 ? inS : 0.f);
         }
     };
+    // Loads go through a buffer descriptor of this sample's view (base = its first channel): the address of a load is
+    // descriptor base + SGPR offset (the channel: wave-uniform for slots 0..2, so it costs one scalar multiply) + 32-bit
+    // per-lane offset (the pixel) -- no 64-bit vector address arithmetic per load (it was one v_lshl_add_u64 each, 32 per chunk).
+    const unsigned hw4 = (unsigned)HWp * 4u;
+    __amdgpu_buffer_rsrc_t xrs;
+    {
+        const size_t ext = (size_t)(a.x_ctot - a.x_coff) * (size_t)HWp * 4;            // to the end of this sample
+        xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)(n * a.x_ctot + a.x_coff) * HWp), 0,
+                                                (int)(ext > 0x7fffffffu ? 0x7fffffffu : ext), 0x00020000);
+    }
+    unsigned s_boff[kUnits];
+#pragma unroll
+    for (int s = 0; s < kUnits; ++s) s_boff[s] = (unsigned)s_goff[s] * 4u;
     auto prefetch = [&](int chunk) {
 #pragma unroll
         for (int s = 0; s < kUnits; ++s) {
-            const int c0 = chunk * kCKC + s_chg[s] * 8;
+            if (s < 3) {
+                const int c0 = chunk * kCKC + s * 8;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) st[s][i] = xs[s][min(c0 + i, a.cin - 1) * HWp];
+                for (int i = 0; i < 8; ++i)
+                    st[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             xrs, (int)s_boff[s], (int)((unsigned)min(c0 + i, a.cin - 1) * hw4), 0));
+            } else {
+                const int c0 = chunk * kCKC + s_chg[s] * 8;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    st[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             xrs, (int)(s_boff[s] + (unsigned)min(c0 + i, a.cin - 1) * hw4), 0, 0));
+            }
         }
         fetch_aff(chunk + 1);                         // stored as the next table during this chunk's staging phase
         if constexpr (!WD) {
@@ -388,10 +432,16 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             const f4 sh0 = *reinterpret_cast<const f4*>(afc + 24 + s_chg[s] * 8), sh1 = *reinterpret_cast<const f4*>(afc + 24 + s_chg[s] * 8 + 4);
 #pragma unroll
             for (int i = 0; i < 8; i += 2) {
-                const float sca = i < 4 ? sc0[i] : sc1[i - 4], scb = i < 4 ? sc0[i + 1] : sc1[i - 3];
-                const float sha = i < 4 ? sh0[i] : sh1[i - 4], shb = i < 4 ? sh0[i + 1] : sh1[i - 3];
-                const float v0 = s_in[s] ? san_act(st[s][i], sca, sha, a.in_slope) : 0.f;
-                const float v1 = s_in[s] ? san_act(st[s][i + 1], scb, shb, a.in_slope) : 0.f;
+                // two elements at a time on the packed fp32 pipe: affine (v_pk_fma_f32), slope product (v_pk_mul_f32), then
+                // LeakyReLU as one v_med3_f32 per element: med3(v, slope v, +inf) = max(v, slope v) for slope <= 1,
+                // med3(v, slope v, -inf) = min(v, slope v) for slope > 1 -- the reference's leaky_relu for every slope
+                const fl2 xv = {st[s][i], st[s][i + 1]};
+                const fl2 scv = {i < 4 ? sc0[i] : sc1[i - 4], i < 4 ? sc0[i + 1] : sc1[i - 3]};
+                const fl2 shv = {i < 4 ? sh0[i] : sh1[i - 4], i < 4 ? sh0[i + 1] : sh1[i - 3]};
+                const fl2 av = __builtin_elementwise_fma(xv, scv, shv);
+                const fl2 sv = av * fl2{a.in_slope, a.in_slope};
+                const float v0 = __builtin_amdgcn_fmed3f(av[0], sv[0], lrelu_c);
+                const float v1 = __builtin_amdgcn_fmed3f(av[1], sv[1], lrelu_c);
                 if constexpr (F8) {
                     vv[i] = v0;
                     vv[i + 1] = v1;
@@ -403,9 +453,9 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                 }
             }
             if constexpr (F8) {
-                if (s_loff[s] >= 0)
+                if (s_in[s])
                     *reinterpret_cast<uint2*>(lds_a + s_loff[s]) = make_uint2(cvt_f8x4(vv[0], vv[1], vv[2], vv[3]), cvt_f8x4(vv[4], vv[5], vv[6], vv[7]));
-            } else if (s_loff[s] >= 0) {
+            } else if (s_in[s]) {
                 *reinterpret_cast<uint4*>(lds_a + s_loff[s]) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
                 if constexpr (NP > 1) *reinterpret_cast<uint4*>(lds_a + kPartB + s_loff[s]) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
                 if constexpr (NP > 2) *reinterpret_cast<uint4*>(lds_a + 2 * kPartB + s_loff[s]) = make_uint4(q3[0], q3[1], q3[2], q3[3]);
@@ -528,13 +578,17 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
         a.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // XCC_ID
     }
 #endif
-    if constexpr (F16 || F8) {
-        if (F8 || a.amax) {
+    // The matrix cores leave the accumulators in AGPRs.  The power-of-two rescale of the fp16 / fp8 formats is applied
+    // UNCONDITIONALLY (x 1 where there is none: exact): a run-time `if` around an in-place update made the compiler keep the
+    // array in AGPRs across the whole epilogue, and every later use (bias, statistics, stores) paid a v_accvgpr_read pass
+    // plus a write-back (four reads + two writes over all accumulators); now there is one read pass.
+    {
+        float osc = 1.f;
+        if constexpr (F16 || F8) osc = (F8 || a.amax) ? inInvS : 1.f;
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[m][b] *= inInvS;
-        }
+            for (int b = 0; b < 4; ++b) acc[m][b] = acc[m][b] * osc;
     }
     if constexpr (SWAP) {
         // acc[m][b][r] = output channel (cg MB + m) 16 + nn at the tile pixel r places after pixel 64 wave + 16 b + 4 kg

@@ -562,6 +562,41 @@ def make_train_full(with_f64=True):
     save("train_full_320.npz", **out)
 
 
+def make_train_n8(with_f64=True):
+    """The BENCH batch: one 'Rec' train step at N = 8, 320 x 320, 12 cascades, chans 18 (BASELINE configs[1]; model.py:206-216)
+    with the 'damped' weight set (cascade output convolutions x 0.1: behaves like a trained network, fp32 noise near 1e-6),
+    fp32 as the reference runs it + the fp64 arbiter.  Stored as digests: losses, per-tensor gradient L2 norms + 16 probes,
+    and the reconstruction at every second row / column (+ per-slice L2 norms of the full images)."""
+    import time
+    out = {}
+    n = 8
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        if tag == "f64" and not with_f64:
+            continue
+        t0 = time.time()
+        net_T, net_R, res = _rec_step(n, 1, 320, 320, 0.25, 12, seed=4234, dtype=dt, damp=0.1)
+        print(f"[n8 {tag}] reference step: {time.time() - t0:.0f} s")
+        _digest_step(out, f"{tag}.", net_T, net_R, res)
+        rec = res["img_rec"].detach()
+        out[f"{tag}.img_rec_s2"] = rec[:, :, ::2, ::2].contiguous().numpy()
+        out[f"{tag}.img_rec_l2"] = rec.double().pow(2).sum((1, 2, 3)).sqrt().numpy()
+        out[f"{tag}.img_warped_l2"] = res["img_warped"].detach().double().pow(2).sum((1, 2, 3)).sqrt().numpy()
+        if tag == "f32":
+            keep = (net_T, net_R, rec)
+            for nm, buf in net_T.named_buffers():
+                if nm.endswith(("running_mean", "running_var")):
+                    out["f32.bn_after.T." + nm] = buf.numpy()
+        else:
+            for nt, a, b in (("T", keep[0], net_T), ("R", keep[1], net_R)):
+                num = sum(((p.grad.double() - q.grad) ** 2).sum().item() for p, q in zip(a.parameters(), b.parameters()))
+                den = sum((q.grad ** 2).sum().item() for q in b.parameters())
+                out[f"ref32_vs_ref64.grad.{nt}"] = np.float64((num / den) ** 0.5)
+                print(f"[n8] reference fp32 vs fp64 gradients, net_{nt}: relative L2 {(num / den) ** 0.5:.3e}")
+            out["ref32_vs_ref64.img_rec"] = np.float64(((keep[2].double() - rec).norm() / rec.norm()).item())
+            print("[n8] reference fp32 vs fp64 rec:", out["ref32_vs_ref64.img_rec"])
+    save("train_n8_320.npz", **out)
+
+
 def make_multicoil():
     """Config 4: one 640 x 368 slice with 15 coils, 8x equispaced mask (46 kept columns, nlf = 14), sensitivity-map
     VarNet with 12 cascades + the 30-channel alignment net.  (a) eval forward with fp64 arbiter; (b) a 2-cascade train
@@ -663,7 +698,7 @@ def run_pair_full(n, c, h, w, sparsity, num_cascades, seed, training):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "small", "full", "augment", "metrics", "ckpt", "layers", "pad", "scalars", "train_full",
-                             "multicoil", "autograd"]
+                             "multicoil", "autograd", "train_n8"]
     with torch.no_grad():
         if "ops" in which:
             make_ops()
@@ -690,3 +725,5 @@ if __name__ == "__main__":
         make_multicoil()
     if "autograd" in which:
         make_autograd()
+    if "train_n8" in which:
+        make_train_n8()
