@@ -2,7 +2,7 @@
 #   SAN_B16_ABL bit 1 = no activation loads, 2 = no weight loads, 4 = no K-loop, 8 = no statistics, 16 = no stores
 cp spatialalignmentnetwork_amd/libsan_hip.so /tmp/keep.so
 cp scratch/libs/abl.so spatialalignmentnetwork_amd/libsan_hip.so
-for m in 0 1 2 4 8 16 17 3 6 7 24 28 31; do
+for m in ${ABLS:-0 31 63 127 95 255 223 160 64 32}; do
   echo "== ABL=$m"; SAN_B16_ABL=$m BL_ONLY=${1:-18-18-320,36-18-320,72-36-160,144-72-80} python scratch/bench_layers.py conv 2>/dev/null | grep "@"
 done
 cp /tmp/keep.so spatialalignmentnetwork_amd/libsan_hip.so

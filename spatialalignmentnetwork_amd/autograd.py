@@ -243,8 +243,23 @@ class _VarNetFn(Function):
         return (None, None, None, g_ref if want_ref else None, None) + (None,) * ctx.nparams
 
 
+def _trainable(mod):
+    """The module's parameters that require gradients (memoised: walking 300-odd parameters per forward was 2 ms of host
+    time per training step; the key notices requires_grad_() / parameter replacement through the list's identity set)."""
+    hit = mod.__dict__.get("_san_trainable")
+    plist = mod.__dict__.get("_san_plist")
+    if plist is None:
+        plist = list(mod.parameters())
+        object.__setattr__(mod, "_san_plist", plist)
+    flags = tuple(p.requires_grad for p in plist)
+    if hit is None or hit[0] != flags:
+        hit = (flags, tuple(p for p in plist if p.requires_grad))
+        object.__setattr__(mod, "_san_trainable", hit)
+    return hit[1]
+
+
 def varnet_forward(net, masked_kspace, mask, ref, nlf):
-    params = tuple(p for p in net.parameters() if p.requires_grad)
+    params = _trainable(net)
     if torch.is_grad_enabled() and (params or _needs_grad(ref)):
         if _needs_grad(masked_kspace):
             raise NotImplementedError("VarNet: no gradient path wrt the measured k-space (it is data)")
@@ -283,7 +298,7 @@ class _AlignFn(Function):
 
 
 def align_forward(st, moving, fixed):
-    params = tuple(p for p in st.parameters() if p.requires_grad)
+    params = _trainable(st)
     if torch.is_grad_enabled() and params:
         if _needs_grad(moving, fixed):
             raise NotImplementedError("SpatialTransformer: no gradient path wrt the input images (they are data)")

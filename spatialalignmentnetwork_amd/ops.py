@@ -168,7 +168,8 @@ class Arena:
         self._retired = []
 
     def get(self, name: str, shape, device, dtype=torch.float32, zero: bool = False, _no_wait: bool = False) -> torch.Tensor:
-        key = (name, tuple(int(s) for s in shape), _dev_key(device), dtype)
+        # (shapes arrive as tuples of Python ints or torch.Size: both hash / compare equal to the int tuple)
+        key = (name, shape if type(shape) is tuple else tuple(shape), _DEV_KEYS.get(device) or _dev_key(device), dtype)
         t = self._bufs.get(key)
         if t is None:
             t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
@@ -195,12 +196,21 @@ class Arena:
         self._bufs.clear()
 
 
+_DEV_KEYS: Dict[object, str] = {}
+
+
 def _dev_key(device) -> str:
-    """'cuda' and 'cuda:0' name the same device: buffers and pools are keyed by the resolved form."""
+    """'cuda' and 'cuda:0' name the same device: buffers and pools are keyed by the resolved form (memoised: this sits on
+    the path of every arena request, thousands per training step)."""
+    try:
+        return _DEV_KEYS[device]
+    except KeyError:
+        pass
     d = torch.device(device)
     if d.type == "cuda" and d.index is None:
-        d = torch.device("cuda", torch.cuda.current_device())
-    return str(d)
+        return str(torch.device("cuda", torch.cuda.current_device()))      # depends on the current device: not memoised
+    _DEV_KEYS[device] = str(d)
+    return _DEV_KEYS[device]
 
 
 # Arenas have OWNERS.  Every CSModel (and every VarNet / SpatialTransformer used on its own) keeps its activation tapes in an
@@ -1187,19 +1197,44 @@ def wgrad_dy_buffer(name: str, shape, device, arena: Arena = GLOBAL_ARENA) -> to
     return first
 
 
+class _EventRing:
+    """Reusable events for the main <-> side stream hand-offs (creating a torch.cuda.Event per hand-off, two per weight
+    gradient, ~650 per step, was ~1 ms of host time).  A stream wait captures the event's LAST record at the time of the
+    call, so an event may be recorded again once its waits have been issued; the ring is far longer than a step."""
+
+    def __init__(self, n: int = 4096):
+        self.n, self.i, self.ev = n, 0, {}
+
+    def next(self) -> "torch.cuda.Event":
+        dev = torch.cuda.current_device()
+        ring = self.ev.get(dev)
+        if ring is None:
+            ring = self.ev[dev] = [torch.cuda.Event() for _ in range(self.n)]
+        self.i = (self.i + 1) % self.n
+        return ring[self.i]
+
+
+_EVENTS = _EventRing()
+
+
 def _on_side_stream(dy: Act, x: Act, fn) -> None:
     side = _WG["stream"]
     if side is None:
         fn()
         return
     main = _WG["main"]
-    side.wait_stream(main)                      # the operands' producers are queued on main up to here
+    if torch.cuda.is_current_stream_capturing():
+        side.wait_stream(main)                  # (capture: fresh events, the graph keeps them as edges)
+    else:
+        e0 = _EVENTS.next()
+        e0.record(main)                         # the operands' producers are queued on main up to here
+        side.wait_event(e0)
     _STREAM_OVERRIDE[0] = side                  # (launches take the side stream's handle; torch's current stream stays put)
     try:
         fn()
     finally:
         _STREAM_OVERRIDE[0] = None
-    ev = torch.cuda.Event()
+    ev = torch.cuda.Event() if torch.cuda.is_current_stream_capturing() else _EVENTS.next()
     ev.record(side)
     _WG["busy"][dy.buf.data_ptr()] = ev
     dy.buf.record_stream(side)
