@@ -1,4 +1,4 @@
-"""gpurun_out/<tag>_pmc_raw.json (scratch/prof_r02.sh) -> profiles/<tag>_pmc.json.
+"""gpurun_out/<tag>_pmc_raw.json (scratch/prof_round.sh) -> profiles/<tag>_pmc.json.
 
 HBM bytes per launch: FETCH_SIZE / WRITE_SIZE are reported in KiB of 64-byte fabric requests; on gfx950 a wide coalesced
 read is tallied at half its bytes (MI355X_MICROARCH.md, HBM section), other widths are uncalibrated -> the factors are
@@ -55,7 +55,7 @@ for a, b in alias.items():
 if "dc_rows" in kern and "hbm_bytes_per_launch" in kern["dc_rows"]:
     kern["fft_dc"] = dict(kern["dc_rows"], note="the image-domain cascade kernel (forward launches with and without dk_out, and the backward form)")
 out = {"note": "rocprofv3 --pmc passes of scratch/pmc_traffic.py (calibration kernels + 3 train steps at N = 8, 320 x 320, 12 cascades), "
-               "each counter set in its own run with --kernel-trace only (scratch/prof_r02.sh); corrected by scratch/pmc_r02_finalize.py",
+               "each counter set in its own run with --kernel-trace only (scratch/prof_round.sh); corrected by scratch/pmc_round_finalize.py",
        "calibration": cal, "fetch_factor": {"16B_per_lane": f16, "8B_per_lane": f8, "4B_per_lane": f4}, "write_factor": {"16B_per_lane": wf, "4B_per_lane": wf4},
        "mfma_busy_definition": "SQ_VALU_MFMA_BUSY_CYCLES / ((GRBM_GUI_ACTIVE / 8 XCDs) * 1024 SIMDs), summed over the family's launches",
        "kernels": kern}

@@ -3,8 +3,8 @@
 #       weight gradients in line (SAN_NO_WGRAD_OVERLAP=1 --main-only: the per-step kernel budget);
 #   (2) PMC passes of scratch/pmc_traffic.py (calibration kernels + 3 train steps), each in its own run with
 #       --kernel-trace only: FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
-# Results land in gpurun_out/r02_*; scratch/pmc_r02_finalize.py turns the raw PMC json into profiles/r02_pmc.json.
-TAG=${1:-r02}
+# Results land in gpurun_out/r02_*; scratch/pmc_round_finalize.py turns the raw PMC json into profiles/r02_pmc.json.
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
