@@ -172,6 +172,14 @@ int san_bwd_stat_tiles(int hw);
 int san_plane_dot_stats(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                         const float* sc, const float* sh, float slope, float* part,
                         int n, int c, int hw, void* stream);
+/* san_act_bwd_amax with a destination mode.  flags & 1: dy is stored pixel-UNSHUFFLED as [n, d_ctot, h/2, w/2], channel
+ * d_coff + 4 ch + 2 (row & 1) + (col & 1) -- the backward of ConvTranspose2d as a 1x1 convolution to 4 Cout virtual channels
+ * (varnet.py:176-182) wants dy in that order, and a separate san_unshuffle2_fwd pass over the tensor is saved (w = plane width,
+ * w % 4 == 0, even height, 16-byte aligned g / y).  flags & 2: dy += (gradient accumulation, e.g. dL/d ref over the cascades,
+ * varnet.py:478-484).  amax may be NULL. */
+int san_act_bwd_ex_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
+                        const float* sc, const float* sh, float slope, int mode, float* part,
+                        float* dy, int d_ctot, int d_coff, void* amax, int n, int c, int hw, int w, int flags, void* stream);
 int san_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                 const float* sc, const float* sh, float slope, int mode, float* part,
                 float* dy, int d_ctot, int d_coff, int n, int c, int hw, void* stream);

@@ -694,6 +694,39 @@ __device__ __forceinline__ bf4 g2_add(bf4 gv, const float* __restrict__ q, int i
     return gv;
 }
 
+// Where dy goes.  shuf: the pixel un-shuffle of the transposed convolution's backward folded into the store -- dy of the
+// [n, C, h, w] activation lands as [n, 4 C, h/2, w/2] with channel 4 c + 2 (row & 1) + (col & 1) (what san_unshuffle2_fwd
+// produced in a second pass over the tensor): a lane's four consecutive pixels are two pairs of neighbouring positions in
+// two destination planes, i.e. two 8-byte stores.  acc: add to what dy holds (gradient accumulation across cascades).
+struct DyDst {
+    int shuf, acc;
+    int w4;                // plane width / 4
+    float inv_w4;
+};
+__device__ __forceinline__ void dy_store(float* __restrict__ base, int i, bf4 o, const DyDst d) {
+    // base: the (n, channel) plane of dy in the plain form; the (n, 4 * channel) plane in the shuffled form
+    if (!d.shuf) {
+        bf4* q = reinterpret_cast<bf4*>(base) + i;
+        if (d.acc) o += *q;
+        *q = o;
+        return;
+    }
+    typedef float bf2 __attribute__((ext_vector_type(2)));
+    const int row = (int)(((float)i + 0.5f) * d.inv_w4);            // exact for i < 2^22
+    const int c4 = i - row * d.w4;                                  // pixels 4 c4 .. 4 c4 + 3 of image row `row`
+    // half-resolution plane: width 2 w4, this row's positions 2 c4, 2 c4 + 1; channel offset 2 (row & 1) + dx
+    float* q = base + (size_t)(row >> 1) * (2 * d.w4) + 2 * c4;
+    bf2 e = bf2{o[0], o[2]}, f = bf2{o[1], o[3]};
+    float* qe = q + (size_t)(2 * (row & 1)) * d.shuf;               // d.shuf = elements per destination plane (h/2 * w/2)
+    float* qf = qe + d.shuf;
+    if (d.acc) {
+        e += *reinterpret_cast<bf2*>(qe);
+        f += *reinterpret_cast<bf2*>(qf);
+    }
+    *reinterpret_cast<bf2*>(qe) = e;
+    *reinterpret_cast<bf2*>(qf) = f;
+}
+
 // InstanceNorm + LeakyReLU backward of a whole (sample, channel) plane in ONE pass: the plane's g and y (<= V float4 per
 // thread each, 512 threads) stay in registers between the two reductions and the write of dy, so g and y are read once
 // instead of twice and there is one launch instead of two.  Planes of up to 512 * 4 * V values (V = 13: 160 x 160).
@@ -702,7 +735,7 @@ __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restr
                                                             const float* __restrict__ y, int y_ctot, int y_coff,
                                                             const float* __restrict__ sc, const float* __restrict__ sh, float slope,
                                                             float* __restrict__ dy, int d_ctot, int d_coff, int hw, unsigned* amax,
-                                                            const G2Src g2) {
+                                                            const G2Src g2, const DyDst dd) {
     __shared__ float red[16];
     const int ch = blockIdx.x, n = blockIdx.y;
     const float* q2 = g2.p ? g2.p + ((size_t)(n * g2.ctot + g2.coff + ch)) * (hw >> 2) : nullptr;
@@ -710,7 +743,8 @@ __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restr
     const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
     const bf4* gp = reinterpret_cast<const bf4*>(g + ((size_t)(n * g_ctot + g_coff + ch)) * hw);
     const bf4* yp = reinterpret_cast<const bf4*>(y + ((size_t)(n * y_ctot + y_coff + ch)) * hw);
-    bf4* dp = reinterpret_cast<bf4*>(dy + ((size_t)(n * d_ctot + d_coff + ch)) * hw);
+    // (shuffled form: d_ctot / d_coff count the 4 C destination channels of hw / 4 elements each: the same byte offset)
+    float* dp = dy + (dd.shuf ? ((size_t)(n * d_ctot + d_coff + 4 * ch)) * (hw >> 2) : ((size_t)(n * d_ctot + d_coff + ch)) * hw);
     const int n4 = hw >> 2;
     bf4 u[V], yh[V];
     float s1 = 0.f, s2 = 0.f;
@@ -759,7 +793,7 @@ __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restr
                 o[e] = s * (u[k][e] - m1 - yh[k][e] * m2);
                 mx = fmaxf(mx, fabsf(o[e]));
             }
-            dp[i] = o;
+            dy_store(dp, i, o, dd);
         }
     }
     san_amax_record<8>(amax, blockIdx.y * gridDim.x + blockIdx.x, mx);
@@ -826,7 +860,7 @@ __global__ void __launch_bounds__(kThreads)
 act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
                const float* __restrict__ sc, const float* __restrict__ sh, float slope, const float* __restrict__ part,
                int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, unsigned* amax,
-               const G2Src g2) {
+               const G2Src g2, const DyDst dd) {
     const int ch = blockIdx.y, n = blockIdx.z;
     const float* q2 = g2.p ? g2.p + ((size_t)(n * g2.ctot + g2.coff + ch)) * (hw >> 2) : nullptr;
     const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
@@ -844,9 +878,9 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
     }
     const float* gp = g + ((size_t)(n * g_ctot + g_coff + ch)) * hw;
     const float* yp = y + ((size_t)(n * y_ctot + y_coff + ch)) * hw;
-    float* dp = dy + ((size_t)(n * d_ctot + d_coff + ch)) * hw;
+    float* dp = dy + (dd.shuf ? ((size_t)(n * d_ctot + d_coff + 4 * ch)) * (hw >> 2) : ((size_t)(n * d_ctot + d_coff + ch)) * hw);
     float mx = 0.f;
-    if ((hw & 3) == 0 && ((((uintptr_t)gp | (uintptr_t)yp | (uintptr_t)dp)) & 15) == 0) {
+    if ((hw & 3) == 0 && ((((uintptr_t)gp | (uintptr_t)yp | (dd.shuf ? (uintptr_t)0 : (uintptr_t)dp))) & 15) == 0) {
         for (int i = blockIdx.x * kThreads + threadIdx.x; i < (hw >> 2); i += gridDim.x * kThreads) {
             bf4 gv = reinterpret_cast<const bf4*>(gp)[i];
             const bf4 yv = reinterpret_cast<const bf4*>(yp)[i];
@@ -859,7 +893,7 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
                 o[e] = s * (u - m1 - yh * m2);
                 mx = fmaxf(mx, fabsf(o[e]));
             }
-            reinterpret_cast<bf4*>(dp)[i] = o;
+            dy_store(dp, i, o, dd);
         }
         san_amax_record<kThreads / 64>(amax, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, mx);
         return;
@@ -867,7 +901,7 @@ act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float*
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < hw; i += gridDim.x * kThreads) {
         const float yh = fmaf(yp[i], s, b);
         const float u = gp[i] * (yh >= 0.f ? 1.f : slope);
-        const float o = s * (u - m1 - yh * m2);
+        const float o = s * (u - m1 - yh * m2) + (dd.acc ? dp[i] : 0.f);      // (the shuffled form always takes the vector path: host check)
         dp[i] = o;
         mx = fmaxf(mx, fabsf(o));
     }
@@ -1418,8 +1452,16 @@ int san_bwd_stat_tiles(int hw) {
 static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
                         const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, int n, int c,
                         int hw, unsigned* amax, void* stream, const float* g2 = nullptr, int g2_ctot = 0,
-                        int g2_coff = 0, float g2_scale = 0.f, int w = 0) {
+                        int g2_coff = 0, float g2_scale = 0.f, int w = 0, int flags = 0) {
     SAN_CHECK_ARG(g && y && dy, "null pointer");
+    DyDst dd{0, (flags & 2) ? 1 : 0, 1, 1.f};
+    if (flags & 1) {
+        // un-shuffled destination [n, d_ctot, h/2, w/2]: channels [d_coff, d_coff + 4 c)
+        SAN_CHECK_ARG(w > 0 && (w & 3) == 0 && hw % w == 0 && ((hw / w) & 1) == 0 && (hw >> 2) < (1 << 22), "shuffled store: width % 4 == 0, even height");
+        SAN_CHECK_ARG(((((uintptr_t)g | (uintptr_t)y)) & 15) == 0 && ((uintptr_t)dy & 7) == 0, "shuffled store: 16-byte aligned inputs, 8-byte aligned destination");
+        SAN_CHECK_ARG(d_coff >= 0 && d_coff + 4 * c <= d_ctot, "bad channel view (shuffled destination)");
+        dd = DyDst{hw >> 2, dd.acc, w >> 2, 1.f / (float)(w >> 2)};
+    }
     G2Src q{nullptr, 0, 0, 0.f, 1, 1.f};
     if (g2) {
         SAN_CHECK_ARG(w > 0 && (w & 3) == 0 && hw % w == 0 && ((hw / w) & 1) == 0, "second gradient source: width % 4 == 0, even height");
@@ -1433,15 +1475,15 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
     SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
     SAN_CHECK_ARG(mode == 0 || part != nullptr, "instance-norm backward needs the partial buffer");
     SAN_CHECK_ARG(g_coff >= 0 && g_coff + c <= g_ctot && y_coff >= 0 && y_coff + c <= y_ctot && d_coff >= 0 &&
-                      d_coff + c <= d_ctot, "bad channel view");
+                      (dd.shuf || d_coff + c <= d_ctot), "bad channel view");
     hipStream_t s = (hipStream_t)stream;
     const int tiles = san_bwd_stat_tiles(hw);
     if (mode == 1 && (hw & 3) == 0 && hw <= 512 * 4 * 13 && g_act_bwd_fused &&
-        ((((uintptr_t)g | (uintptr_t)y | (uintptr_t)dy)) & 15) == 0) {
+        ((((uintptr_t)g | (uintptr_t)y | (dd.shuf ? (uintptr_t)0 : (uintptr_t)dy))) & 15) == 0) {
         // the whole plane fits one workgroup's registers: statistics and gradient in one pass
         const int v = san_cdiv(hw >> 2, 512);
         const dim3 grid(c, n);
-#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw, amax, q)
+#define SAN_ABP(V) hipLaunchKernelGGL((act_bwd_plane_kernel<V>), grid, dim3(512), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw, amax, q, dd)
         if (v <= 1) SAN_ABP(1);
         else if (v <= 2) SAN_ABP(2);
         else if (v <= 4) SAN_ABP(4);
@@ -1462,7 +1504,7 @@ static int act_bwd_impl(const float* g, int g_ctot, int g_coff, const float* y, 
     if (bx > cap) bx = (int)cap;
     if (bx < 1) bx = 1;
     hipLaunchKernelGGL(act_bwd_kernel, dim3(bx, c, n), dim3(kThreads), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc,
-                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw, amax, q);
+                       sh, slope, part, tiles, mode, dy, d_ctot, d_coff, c, hw, amax, q, dd);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }
@@ -1489,6 +1531,17 @@ int san_act_bwd_up_amax(const float* g, int g_ctot, int g_coff, const float* g2,
     SAN_CHECK_ARG(g2 != nullptr, "null second source");
     return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw,
                         static_cast<unsigned*>(amax), stream, g2, g2_ctot, g2_coff, g2_scale, w);
+}
+
+// san_act_bwd_amax with a destination mode (flags): 1 = dy is stored pixel-UNSHUFFLED as [n, d_ctot, h/2, w/2], channel
+// d_coff + 4 ch + 2 (row & 1) + (col & 1) (the transposed convolution's backward: san_unshuffle2_fwd folded into the store; w =
+// plane width, w % 4 == 0, even height); 2 = dy += (accumulate).  amax may be NULL.
+int san_act_bwd_ex_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc,
+                        const float* sh, float slope, int mode, float* part, float* dy, int d_ctot, int d_coff, void* amax,
+                        int n, int c, int hw, int w, int flags, void* stream) {
+    SAN_CHECK_ARG((flags & ~3) == 0, "flags: 1 = shuffled store, 2 = accumulate");
+    return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw,
+                        static_cast<unsigned*>(amax), stream, nullptr, 0, 0, 0.f, w, flags);
 }
 
 // uint32 words of one amax record (see san_common.h)

@@ -1333,6 +1333,26 @@ def act_bwd_up_ok(y: Act) -> bool:
     return (y.h & 1) == 0 and (y.w & 3) == 0 and y.h * y.w // 4 < (1 << 22)
 
 
+def act_bwd_ex(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA, unshuffle: bool = False,
+               accumulate: bool = False) -> None:
+    """act_bwd with a destination mode (san_act_bwd_ex_amax).  unshuffle: dy is a [n, 4c, h/2, w/2] view and receives the
+    gradient pixel-unshuffled (channel 4 ch + 2 (row & 1) + (col & 1)): the transposed convolution's backward without the
+    separate un-shuffle pass.  accumulate: dy += ."""
+    assert g.c == y.c and (dy.c == 4 * y.c if unshuffle else dy.c == y.c)
+    hw = y.h * y.w
+    part = None
+    if instance_norm:
+        part = arena.get("bwd_part", (y.n, y.c, lib().query("san_bwd_stat_tiles", hw), 2), y.buf.device)
+    dy.amax = AMAX.next(y.buf.device)
+    lib().call("san_act_bwd_ex_amax", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+               float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, y.w,
+               (1 if unshuffle else 0) | (2 if accumulate else 0), _stream())
+
+
+def act_bwd_unshuffle_ok(y: Act) -> bool:
+    return (y.h & 1) == 0 and (y.w & 3) == 0 and y.h * y.w // 4 < (1 << 22) and y.buf.data_ptr() % 16 == 0
+
+
 def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA, g2: Optional[Act] = None,
             g2_scale: float = 0.25) -> None:
     """Gradient through y's lazy (scale, shift, LeakyReLU) read: g = dL/d(activation) -> dy = dL/dy_raw.

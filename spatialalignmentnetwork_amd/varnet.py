@@ -111,10 +111,14 @@ class TransposeConvBlock(nn.Module):
         wt = self.layers[0].weight                       # [Cin, Cout, 2, 2]
         cin, cout = wt.shape[0], wt.shape[1]
         n, h, w, dev = x.n, x.h, x.w, x.buf.device
-        dyt = Act(ARENA.get("bwd.dyt", (n, cout, 2 * h, 2 * w), dev), 0, cout)
-        ops.act_bwd(g_out, out, dyt, instance_norm=True)
         dyp = Act(ops.wgrad_dy_buffer("bwd.dyp", (n, 4 * cout, h, w), dev, ARENA), 0, 4 * cout)
-        ops.unshuffle2(dyt, dyp)
+        if ops.act_bwd_unshuffle_ok(out) and g_out.buf.data_ptr() % 16 == 0:
+            # the activation backward writes dy pixel-unshuffled itself (no second pass over the tensor)
+            ops.act_bwd_ex(g_out, out, dyp, instance_norm=True, unshuffle=True)
+        else:
+            dyt = Act(ARENA.get("bwd.dyt", (n, cout, 2 * h, 2 * w), dev), 0, cout)
+            ops.act_bwd(g_out, out, dyt, instance_norm=True)
+            ops.unshuffle2(dyt, dyp)
         wv = _view_cached(wt, (cin, 4 * cout, 1, 1))
         # dL/dx[ci] = sum_c' Wv[ci, c'] dy'[c']  == forward 1x1 conv with weight [cout'=Cin, cin'=4Cout]
         ops.conv2d(dyp, wv, None, g_in, grad_input=True)
@@ -382,8 +386,9 @@ class NormUnet(nn.Module):
         self._tapes[key] = (xin, out_planar, std, mean, std2[1], mean2[1])
         return out_planar
 
-    def run_bwd(self, g_out: torch.Tensor, key: str, want_ref_grad: bool = False):
-        """Backward of the last run(key).  g_out: dL/d(output) planar [B,2,H,W].  Returns
+    def run_bwd(self, g_out: torch.Tensor, key: str, want_ref_grad: bool = False, g_ref_acc: Optional[torch.Tensor] = None):
+        """Backward of the last run(key).  g_out: dL/d(output) planar [B,2,H,W].  g_ref_acc: a tensor dL/d(ref) is ADDED to
+        (then also the returned one).  Returns
         (dL/d(input planar) [B,2,H,W], dL/d(ref) [B,1,H,W] or None); parameter gradients accumulate.
 
         With x^ = (m - mu)/(sigma + eps) (sigma = unbiased std of the plane), U = unet(x^, ref^) and
@@ -418,8 +423,13 @@ class NormUnet(nn.Module):
         ops.add(Act(g_xh, 0, 2, a_sc, a_sh, 1.0), Act(xin.buf, xin.coff, 2, m_sc, m_sh, 1.0), ops.full(g_m))
         g_ref = None
         if self.use_ref and want_ref_grad:
-            g_ref = torch.empty((b, 1, h, w), device=dev)
-            ops.act_bwd(Act(g_xh, 2, 1), xin.view(2, 1), ops.full(g_ref), instance_norm=True)
+            if g_ref_acc is not None:
+                # dL/d ref is the sum over the cascades (every cascade reads the same ref): accumulated in place by the kernel
+                g_ref = g_ref_acc
+                ops.act_bwd_ex(Act(g_xh, 2, 1), xin.view(2, 1), ops.full(g_ref), instance_norm=True, accumulate=True)
+            else:
+                g_ref = torch.empty((b, 1, h, w), device=dev)
+                ops.act_bwd(Act(g_xh, 2, 1), xin.view(2, 1), ops.full(g_ref), instance_norm=True)
         return g_m, g_ref
 
     # -- reference-compatible entry --------------------------------------
@@ -571,7 +581,8 @@ class VarNetBlock(nn.Module):
         self._dk = dk_out
         return x_out
 
-    def run_bwd_img(self, g_xout: torch.Tensor, g_sens: Optional[torch.Tensor], want_ref_grad: bool):
+    def run_bwd_img(self, g_xout: torch.Tensor, g_sens: Optional[torch.Tensor], want_ref_grad: bool,
+                    g_ref_acc: Optional[torch.Tensor] = None):
         """Backward of the last run_img().  g_xout = dL/dx' (complex; the caller may not reuse it).  Returns
         (dL/dx, dL/d ref or None).  With D_lin = ifft_x M fft_x (Hermitian):
             dL/dr = -sum_c conj(S_c) g_c          dL/dw = -Re sum conj(fft_x g) M (fft_x x - k0x)
@@ -582,7 +593,7 @@ class VarNetBlock(nn.Module):
         g_r = ARENA.get("bwd.g_r", (n, 2, h, w), dev)
         g_d = torch.empty_like(g_xout)
         ops.dc_rows_bwd(g_xout, sens, mask_f, self.dc_weight.detach(), g_d, g_r, self._dk, dcw_grad=_grad_of(self.dc_weight))
-        g_m, g_ref = self.model.run_bwd(g_r, key, want_ref_grad)
+        g_m, g_ref = self.model.run_bwd(g_r, key, want_ref_grad, g_ref_acc)
         ops.sens_grad_prop(g_sens, r, g_xout, x, g_m, g_d, sens)
         return g_d, g_ref
 
@@ -682,12 +693,10 @@ class VarNet(nn.Module):
         g_sens = torch.zeros_like(x_last)
         g_ref1 = None
         for cascade in reversed(self.cascades):
-            g_x, g_ref = cascade.run_bwd_img(g_x, g_sens, want_ref_grad and self.use_ref)
+            # (the first cascade visited creates dL/d ref, the others add to it inside their activation-backward kernel)
+            g_x, g_ref = cascade.run_bwd_img(g_x, g_sens, want_ref_grad and self.use_ref, g_ref1)
             if g_ref is not None:
-                if g_ref1 is None:
-                    g_ref1 = g_ref
-                else:
-                    ops.add(ops.full(g_ref1), ops.full(g_ref), ops.full(g_ref1))
+                g_ref1 = g_ref
         # x_0 = ifft2(k0) and m_0 depend on the sensitivity maps only through m_0 = sum_c conj(S_c) x_0, which
         # run_bwd_img of cascade 0 has already accounted for; k0 itself needs no gradient
         self.sens_net.backward(g_sens)

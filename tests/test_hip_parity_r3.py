@@ -585,3 +585,27 @@ def test_narrow_precision_psnr_on_trained_like_weights(S):
     BARS = {"bf16": 40.0, "fp8": 25.0}                      # measured 44.9 / 30.2 dB (vs fp64: 43.5 / 29.4)
     for m_, (p32, p64) in res.items():
         assert p32 > BARS[m_] and p64 > BARS[m_] - 1.0, (m_, p32, p64)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 5, 16, 24), (1, 3, 320, 320), (2, 4, 40, 40)])
+def test_act_bwd_destination_modes_are_bit_identical(S, n, c, h, w):
+    """san_act_bwd_ex_amax: the pixel-unshuffled store equals san_act_bwd_amax + san_unshuffle2_fwd bit for bit (one-pass plane
+    kernel and the two-kernel form for 320 x 320), and the accumulate form equals a separate add."""
+    ops = S.ops
+    gv, yv = g(philox("abx.g", (n, c, h, w))), g(philox("abx.y", (n, c, h, w)))
+    sc, sh = g(philox("abx.sc", (n, c), lo=0.5, hi=1.5)), g(philox("abx.sh", (n, c)))
+    ya = ops.Act(yv, 0, c, sc, sh, 0.2)
+    ref_dy = torch.empty((n, c, h, w), device=DEV)
+    ops.act_bwd(ops.full(gv), ya, ops.full(ref_dy), instance_norm=True)
+    want = torch.empty((n, 4 * c + 3, h // 2, w // 2), device=DEV).fill_(7.0)
+    ops.unshuffle2(ops.full(ref_dy), ops.Act(want, 2, 4 * c))
+    got = torch.empty_like(want).fill_(7.0)
+    dst = ops.Act(got, 2, 4 * c)
+    ops.act_bwd_ex(ops.full(gv), ya, dst, instance_norm=True, unshuffle=True)
+    assert torch.equal(got, want)
+    if dst.amax is not None:
+        assert abs(ops.amax_value(dst.amax) - ref_dy.abs().max().item()) == 0
+    acc = g(philox("abx.acc", (n, c, h, w)))
+    want2 = acc + ref_dy
+    ops.act_bwd_ex(ops.full(gv), ya, ops.full(acc), instance_norm=True, accumulate=True)
+    assert torch.equal(acc, want2)
