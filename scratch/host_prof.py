@@ -20,4 +20,4 @@ pr.enable()
 for _ in range(3): bench.train_step(net, a, b)
 pr.disable()
 torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(45); st.sort_stats("cumulative").print_stats(60)

@@ -55,6 +55,8 @@ class SanLibrary:
                 f"{path} is missing: build it with `python -m spatialalignmentnetwork_amd.build` "
                 "(there is no CPU or PyTorch fallback for the hot path)")
         self._memo = {}
+        self._fns = {}
+        self._setters = set()
         self._dll = ctypes.CDLL(path)
         self.protos = parse_header()
         for name, (restype, argtypes) in self.protos.items():
@@ -74,10 +76,17 @@ class SanLibrary:
     _STATEFUL = frozenset({"san_get_conv_precision", "san_wgrad_defer", "san_wgrad_defer_pending", "san_version"})
 
     def call(self, name: str, *args):
-        """Call an int-returning entry point; raise RuntimeError on failure."""
-        if name.startswith("san_set_") or name.endswith("_set_tuning"):
+        """Call an int-returning entry point; raise RuntimeError on failure.  (~2,000 calls per training step: the function
+        object comes from a dict, and only the few setters pay for clearing the query cache.)"""
+        try:
+            fn = self._fns[name]
+        except KeyError:
+            fn = self._fns[name] = getattr(self, "_" + name)
+            if name.startswith("san_set_") or name.endswith("_set_tuning"):
+                self._setters.add(name)
+        if name in self._setters:
             self._memo.clear()
-        rc = getattr(self, "_" + name)(*args)
+        rc = fn(*args)
         if rc != 0:
             kind = "argument error" if rc < 0 else "hipError_t"
             raise RuntimeError(f"{name} failed ({kind} {rc}): {self.last_error()}")

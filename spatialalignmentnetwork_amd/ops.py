@@ -148,20 +148,26 @@ def _chk(t: torch.Tensor, dtype=torch.float32, name: str = "tensor") -> torch.Te
 
 
 def _creal(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
-    """complex64 [..] -> float32 [.., 2] view (no copy)."""
+    """A complex64 tensor checked for the C ABI (interleaved (re, im) fp32 = torch.view_as_real: the same storage and the
+    same data pointer, so the tensor itself is handed on; building the real view was ~190 dispatches per training step)."""
     if t.dtype != torch.complex64:
         raise RuntimeError(f"{name} must be complex64, got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must live on the GPU (the HIP path has no CPU fallback)")
-    return torch.view_as_real(t)
+    return t
 
 
 # ---------------------------------------------------------------------------
 # scratch arena: named, shape-keyed device buffers reused across calls (the
 # library never allocates activations; the caching allocator does, once)
 # ---------------------------------------------------------------------------
+# data pointers of buffers an arena owns (they are never handed back to the caching allocator while the arena lives, so a side
+# stream that reads them needs no record_stream: 650 dispatches per training step)
+_ARENA_PTRS = set()
+
+
 class Arena:
     def __init__(self):
         self._bufs: Dict[Tuple, torch.Tensor] = {}
@@ -174,6 +180,7 @@ class Arena:
         if t is None:
             t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
             self._bufs[key] = t
+            _ARENA_PTRS.add(t.data_ptr())
         elif not _no_wait and _WG["busy"]:
             _wait_if_busy(t)                    # a side-stream weight gradient may still be reading it (wgrad_overlap)
         return t
@@ -193,7 +200,16 @@ class Arena:
         return sum(t.numel() * t.element_size() for t in self._bufs.values())
 
     def clear(self):
+        for t in self._bufs.values():
+            _ARENA_PTRS.discard(t.data_ptr())
         self._bufs.clear()
+
+    def __del__(self):                          # an arena dies with its owner: its addresses may come back as ordinary tensors
+        try:
+            for t in self._bufs.values():
+                _ARENA_PTRS.discard(t.data_ptr())
+        except Exception:
+            pass
 
 
 _DEV_KEYS: Dict[object, str] = {}
@@ -666,6 +682,7 @@ class AmaxPool:
 
     def __init__(self):
         self.buf = {}
+        self.views = {}
         self.idx = 0
         self.words = None
 
@@ -700,7 +717,13 @@ class AmaxPool:
                 torch.cuda.current_stream().wait_stream(side)
             self.reset(device)
         self.idx += 1
-        return t[(self.idx - 1) * w:self.idx * w]
+        slots = self.views.get(key)
+        if slots is None:
+            slots = self.views[key] = [None] * self.SLOTS
+        v = slots[self.idx - 1]
+        if v is None:
+            v = slots[self.idx - 1] = t[(self.idx - 1) * w:self.idx * w]       # (a view per slot, made once: not per step)
+        return v
 
 
 def amax_record(value: torch.Tensor) -> torch.Tensor:
@@ -1236,9 +1259,12 @@ def _on_side_stream(dy: Act, x: Act, fn) -> None:
         _STREAM_OVERRIDE[0] = None
     ev = torch.cuda.Event() if torch.cuda.is_current_stream_capturing() else _EVENTS.next()
     ev.record(side)
-    _WG["busy"][dy.buf.data_ptr()] = ev
-    dy.buf.record_stream(side)
-    x.buf.record_stream(side)
+    dptr = dy.buf.data_ptr()
+    _WG["busy"][dptr] = ev
+    if dptr not in _ARENA_PTRS:                 # allocator-owned operands: keep their memory until the side stream is done
+        dy.buf.record_stream(side)
+    if x.buf.data_ptr() not in _ARENA_PTRS:
+        x.buf.record_stream(side)
 
 
 def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
@@ -1405,7 +1431,7 @@ def bn_bwd_coef(g: Act, y: Act, gamma: torch.Tensor, beta: torch.Tensor, dgamma:
     dgamma / dbeta and returns coef [n, c, 4] for act_bwd_coef.  Two launches, no host arithmetic."""
     part = plane_dot_part(g, y, "bn", arena)
     coef = arena.get("bn_coef", (y.n, y.c, 4), y.buf.device)
-    lib().call("san_bn_bwd_finalize", _p(part), _p(_chk(gamma.detach(), name="gamma")), _p(_chk(beta.detach(), name="beta")),
+    lib().call("san_bn_bwd_finalize", _p(part), _p(_chk(gamma, name="gamma")), _p(_chk(beta, name="beta")),
                _p(_chk(dgamma, name="dgamma")), _p(_chk(dbeta, name="dbeta")), _p(coef), y.n, y.c, int(part.shape[2]),
                float(y.n * y.h * y.w), _stream())
     return coef

@@ -124,12 +124,12 @@ class UNet(torch.nn.Module):
             c = conv.weight.shape[0]
             bmean = ARENA.get(f"{tag}.bmean", (c,), x.buf.device)
             bvar = ARENA.get(f"{tag}.bvar", (c,), x.buf.device)
-            ops.norm_finalize(part, ops.NORM_BATCH, BN_EPS, out.scale, out.shift, out.coff, gamma=bn.weight.detach(),
-                              beta=bn.bias.detach(), aux_a=bmean, aux_b=bvar)
+            ops.norm_finalize(part, ops.NORM_BATCH, BN_EPS, out.scale, out.shift, out.coff, gamma=bn.weight,
+                              beta=bn.bias, aux_a=bmean, aux_b=bvar)
             _update_running_stats(bn, bmean, bvar, x.n * x.h * x.w, count_scale)
         else:
             ops.conv2d(x, conv.weight, conv.bias, out, stats=False)
-            ops.bn_eval_affine(bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, BN_EPS,
+            ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS,
                                out.scale, out.shift, out.coff)
         self._record(("cba", conv, bn, x, out), out)
         return out
@@ -342,8 +342,12 @@ def _expand_aff(a: torch.Tensor, g: Act) -> torch.Tensor:
     place a per-view [n, c] constant array at the view's offset of a [n, ctot] array."""
     if g.coff == 0 and g.ctot == a.shape[1]:
         return a
-    full = torch.zeros((a.shape[0], g.ctot), device=a.device)
-    full[:, g.coff:g.coff + g.c] = a
+    # (constant arrays: built once per (value array, view) and kept in the arena)
+    full = ARENA.get(f"abwd.aff.{a.data_ptr()}.{g.ctot}.{g.coff}.{g.c}", (a.shape[0], g.ctot), a.device)
+    if not getattr(full, "_san_filled", False):
+        full.zero_()
+        full[:, g.coff:g.coff + g.c] = a
+        full._san_filled = True
     return full
 
 

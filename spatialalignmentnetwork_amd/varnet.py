@@ -516,7 +516,7 @@ class VarNetBlock(nn.Module):
         out = torch.empty((n, c, h, w), device=dev, dtype=torch.complex64)
         ones = ARENA.get("expand.ones", (w,), dev)
         ones.fill_(1.0)
-        ops.sens_expand_dc(r, sens_maps.contiguous(), zeros, zeros, ones, self.dc_weight.detach(), out)
+        ops.sens_expand_dc(r, sens_maps.contiguous(), zeros, zeros, ones, self.dc_weight, out)
         return out
 
     def sens_reduce(self, kspace: torch.Tensor, sens_maps: torch.Tensor) -> torch.Tensor:
@@ -534,7 +534,7 @@ class VarNetBlock(nn.Module):
         ops.sens_reduce(k, sens, xin.buf, cols=k_cols)
         r = ARENA.get(f"{key}.r", (n, 2, h, w), k.device)
         self.model.run(xin, r, key)
-        ops.sens_expand_dc(r, sens, k, k0, mask_f, self.dc_weight.detach(), k_out, next_cols=next_cols)
+        ops.sens_expand_dc(r, sens, k, k0, mask_f, self.dc_weight, k_out, next_cols=next_cols)
         self._tape = (k, k0, mask_f, sens, r, key)
         return k_out
 
@@ -564,7 +564,7 @@ class VarNetBlock(nn.Module):
         ops.apply(Act(g_m, 0, 2, neg_sc, neg_sh, 1.0), ops.full(neg_gm))
         zeros = ARENA.get("bwd.zero_k", (n, c, h, w), dev, dtype=torch.complex64, zero=True)
         g_k = torch.empty_like(g_kout)
-        ops.sens_expand_dc(neg_gm, sens, g_kout, zeros, mask_f, self.dc_weight.detach(), g_k)
+        ops.sens_expand_dc(neg_gm, sens, g_kout, zeros, mask_f, self.dc_weight, g_k)
         return g_k, g_ref
 
     # -- image-domain form (what VarNet.forward runs) --------------------------------------------
@@ -576,7 +576,7 @@ class VarNetBlock(nn.Module):
         n, c, h, w = x.shape
         r = ARENA.get(f"{key}.r", (n, 2, h, w), x.device)
         self.model.run(xin, r, key)
-        ops.dc_rows(x, sens, k0x, mask_f, self.dc_weight.detach(), r, x_out, m_next, dk_out)
+        ops.dc_rows(x, sens, k0x, mask_f, self.dc_weight, r, x_out, m_next, dk_out)
         self._tape = (x, None, mask_f, sens, r, key)
         self._dk = dk_out
         return x_out
@@ -592,7 +592,7 @@ class VarNetBlock(nn.Module):
         dev = x.device
         g_r = ARENA.get("bwd.g_r", (n, 2, h, w), dev)
         g_d = torch.empty_like(g_xout)
-        ops.dc_rows_bwd(g_xout, sens, mask_f, self.dc_weight.detach(), g_d, g_r, self._dk, dcw_grad=_grad_of(self.dc_weight))
+        ops.dc_rows_bwd(g_xout, sens, mask_f, self.dc_weight, g_d, g_r, self._dk, dcw_grad=_grad_of(self.dc_weight))
         g_m, g_ref = self.model.run_bwd(g_r, key, want_ref_grad, g_ref_acc)
         ops.sens_grad_prop(g_sens, r, g_xout, x, g_m, g_d, sens)
         return g_d, g_ref
