@@ -77,6 +77,9 @@ def parse_args(argv=None):
                     help="only the timed steps of --mode: no inference / narrow-precision legs after them (profiling runs)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step into a hipGraph and time replays (no per-kernel timer in that mode)")
+    ap.add_argument("--replay", action="store_true",
+                    help="record the training step once (CSModel.record_update) and time replays: the same GPU work with a third of "
+                         "the host time (no per-kernel timer in that mode)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own share of the host cores")
     ap.add_argument("--launch-test", action="store_true",
                     help="(CPU) exercise only the launcher: rendezvous over gloo, barrier, max-over-ranks, one JSON line")
@@ -345,6 +348,13 @@ def main(argv=None):
         step()
     torch.cuda.synchronize()
     graph = None
+    if args.replay:
+        assert args.mode == "train", "--replay records the training step"
+        graph = net.record_update(img_full, img_aux, warmup=1)
+        graph.replay()
+        torch.cuda.synchronize()
+        step = graph.replay
+        args.no_kernel_timer = True
     if args.graph:
         # the arena, packed weights, twiddles and masks exist after warm-up, so the step neither
         # allocates through the library nor synchronises: it is capture-safe
@@ -483,7 +493,7 @@ def main(argv=None):
                                       f"buffers per step)" if args.mode == "train" else
                                       f"dp{world} (independent slice shards, no data-path collective)",
                        "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks, "hip_graph": bool(args.graph),
-                       "hip_graph_mode": getattr(graph, "mode", None) if args.graph else None,
+                       "hip_graph_mode": getattr(graph, "mode", None) if (args.graph or args.replay) else None,
                        "cores_per_rank": len(my_cores) if my_cores else None},
             # the host's share of a step (time until step() returns = everything is enqueued; max over ranks): a value close
             # to ms_per_step means the eager step is HOST-bound on this box (then run --graph: one launch per step)

@@ -18,6 +18,44 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "san_hip.h")
 LIB_PATH = os.path.join(HERE, "libsan_hip.so")
 
+# ---------------------------------------------------------------------------------------------------------------
+# Step recorder.  A training step issues the SAME ~2,000 C-ABI calls with the same arguments every time once the arenas are
+# warm; what differs between steps lives in device memory.  While REC is a list, every C-ABI call, every stream / event
+# operation and every torch operation of the step that is routed through ``rec()`` is executed AND remembered as
+# ``(callable, args)``; ``CSModel.record_update`` turns one recorded step into an object whose ``replay()`` is a flat loop
+# over those pairs -- the Python between the calls (layer logic, arena look-ups, argument marshalling decisions: three
+# quarters of the ~45 ms a step costs the host) is not run again.  Unlike a hipGraph this keeps ordinary stream semantics (and
+# ROCm's graph launch was measured to cost the host as much as eager launching).
+REC = None          # list of (callable, args) while recording
+KEEP = None         # objects whose addresses were recorded (host scratch of C calls)
+IN_REC = [0]        # > 0 inside rec(): torch operations seen by the recording's dispatch mode are accounted for
+UNTRACKED = [0]     # > 0 inside untracked(): torch operations that need no replay (constants, host-side scalars)
+
+
+def rec(fn, *args):
+    """Run ``fn(*args)`` now; remember it when a step is being recorded."""
+    IN_REC[0] += 1
+    try:
+        out = fn(*args)
+    finally:
+        IN_REC[0] -= 1
+    if REC is not None:
+        REC.append((fn, args))
+    return out
+
+
+class untracked:
+    """``with untracked():`` -- torch operations inside do not belong to the replayed step (constant results such as the
+    float copy of the sampling mask, or host-visible scalars nobody replays such as ``loss_all``)."""
+
+    def __enter__(self):
+        UNTRACKED[0] += 1
+
+    def __exit__(self, *exc):
+        UNTRACKED[0] -= 1
+        return False
+
+
 _CT = {
     "int": ctypes.c_int,
     "float": ctypes.c_float,
@@ -90,11 +128,16 @@ class SanLibrary:
         if rc != 0:
             kind = "argument error" if rc < 0 else "hipError_t"
             raise RuntimeError(f"{name} failed ({kind} {rc}): {self.last_error()}")
+        if REC is not None:
+            REC.append((fn, args))
 
     def query(self, name: str, *args):
         """Call a size/count query (returns its value)."""
         if name in self._STATEFUL:
-            return getattr(self, "_" + name)(*args)
+            fn = getattr(self, "_" + name)
+            if REC is not None and name == "san_wgrad_defer":      # switches the library's deferred-reduction mode: part of the step
+                REC.append((fn, args))
+            return fn(*args)
         key = (name, args)
         try:
             return self._memo[key]

@@ -65,7 +65,8 @@ class SpatialTransformer(torch.nn.Module):
         head, feat = self.net[2], self._feat
         dy = ops.full(g_offset_nchw.contiguous())
         part = ops.plane_stats(dy, tag="st.b")
-        _grad_of(head.bias).add_((part[..., 0] * part[..., 1]).sum(dim=(0, 2)))
+        gb = _grad_of(head.bias)
+        ops._lib.rec(lambda: gb.add_((part[..., 0] * part[..., 1]).sum(dim=(0, 2))))
         ops.conv2d_wgrad(feat, dy, _grad_of(head.weight), accumulate=True)
         g_feat = Act(ARENA.get("align.g_feat", tuple(feat.buf.shape), feat.buf.device), 0, feat.c)
         ops.conv2d_dgrad(dy, head.weight, g_feat)

@@ -135,7 +135,8 @@ class GradBucket:
             p.grad = self.flat[o:o + p.numel()].view_as(p)
 
     def zero(self):
-        self.flat.zero_()
+        from . import _lib
+        _lib.rec(self.flat.zero_)
 
     def allreduce_sum(self, dist) -> None:
         """Sum the gradients over all ranks in place (the optimiser kernel applies the 1/world factor)."""
@@ -185,37 +186,43 @@ class GradExchange:
         if self.dist is None:
             return
         flat = bucket.flat
+        from . import _lib
         if not flat.is_cuda or BACKEND == "gloo":
             if flat.is_cuda:
                 cur = torch.cuda.current_stream()
                 for s in after:
                     if s is not None:
-                        cur.wait_stream(s)
-            bucket.allreduce_sum(self.dist)
+                        _lib.rec(cur.wait_stream, s)
+            _lib.rec(bucket.allreduce_sum, self.dist)
             return
         cur = torch.cuda.current_stream()
         comm = self.comm = self._comm(flat.device)
-        comm.wait_stream(cur)
+        _lib.rec(comm.wait_stream, cur)
         for s in after:
             if s is not None:
-                comm.wait_stream(s)
-        timed = self.timed and not torch.cuda.is_current_stream_capturing()
-        with torch.cuda.stream(comm):
-            e0 = e1 = None
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(comm)
-            work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True)
-            work.wait()                         # stream-level: the communication stream waits for the collective
-            if timed:
-                e1.record(comm)
-                self.events.append((e0, e1))
+                _lib.rec(comm.wait_stream, s)
+        timed = self.timed and not torch.cuda.is_current_stream_capturing() and _lib.REC is None
+        dist = self.dist
+
+        def _collective():
+            with torch.cuda.stream(comm):
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+                work.wait()                     # stream-level: the communication stream waits for the collective
+
+        e0 = e1 = None
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(comm)
+        _lib.rec(_collective)
+        if timed:
+            e1.record(comm)
+            self.events.append((e0, e1))
         flat.record_stream(comm)
-        self.works.append(work)
 
     def wait(self) -> None:
         if self.comm is not None:
-            torch.cuda.current_stream().wait_stream(self.comm)
+            from . import _lib
+            _lib.rec(torch.cuda.current_stream().wait_stream, self.comm)
         self.works.clear()
 
     def elapsed_ms(self) -> float:

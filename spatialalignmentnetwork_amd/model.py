@@ -15,7 +15,7 @@ import math
 
 import torch
 
-from . import autograd, ops
+from . import _lib, autograd, ops
 from .basemodel import BaseModel, Config  # noqa: F401
 from .cross import SpatialTransformer
 from . import metrics
@@ -103,7 +103,8 @@ class CSModel(BaseModel):
         self.img_sampled_rss = rss(self.img_sampled)
         self.img_aux_rss = rss(self.img_aux)
         n, _, h, w = self.img_full.shape
-        vis = (1.0 - pruned.float()).roll(w // 2).view(1, 1, 1, w).expand(n, 1, h, w)   # fftshift2 of a column mask
+        with _lib.untracked():                   # (a constant of the model, for visualisation only)
+            vis = (1.0 - pruned.float()).roll(w // 2).view(1, 1, 1, w).expand(n, 1, h, w)   # fftshift2 of a column mask
         self.img_mask = vis
 
     # ---------------------------------------------------------------- forwards
@@ -116,18 +117,22 @@ class CSModel(BaseModel):
         self.img_warped = self.net_T.warp(aux_abs, self.img_grid)
         self.img_warped_rss = rss(self.img_warped)
         self.loss_smooth = gradient_loss(self.img_offset)
-        self.loss_all = self.loss_all + self.loss_smooth * self.cfg.weight_smooth
+        with _lib.untracked():                   # (host-visible scalar arithmetic: the direct backward does not read it)
+            self.loss_all = self.loss_all + self.loss_smooth * self.cfg.weight_smooth
 
     @_own_arena
     def forwardR(self):
         """model.py:157-169."""
+        with _lib.untracked():
+            keep = torch.logical_not(self.net_mask.pruned)
         self.img_rec = self.net_R(
             masked_kspace=self.img_k_sampled,
-            mask=torch.logical_not(self.net_mask.pruned),
+            mask=keep,
             ref=self.img_warped,
             num_low_frequencies=int(self.cfg.shape * self.cfg.sparsity * 0.32))
         self.loss_sim = ssimloss(self.img_full_rss, self.img_rec)
-        self.loss_all = self.loss_all + self.loss_sim * self.cfg.weight_sim
+        with _lib.untracked():
+            self.loss_all = self.loss_all + self.loss_sim * self.cfg.weight_sim
 
     @_own_arena
     def backward(self, train_T: bool) -> None:
@@ -305,6 +310,70 @@ class CSModel(BaseModel):
             self._split_capture = False
         return CapturedStep([g1, g2], self._exchange_eager, "two graphs around an eager exchange")
 
+    def record_update(self, img_full, img_aux=None, warmup: int = 2, restore: bool = True):
+        """Record ``set_input(img_full, img_aux); update()`` once and return an object whose ``replay()`` re-issues exactly
+        that step's ~2,000 C-ABI calls, stream / event operations and the handful of torch operations as a flat loop over
+        ``(callable, args)`` pairs (``_lib.rec``) -- the host then spends ~a third of what the eager step costs it, with
+        ordinary stream semantics (ROCm's hipGraph launch was measured to cost the host as much as eager launching).
+        Contract = a graph's: the two input tensors are static (refill them in place between replays), every tensor the
+        step created stays alive inside the returned object and is overwritten by each replay (``img_*`` / ``loss_sim`` /
+        ``loss_smooth`` keep pointing at them; ``loss_all`` is not recomputed), optimiser step counts and hyper-parameters
+        live in device memory (``optim.sync_hyper()`` after changing the learning rate).  Works under a process group (the
+        collectives are part of the recording).  ``restore``: the warm-up steps and the recorded step itself are undone."""
+        from torch.utils._python_dispatch import TorchDispatchMode
+        assert self.training is True and ops.TIMER is None
+        dist = _active_dist()
+        if dist is not None and not getattr(self, "_replicas_synced", False):
+            self.sync_replicas()
+        for o in (self.optim_R, self.optim_T):
+            o.device_step = True
+            o.bucket()
+        snap = self._snapshot_state() if restore else None
+        for _ in range(max(1, warmup)):         # arenas, packed weights, twiddles, flat buffers, constant tables exist afterwards
+            self.set_input(img_full, img_aux)
+            self.update()
+        torch.cuda.synchronize()
+        for reg in (ops.PACKS, ops.PACKS16):   # the pack job tables are uploaded now (a host-to-device copy), not inside the step
+            reg.ensure_table(self.device)
+        keep, stray = [], []
+
+        class _Watch(TorchDispatchMode):
+            """Keeps every tensor the step creates alive (their addresses are in the recording) and notes torch operations
+            with side effects on device memory that neither went through _lib.rec nor were declared untracked."""
+            QUIET = ("aten.empty", "aten.view", "aten._unsafe_view", "aten.reshape", "aten.permute", "aten.select", "aten.slice",
+                     "aten.detach", "aten.alias", "aten.expand", "aten.as_strided", "aten.t.", "aten.transpose", "aten.unsqueeze",
+                     "aten.squeeze", "aten.view_as_real", "aten.view_as_complex", "aten.record_stream", "aten.new_empty",
+                     "aten.is_pinned", "aten._local_scalar_dense", "profiler.", "aten.sym_", "aten.size", "aten.stride", "aten.storage_offset",
+                     "aten.is_contiguous", "aten.numel", "aten.dim", "aten.unbind", "aten.split", "aten.chunk", "aten.lift_fresh")
+
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                out = func(*args, **(kwargs or {}))
+                keep.append(out)
+                name = str(func)
+                if not _lib.IN_REC[0] and not _lib.UNTRACKED[0] and not name.startswith(self.QUIET):
+                    import os
+                    import traceback
+                    site = next((f"{os.path.basename(fr.filename)}:{fr.lineno}" for fr in reversed(traceback.extract_stack(limit=14))
+                                 if "spatialalignmentnetwork_amd" in fr.filename and not fr.name.startswith("__torch_dispatch__")), "?")
+                    stray.append(f"{name} @ {site}")
+                return out
+
+        _lib.REC, _lib.KEEP = [], keep
+        try:
+            with _Watch():
+                self.set_input(img_full, img_aux)
+                self.update()
+        finally:
+            calls, _lib.REC, _lib.KEEP = _lib.REC, None, None
+        torch.cuda.synchronize()
+        if stray:
+            raise RuntimeError("record_update: torch operations outside _lib.rec / _lib.untracked in the step: "
+                               + ", ".join(sorted(set(stray))))
+        if snap is not None:
+            self._restore_state(snap)
+            torch.cuda.synchronize()
+        return RecordedStep(calls, keep)
+
     def _state_tensors(self):
         ts = []
         for o in (self.optim_R, self.optim_T):
@@ -406,6 +475,18 @@ class CSModel(BaseModel):
         if content in (None, "histograms"):
             vis["histograms"] = {"weights": {"values": self.net_mask.weight.detach()}}
         return vis
+
+
+class RecordedStep:
+    """What CSModel.record_update returns: ``replay()`` re-issues the recorded step."""
+
+    def __init__(self, calls, keep):
+        self.calls, self.keep = calls, keep
+        self.mode = f"recorded step: {len(calls)} calls"
+
+    def replay(self) -> None:
+        for fn, args in self.calls:
+            fn(*args)
 
 
 class CapturedStep:

@@ -14,6 +14,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
+from . import _lib
 from ._lib import lib
 
 NORM_INSTANCE, NORM_GROUP, NORM_BATCH, NORM_GROUP_BWD = 0, 1, 2, 3
@@ -698,7 +699,7 @@ class AmaxPool:
         want = None if device is None else _dev_key(device)
         for key, t in self.buf.items():
             if used and (want is None or key == want):
-                t[:used].zero_()
+                _lib.rec(t[:used].zero_)
         self.idx = 0
 
     def next(self, device) -> Optional[torch.Tensor]:
@@ -804,6 +805,8 @@ def _bf16x3_launch(ks: int, bargs, n: int, h: int, w: int, cin: int, cout: int, 
     if fin is not None and bargs[13] is not None:
         scale, shift, coff, eps = fin
         done = ctypes.c_int(0)
+        if _lib.KEEP is not None:
+            _lib.KEEP.append(done)              # its address is part of the recorded call
         lib().call("san_conv2d_bf16x3_fwd_ws_in", *bargs[:-1], _p(ws), nbytes, _p(scale), _p(shift), int(scale.shape[1]), int(coff),
                    float(eps), ctypes.c_void_p(ctypes.addressof(done)), bargs[-1])
         return bool(done.value)
@@ -1110,8 +1113,7 @@ _DEFER_BATCH = 48
 def wgrad_flush() -> None:
     """Launch the queued weight-gradient reductions (on the side stream)."""
     if _WG["defer"] and _WG["defer_k"]:
-        with torch.cuda.stream(_WG["stream"]):
-            lib().call("san_wgrad_defer_flush", _stream())
+        lib().call("san_wgrad_defer_flush", _WG["stream"].cuda_stream)
     _WG["defer_k"] = 0
     _WG["defer_dw"].clear()
 
@@ -1153,7 +1155,7 @@ class wgrad_overlap:
                 wgrad_flush()
                 lib().query("san_wgrad_defer", 0)
                 _WG["defer"] = False
-            torch.cuda.current_stream().wait_stream(side)
+            _lib.rec(torch.cuda.current_stream().wait_stream, side)
         _WG["stream"] = None
         _WG["main"] = None
         _WG["busy"].clear()
@@ -1191,7 +1193,7 @@ class backward_scope:
 def _wait_if_busy(t: torch.Tensor) -> None:
     ev = _WG["busy"].pop(t.data_ptr(), None)
     if ev is not None:
-        torch.cuda.current_stream().wait_event(ev)
+        _lib.rec(torch.cuda.current_stream().wait_event, ev)
 
 
 def wgrad_dy_buffer(name: str, shape, device, arena: Arena = GLOBAL_ARENA) -> torch.Tensor:
@@ -1199,9 +1201,9 @@ def wgrad_dy_buffer(name: str, shape, device, arena: Arena = GLOBAL_ARENA) -> to
     one of up to four rotating copies without a side-stream reader in flight (else the oldest, after waiting)."""
     if _WG["stream"] is None:
         return arena.get(name, shape, device)
-    if torch.cuda.is_current_stream_capturing():
-        # hipGraph capture: events may not be queried; take the copies round-robin and wait (a graph dependency, not a
-        # host wait) for the reader that used this copy four requests ago
+    if torch.cuda.is_current_stream_capturing() or _lib.REC is not None:
+        # hipGraph capture / step recording: no event queries (the choice must not depend on timing); take the copies
+        # round-robin and wait (a stream dependency, not a host wait) for the reader that used this copy four requests ago
         k = _WG["rr"].get(name, 0)
         _WG["rr"][name] = (k + 1) & 3
         t = arena.get(name if k == 0 else f"{name}#{k}", shape, device, _no_wait=True)
@@ -1249,16 +1251,16 @@ def _on_side_stream(dy: Act, x: Act, fn) -> None:
     if torch.cuda.is_current_stream_capturing():
         side.wait_stream(main)                  # (capture: fresh events, the graph keeps them as edges)
     else:
-        e0 = _EVENTS.next()
-        e0.record(main)                         # the operands' producers are queued on main up to here
-        side.wait_event(e0)
+        e0 = torch.cuda.Event() if _lib.REC is not None else _EVENTS.next()      # (a recorded step owns its events)
+        _lib.rec(e0.record, main)               # the operands' producers are queued on main up to here
+        _lib.rec(side.wait_event, e0)
     _STREAM_OVERRIDE[0] = side                  # (launches take the side stream's handle; torch's current stream stays put)
     try:
         fn()
     finally:
         _STREAM_OVERRIDE[0] = None
-    ev = torch.cuda.Event() if torch.cuda.is_current_stream_capturing() else _EVENTS.next()
-    ev.record(side)
+    ev = torch.cuda.Event() if (torch.cuda.is_current_stream_capturing() or _lib.REC is not None) else _EVENTS.next()
+    _lib.rec(ev.record, side)
     dptr = dy.buf.data_ptr()
     _WG["busy"][dptr] = ev
     if dptr not in _ARENA_PTRS:                 # allocator-owned operands: keep their memory until the side stream is done

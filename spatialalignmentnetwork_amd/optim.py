@@ -54,7 +54,9 @@ class FusedAdamW(torch.optim.Optimizer):
             # lr / weight decay / gradient scale live in device memory too, so that a captured launch follows
             # param_groups['lr'] (sync_hyper() refreshes them; an eager step calls it itself)
             if not torch.cuda.is_current_stream_capturing():
-                self.sync_hyper(grad_scale)
+                from . import _lib
+                with _lib.untracked():          # (a 12-byte host-to-device copy when a value changed; never part of a replay)
+                    self.sync_hyper(grad_scale)
             elif self._hyper is None:
                 raise RuntimeError("FusedAdamW: run one eager step (or sync_hyper()) before capturing")
             ops.adamw_step_dev(b.flat_p, b.flat, b.exp_avg, b.exp_avg_sq, float(g["lr"]), float(g["betas"][0]),

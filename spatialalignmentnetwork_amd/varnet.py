@@ -128,7 +128,8 @@ class TransposeConvBlock(nn.Module):
         else:
             dwv = ARENA.get("bwd.dwv", (4 * cout, cin, 1, 1), dev)
             ops._conv2d_wgrad(x, dyp, dwv, accumulate=False, scratch_tag=".inline")      # in line (own scratch): its result is consumed right here
-            _grad_of(wt).add_(dwv.view(4 * cout, cin).t().reshape(cin, cout, 2, 2))
+            gw = _grad_of(wt)
+            ops._lib.rec(lambda: gw.add_(dwv.view(4 * cout, cin).t().reshape(cin, cout, 2, 2)))
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         n, _, h, w = image.shape
@@ -637,7 +638,8 @@ class VarNet(nn.Module):
         dev = masked_kspace.device
         self._fwd_id = getattr(self, "_fwd_id", 0) + 1
         sens = self.sens_net(masked_kspace, num_low_frequencies)
-        mask_f = mask.reshape(-1).to(torch.float32).contiguous()
+        with ops._lib.untracked():                       # (a constant of the model: the sampling mask as floats)
+            mask_f = mask.reshape(-1).to(torch.float32).contiguous()
         assert mask_f.numel() == w, "mask must be a [W] column mask (broadcast like the reference's [1,1,1,W])"
         ref1 = None
         if self.use_ref:
@@ -690,7 +692,8 @@ class VarNet(nn.Module):
     def _backward_impl(self, g_img: torch.Tensor, want_ref_grad: bool) -> Optional[torch.Tensor]:
         x_last, out, ref, ref1 = self._train_state
         g_x = ops.rss_bwd(x_last, out, g_img.contiguous())          # dL/dx_T: the state is already in the image domain
-        g_sens = torch.zeros_like(x_last)
+        g_sens = torch.empty_like(x_last)
+        ops._lib.rec(g_sens.zero_)
         g_ref1 = None
         for cascade in reversed(self.cascades):
             # (the first cascade visited creates dL/d ref, the others add to it inside their activation-backward kernel)

@@ -417,7 +417,12 @@ def _dp_worker3(rank, world, port, path, captured):
     lo, hi = sdist.shard_bounds(4, rank, world)
     xf, xa = img_full[lo:hi].to("cuda:0").contiguous(), img_aux[lo:hi].to("cuda:0").contiguous()
     mode = "eager"
-    if captured:
+    if captured == 2:
+        step = net.record_update(xf, xa, warmup=1)
+        mode = step.mode
+        for _ in range(3):
+            step.replay()
+    elif captured:
         step = net.capture_update(xf, xa, warmup=1)
         mode = step.mode
         for _ in range(3):
@@ -441,7 +446,7 @@ def test_captured_step_under_a_process_group_two_ranks(S, tmp_path):
     graph) leaves bit-identical parameters to the eager data-parallel steps, on both ranks, and capturing itself does not
     advance the optimiser."""
     import torch.multiprocessing as mp
-    for captured in (False, True):
+    for captured in (0, 1, 2):
         mp.spawn(_dp_worker3, args=(2, _free_port(), str(tmp_path), captured), nprocs=2, join=True)
     e0, e1 = torch.load(tmp_path / "rank0_0.pt"), torch.load(tmp_path / "rank1_0.pt")
     c0, c1 = torch.load(tmp_path / "rank0_1.pt"), torch.load(tmp_path / "rank1_1.pt")
@@ -453,6 +458,12 @@ def test_captured_step_under_a_process_group_two_ranks(S, tmp_path):
             assert torch.equal(c0["params"][k], c1["params"][k]), ("captured replicas diverged", k)
         assert torch.equal(e0["params"][k], c0["params"][k]), ("captured != eager on rank 0", k)
         assert torch.equal(e1["params"][k], c1["params"][k]), ("captured != eager on rank 1", k)
+    # the recorded-step form (CSModel.record_update) under the same process group
+    r0, r1 = torch.load(tmp_path / "rank0_2.pt"), torch.load(tmp_path / "rank1_2.pt")
+    assert r0["mode"].startswith("recorded step") and r0["steps"] == r1["steps"] == 3
+    for k in e0["params"]:
+        assert torch.equal(e0["params"][k], r0["params"][k]), ("recorded != eager on rank 0", k)
+        assert torch.equal(e1["params"][k], r1["params"][k]), ("recorded != eager on rank 1", k)
 
 
 # ------------------------------------------------------------------------------------------- the bench batch (N = 8)
@@ -609,3 +620,72 @@ def test_act_bwd_destination_modes_are_bit_identical(S, n, c, h, w):
     want2 = acc + ref_dy
     ops.act_bwd_ex(ops.full(gv), ya, ops.full(acc), instance_norm=True, accumulate=True)
     assert torch.equal(acc, want2)
+
+
+# ------------------------------------------------------------------------------------------- recorded step (host-light replay)
+def test_recorded_step_replays_bit_identically(S):
+    """CSModel.record_update(): one recorded 'Rec' step replayed three times (a flat loop over the recorded C-ABI calls,
+    stream / event operations and torch operations) leaves bit-identical parameters and BatchNorm buffers to three eager
+    steps from the same state; recording itself does not advance the model; new data goes through the static input tensors;
+    a learning-rate change is followed; an eager step afterwards continues correctly."""
+    n, c, h, w = 2, 3, 48, 80
+
+    def make():
+        cfg = S.base.Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                            weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=2, chans=18,
+                            sens_chans=8, pools=2, sens_pools=2)
+        net = S.model.CSModel(cfg)
+        net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+        _fill(S, net.net_T, 41)
+        _fill(S, net.net_R, 42)
+        net.to(DEV).train()
+        for o in (net.optim_R, net.optim_T):
+            o.device_step = True
+        return net
+
+    def state(net):
+        return {f"{s_}.{k}": v.detach().cpu().clone() for s_ in ("net_R", "net_T") for k, v in getattr(net, s_).state_dict().items()}
+
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    xf, xa = g(img_full), g(img_aux)
+    eager = make()
+    for _ in range(3):
+        eager.set_input(xf, xa)
+        eager.update()
+    torch.cuda.synchronize()
+    want = state(eager)
+    cap = make()
+    before = state(cap)
+    step = cap.record_update(xf, xa, warmup=2)
+    assert step.mode.startswith("recorded step") and cap.optim_R.steps_taken() == 0
+    after = state(cap)
+    assert all(torch.equal(before[k], after[k]) for k in before), "recording advanced the model"
+    for _ in range(3):
+        step.replay()
+    torch.cuda.synchronize()
+    assert cap.optim_R.steps_taken() == 3 and cap.optim_T.steps_taken() == 3
+    got = state(cap)
+    bad = [k for k in want if not torch.equal(want[k], got[k])]
+    assert not bad, bad[:5]
+    assert torch.equal(cap.img_rec, eager.img_rec) and torch.equal(cap.loss_sim, eager.loss_sim)
+    # new data through the static inputs, and a learning-rate change
+    f2, a2 = S.synth.phantom_pair(n, c, h, w, seed=77)
+    xf.copy_(g(f2))
+    xa.copy_(g(a2))
+    for net_ in (eager, cap):
+        for o in (net_.optim_R, net_.optim_T):
+            o.param_groups[0]["lr"] = 3e-5
+            o.sync_hyper()
+    step.replay()
+    eager.set_input(xf, xa)
+    eager.update()
+    torch.cuda.synchronize()
+    want, got = state(eager), state(cap)
+    assert all(torch.equal(want[k], got[k]) for k in want)
+    # back to eager launching on the recorded model
+    for net_ in (eager, cap):
+        net_.set_input(xf, xa)
+        net_.update()
+    torch.cuda.synchronize()
+    want, got = state(eager), state(cap)
+    assert all(torch.equal(want[k], got[k]) for k in want)
