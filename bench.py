@@ -8,6 +8,11 @@
 ``python bench.py --gpus N`` with N > 1 and no torch.distributed.run environment re-launches itself under
 ``torch.distributed.run`` (one process per GPU, 127.0.0.1 rendezvous); both invocations print the same line.
 
+The timed training steps are REPLAYS of one recorded step (CSModel.record_update: the step's ~2,000 C-ABI calls, stream /
+event operations and torch operations with their arguments as a flat call list; nothing is skipped or cached -- every kernel of
+set_input + forward + backward + exchange + AdamW is launched again, the Python between the launches is not).  The eager step
+is host-limited by ~5 % on this workload (`--eager` times it; `--graph` times a hipGraph of it).
+
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
 CSModel.set_input (fft2 -> column mask -> ifft2 -> rss) + CSModel.update() = forwardT (alignment U-Net + bilinear warp
 + smoothness loss), forwardR (VarNet: sensitivity net + 12 cascades of [ifft2.conj(S).sum -> NormUnet -> fft2 + soft
@@ -24,8 +29,9 @@ Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max ran
                    The split-operand kernels execute 3 fp16 products per fp32 MAC (two fp16 parts per operand; 6 on
                    three bf16 parts with SAN_NO_F16X2=1): `executed_tflops` and `frac_of_bf16x3_ceiling` (ceiling =
                    2500 / products TFLOP/s fp32-equivalent; fp16 and bf16 dense MFMA peaks are equal) are extras.
-                   Every 29th launch of a family is bracketed and run alone (an event pair around each of ~1,700
-                   launches per step costs ~6 % of the step and would serialise the two streams).
+                   The LAST timed step is a second recording of the same step that carries an event pair around every 5th
+                   launch of a family (run alone: the two streams are joined around it); the other timed steps run without
+                   brackets.  Eager mode: every 29th launch of every step.
   roofline_*     : the same for the fused FFT + data-consistency kernels (HBM) and the other conv families.
                    `event_pair_overhead_us` = the elapsed time of an event pair with nothing in between, measured in
                    the same run, and `frac_net_of_event_overhead` = frac with that subtracted from the launch time
@@ -77,9 +83,11 @@ def parse_args(argv=None):
                     help="only the timed steps of --mode: no inference / narrow-precision legs after them (profiling runs)")
     ap.add_argument("--graph", action="store_true",
                     help="capture the step into a hipGraph and time replays (no per-kernel timer in that mode)")
-    ap.add_argument("--replay", action="store_true",
-                    help="record the training step once (CSModel.record_update) and time replays: the same GPU work with a third of "
-                         "the host time (no per-kernel timer in that mode)")
+    ap.add_argument("--replay", action="store_true", help="(the default for --mode train, kept for compatibility)")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every timed training step from Python (default: the step is recorded once with "
+                         "CSModel.record_update and the timed steps are replays -- the same kernels, stream / event and torch "
+                         "operations with the same arguments as a flat call list; the eager step is host-limited by ~5 %%)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own share of the host cores")
     ap.add_argument("--launch-test", action="store_true",
                     help="(CPU) exercise only the launcher: rendezvous over gloo, barrier, max-over-ranks, one JSON line")
@@ -348,13 +356,34 @@ def main(argv=None):
         step()
     torch.cuda.synchronize()
     graph = None
-    if args.replay:
-        assert args.mode == "train", "--replay records the training step"
-        graph = net.record_update(img_full, img_aux, warmup=1)
-        graph.replay()
-        torch.cuda.synchronize()
-        step = graph.replay
-        args.no_kernel_timer = True
+    timer = None
+    step_mode = "eager"
+    if args.mode == "train" and not args.eager and not args.graph:
+        # Default: record one training step and time replays of it.  Nothing is skipped or cached: a replay re-issues every kernel of set_input + forward + backward +
+        # exchange + AdamW; only the Python between the launches is not run again.  Falls back to eager launching if the
+        # recording cannot be made.
+        try:
+            graph = net.record_update(img_full, img_aux, warmup=1, restore=False)
+            marked = graph
+            if not args.no_kernel_timer:
+                # a second recording of the same step WITH the roofline event brackets (every 5th launch of a family, run
+                # alone): it is the LAST of the timed steps, so the HIP-event figures come from inside the timed region while
+                # the other steps run without the brackets' stream joins
+                timer = ops.KernelTimer(stride=5)
+                marked = net.record_update(img_full, img_aux, warmup=1, restore=False, timer=timer)
+            graph.replay()
+            torch.cuda.synchronize()
+            clean_replay, marked_replay, left = graph.replay, marked.replay, [args.steps]
+
+            def step():
+                left[0] -= 1
+                (marked_replay if left[0] == 0 else clean_replay)()
+
+            step_mode = "replay of a recorded step (CSModel.record_update)"
+        except Exception as e:                      # pragma: no cover
+            print(f"[bench] record_update failed ({type(e).__name__}: {e}); timing eager steps", file=sys.stderr, flush=True)
+            graph, timer = None, None
+            step_mode = f"eager (record_update failed: {type(e).__name__})"
     if args.graph:
         # the arena, packed weights, twiddles and masks exist after warm-up, so the step neither
         # allocates through the library nor synchronises: it is capture-safe
@@ -375,11 +404,13 @@ def main(argv=None):
         step = graph.replay
         args.no_kernel_timer = True
     barrier()
-    timer = None
-    if not args.no_kernel_timer:
+    replaying = step_mode.startswith("replay")
+    if args.graph:
+        step_mode = "hipGraph replay"
+    if not args.no_kernel_timer and not replaying:
         timer = ops.KernelTimer()
         ops.TIMER = timer
-    if args.mode == "train" and dist is not None:
+    if args.mode == "train" and dist is not None and not replaying:
         torch.cuda.synchronize()
         net.exchange_ms()                           # drop the warm-up steps' records
     torch.cuda.synchronize()
@@ -399,7 +430,8 @@ def main(argv=None):
     host_ms = 1e3 * sdist.max_over_ranks(host_s, dist, dev) / args.steps
     allreduce_ms = None
     if args.mode == "train" and dist is not None and not args.graph:
-        allreduce_ms = sdist.max_over_ranks(net.exchange_ms(), dist, dev) / args.steps
+        # (a recorded step holds ONE set of event pairs, re-recorded by every replay: the last replay's duration)
+        allreduce_ms = sdist.max_over_ranks(net.exchange_ms(), dist, dev) / (1 if replaying else args.steps)
 
     infer = None
     if args.mode == "train" and not args.main_only:
@@ -493,7 +525,7 @@ def main(argv=None):
                                       f"buffers per step)" if args.mode == "train" else
                                       f"dp{world} (independent slice shards, no data-path collective)",
                        "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks, "hip_graph": bool(args.graph),
-                       "hip_graph_mode": getattr(graph, "mode", None) if (args.graph or args.replay) else None,
+                       "step_mode": step_mode, "hip_graph_mode": getattr(graph, "mode", None),
                        "cores_per_rank": len(my_cores) if my_cores else None},
             # the host's share of a step (time until step() returns = everything is enqueued; max over ranks): a value close
             # to ms_per_step means the eager step is HOST-bound on this box (then run --graph: one launch per step)
@@ -508,7 +540,7 @@ def main(argv=None):
         if variants is not None:
             out["narrow_precision"] = variants
         if timer is not None:
-            tot = timer.totals()
+            tot = timer.totals(replays=args.steps if replaying else 1)
             dom = max(tot, key=lambda k: tot[k]["ms"])
             # HBM bytes per launch, algorithmic bytes and MFMA-busy fractions from the committed PMC passes of THIS workload
             # (separate rocprofv3 --pmc runs, corrected as the file states); bench.py itself cannot run the profiler

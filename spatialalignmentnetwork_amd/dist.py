@@ -201,7 +201,7 @@ class GradExchange:
         for s in after:
             if s is not None:
                 _lib.rec(comm.wait_stream, s)
-        timed = self.timed and not torch.cuda.is_current_stream_capturing() and _lib.REC is None
+        timed = self.timed and not torch.cuda.is_current_stream_capturing()
         dist = self.dist
 
         def _collective():
@@ -212,10 +212,10 @@ class GradExchange:
         e0 = e1 = None
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(comm)
+            _lib.rec(e0.record, comm)
         _lib.rec(_collective)
         if timed:
-            e1.record(comm)
+            _lib.rec(e1.record, comm)
             self.events.append((e0, e1))
         flat.record_stream(comm)
 

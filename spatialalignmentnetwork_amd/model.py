@@ -310,7 +310,7 @@ class CSModel(BaseModel):
             self._split_capture = False
         return CapturedStep([g1, g2], self._exchange_eager, "two graphs around an eager exchange")
 
-    def record_update(self, img_full, img_aux=None, warmup: int = 2, restore: bool = True):
+    def record_update(self, img_full, img_aux=None, warmup: int = 2, restore: bool = True, timer=None):
         """Record ``set_input(img_full, img_aux); update()`` once and return an object whose ``replay()`` re-issues exactly
         that step's ~2,000 C-ABI calls, stream / event operations and the handful of torch operations as a flat loop over
         ``(callable, args)`` pairs (``_lib.rec``) -- the host then spends ~a third of what the eager step costs it, with
@@ -319,7 +319,9 @@ class CSModel(BaseModel):
         step created stays alive inside the returned object and is overwritten by each replay (``img_*`` / ``loss_sim`` /
         ``loss_smooth`` keep pointing at them; ``loss_all`` is not recomputed), optimiser step counts and hyper-parameters
         live in device memory (``optim.sync_hyper()`` after changing the learning rate).  Works under a process group (the
-        collectives are part of the recording).  ``restore``: the warm-up steps and the recorded step itself are undone."""
+        collectives are part of the recording).  ``restore``: the warm-up steps and the recorded step itself are undone.
+        ``timer``: an ops.KernelTimer active during the recorded step only -- its event brackets become part of the recording
+        (``timer.totals(replays=K)`` after K replays)."""
         from torch.utils._python_dispatch import TorchDispatchMode
         assert self.training is True and ops.TIMER is None
         dist = _active_dist()
@@ -358,13 +360,16 @@ class CSModel(BaseModel):
                     stray.append(f"{name} @ {site}")
                 return out
 
+        self._exchange_events = []               # (only the recorded step's exchange events are kept)
         _lib.REC, _lib.KEEP = [], keep
+        ops.TIMER = timer
         try:
             with _Watch():
                 self.set_input(img_full, img_aux)
                 self.update()
         finally:
             calls, _lib.REC, _lib.KEEP = _lib.REC, None, None
+            ops.TIMER = None
         torch.cuda.synchronize()
         if stray:
             raise RuntimeError("record_update: torch operations outside _lib.rec / _lib.untracked in the step: "

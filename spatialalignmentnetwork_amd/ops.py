@@ -51,14 +51,16 @@ class KernelTimer:
         # before and held until after it), so that the time is the kernel's own and not the contention's
         side, other = _WG["stream"], None
         cur = _launch_stream()
+        # (through _lib.rec: inside a recorded step the brackets are part of the recording, every replay re-records the
+        # same event pairs and totals() reads the last replay's)
         if side is not None:
             other = _WG["main"] if cur == side else side
-            cur.wait_stream(other)
-        e0.record(cur)
+            _lib.rec(cur.wait_stream, other)
+        _lib.rec(e0.record, cur)
         fn()
-        e1.record(cur)
+        _lib.rec(e1.record, cur)
         if other is not None:
-            other.wait_stream(cur)
+            _lib.rec(other.wait_stream, cur)
         self.recs.append((name, work, e0, e1))
 
     @staticmethod
@@ -74,10 +76,15 @@ class KernelTimer:
         t = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
         return float(t[len(t) // 2])
 
-    def totals(self):
+    def totals(self, replays: int = 1):
         """{family: launches, work (all launches), sampled_launches / sampled_ms / sampled_work (the bracketed ones),
-        ms = sampled_ms scaled by work (the estimate for all launches)}"""
+        ms = sampled_ms scaled by work (the estimate for all launches)}.  replays: the timer saw ONE recorded step that was
+        then replayed this many times (launches / work / ms are scaled to the whole timed region; the sampled figures are
+        the last replay's event pairs)."""
         out = {k: dict(v, sampled_launches=0, sampled_ms=0.0, sampled_work=0.0) for k, v in self.seen.items()}
+        for d in out.values():
+            for key in ("launches", "work", "abytes", "xwork"):
+                d[key] = d[key] * replays
         for name, work, e0, e1 in self.recs:
             d = out[name]
             d["sampled_launches"] += 1
