@@ -440,14 +440,23 @@ def main(argv=None):
         for _ in range(2):
             one_step(net, img_full, img_aux)
         torch.cuda.synchronize()
+        istep, imode = (lambda: one_step(net, img_full, img_aux)), "eager"
+        if not args.eager and not args.graph:
+            try:
+                irec = net.record_forward(img_full, img_aux)
+                istep, imode = irec.replay, "replay of a recorded pass (CSModel.record_forward)"
+            except Exception as e:                  # pragma: no cover
+                print(f"[bench] record_forward failed ({type(e).__name__}: {e}); timing eager passes", file=sys.stderr, flush=True)
+        istep()
+        torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            one_step(net, img_full, img_aux)
+            istep()
         torch.cuda.synchronize()
         barrier()
         dti = sdist.max_over_ranks(time.perf_counter() - t1, dist, dev)
-        infer = {"value": n * world * args.steps / dti, "unit": "slices/s", "ms_per_step": 1e3 * dti / args.steps}
+        infer = {"value": n * world * args.steps / dti, "unit": "slices/s", "ms_per_step": 1e3 * dti / args.steps, "step_mode": imode}
     variants = None
     if args.dtype == "fp32" and args.mode == "train" and not args.graph and not args.main_only:
         # the narrow-precision modes of the same step (BASELINE configs[1] is written "bf16"): timed the same way, fewer

@@ -322,7 +322,6 @@ class CSModel(BaseModel):
         collectives are part of the recording).  ``restore``: the warm-up steps and the recorded step itself are undone.
         ``timer``: an ops.KernelTimer active during the recorded step only -- its event brackets become part of the recording
         (``timer.totals(replays=K)`` after K replays)."""
-        from torch.utils._python_dispatch import TorchDispatchMode
         assert self.training is True and ops.TIMER is None
         dist = _active_dist()
         if dist is not None and not getattr(self, "_replicas_synced", False):
@@ -335,6 +334,39 @@ class CSModel(BaseModel):
             self.set_input(img_full, img_aux)
             self.update()
         torch.cuda.synchronize()
+
+        def run():
+            self.set_input(img_full, img_aux)
+            self.update()
+
+        self._exchange_events = []               # (only the recorded step's exchange events are kept)
+        step = self._record(run, "record_update", timer)
+        if snap is not None:
+            self._restore_state(snap)
+            torch.cuda.synchronize()
+        return step
+
+    def record_forward(self, img_full, img_aux=None, warmup: int = 1):
+        """The inference pass (``set_input; forwardT; forwardR`` under ``no_grad``, as ``test()`` runs it minus the host-side
+        metrics) as a recorded step: ``replay()`` refreshes ``img_rec`` / ``img_warped`` / ``loss_sim`` ... in place for
+        whatever the two static input tensors hold."""
+        def run():
+            with torch.no_grad(), ops.conv_precision(self._conv_mode()):
+                self.set_input(img_full, img_aux)
+                self.loss_all = 0
+                self.forwardT()
+                self.loss_all = 0
+                self.forwardR()
+
+        for _ in range(max(1, warmup)):
+            run()
+        torch.cuda.synchronize()
+        return self._record(run, "record_forward", None)
+
+    def _record(self, run, what: str, timer):
+        """Execute ``run()`` under the recorder (``_lib.REC``) and a dispatch mode that keeps every tensor it creates alive
+        and refuses stray torch operations; returns the RecordedStep."""
+        from torch.utils._python_dispatch import TorchDispatchMode
         for reg in (ops.PACKS, ops.PACKS16):   # the pack job tables are uploaded now (a host-to-device copy), not inside the step
             reg.ensure_table(self.device)
         keep, stray = [], []
@@ -345,7 +377,7 @@ class CSModel(BaseModel):
             QUIET = ("aten.empty", "aten.view", "aten._unsafe_view", "aten.reshape", "aten.permute", "aten.select", "aten.slice",
                      "aten.detach", "aten.alias", "aten.expand", "aten.as_strided", "aten.t.", "aten.transpose", "aten.unsqueeze",
                      "aten.squeeze", "aten.view_as_real", "aten.view_as_complex", "aten.record_stream", "aten.new_empty",
-                     "aten.is_pinned", "aten._local_scalar_dense", "profiler.", "aten.sym_", "aten.size", "aten.stride", "aten.storage_offset",
+                     "aten.is_pinned", "profiler.", "aten.sym_", "aten.size", "aten.stride", "aten.storage_offset",
                      "aten.is_contiguous", "aten.numel", "aten.dim", "aten.unbind", "aten.split", "aten.chunk", "aten.lift_fresh")
 
             def __torch_dispatch__(self, func, types, args=(), kwargs=None):
@@ -360,23 +392,18 @@ class CSModel(BaseModel):
                     stray.append(f"{name} @ {site}")
                 return out
 
-        self._exchange_events = []               # (only the recorded step's exchange events are kept)
         _lib.REC, _lib.KEEP = [], keep
         ops.TIMER = timer
         try:
             with _Watch():
-                self.set_input(img_full, img_aux)
-                self.update()
+                run()
         finally:
             calls, _lib.REC, _lib.KEEP = _lib.REC, None, None
             ops.TIMER = None
         torch.cuda.synchronize()
         if stray:
-            raise RuntimeError("record_update: torch operations outside _lib.rec / _lib.untracked in the step: "
-                               + ", ".join(sorted(set(stray))))
-        if snap is not None:
-            self._restore_state(snap)
-            torch.cuda.synchronize()
+            raise RuntimeError(f"{what}: torch operations outside _lib.rec / _lib.untracked in the step (a host "
+                               "synchronisation such as .item() counts): " + ", ".join(sorted(set(stray))))
         return RecordedStep(calls, keep)
 
     def _state_tensors(self):

@@ -689,3 +689,28 @@ def test_recorded_step_replays_bit_identically(S):
     torch.cuda.synchronize()
     want, got = state(eager), state(cap)
     assert all(torch.equal(want[k], got[k]) for k in want)
+
+
+def test_recorded_forward_pass_replays_bit_identically(S):
+    """CSModel.record_forward(): the inference pass as a recorded step; replays on new data through the static inputs give the
+    bit-identical reconstruction / warp / loss of the eager pass."""
+    n, c, h, w = 2, 1, 64, 64
+    net = _rec_model(S, w, c).to(DEV).eval()
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    xf, xa = g(img_full), g(img_aux)
+    rec = net.record_forward(xf, xa)
+    f2, a2 = S.synth.phantom_pair(n, c, h, w, seed=77)
+    xf.copy_(g(f2))
+    xa.copy_(g(a2))
+    rec.replay()
+    torch.cuda.synchronize()
+    got = {k: getattr(net, k).detach().clone() for k in ("img_rec", "img_warped", "loss_sim", "loss_smooth", "img_sampled_rss")}
+    ref = _rec_model(S, w, c).to(DEV).eval()
+    with torch.no_grad():
+        ref.set_input(g(f2), g(a2))
+        ref.loss_all = 0
+        ref.forwardT()
+        ref.forwardR()
+    torch.cuda.synchronize()
+    for k, v in got.items():
+        assert torch.equal(v, getattr(ref, k)), k
