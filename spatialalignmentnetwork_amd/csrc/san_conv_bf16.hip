@@ -97,12 +97,23 @@ struct BArgs {
     int S;                     // split-K: S workgroups share an output tile, each takes a contiguous range of the chunks
     float* ws;                 // [S][N][cout][H][W] partial outputs (S > 1); splitk_reduce_kernel adds them up
     int tw, th, hp, npx;       // tile width / height (tw * th <= 256 pixels, taken in flattened order), halo pitch tw + 2, halo pixels
+    // Exact division by run-time constants without the ~25-instruction software divide (eight of them open every workgroup;
+    // scratch/probe/wg_floor.hip: a dozen scalar divisions alone cost 1.7 us per 3,200-workgroup launch): q = umulhi(x, m)
+    // with m = 2^32 / d + 1, exact while x d < 2^32 (checked by the host, which otherwise leaves m = 0 = "divide").
+    // m_*: S, cgs, cgs * ntile, tiles_x, and for the run-time tile shapes hp, npx - 256, tw.
+    unsigned m_S, m_cgs, m_cgsnt, m_tx, m_hp, m_rem, m_tw;
     int fmt;                   // operand format of the packed weights / the staging: 0 = bf16 parts, 1 = two fp16 parts
     unsigned long long* dbg;   // tuning hook (san_conv_bf16x3_debug_timeline): per workgroup 8 x u64 = 100 MHz clock at start, first
                                // chunk staged, epilogue start, end; HW_ID; XCC_ID -- null in normal use
     const uint32_t* amax;      // fp16 format on a GRADIENT input: the tensor's amax record (san_common.h); the input is scaled by a power of two
     const float* f8_tail;      // fp8 format: {S_w, 1 / S_w} behind the packed image (the per-tensor power-of-two weight scale)
 };
+
+// x / d for 0 <= x, d >= 1 with the host's multiplier m (BArgs.m_*); m == 0: plain division
+__device__ __forceinline__ int fdiv(int x, unsigned m, int d) {
+    if (d == 1) return x;
+    return m ? (int)__umulhi((unsigned)x, m) : x / d;
+}
 
 // round-to-nearest-even bf16 of f, returned as the fp32 it represents (upper 16 bits)
 __device__ __forceinline__ float bf16_round(float f) {
@@ -228,13 +239,14 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
     };
     mark(0);
     const int ntile = a.tiles_x * a.tiles_y;
-    const int sk = lin % a.S;                           // split-K part (fastest: the S parts of a tile share its input)
-    const int group = lin / a.S;                        // (n, tile, cg)
-    const int cg = group % a.cgs;
-    const int tile = (group / a.cgs) % ntile;
-    const int n = group / (a.cgs * ntile);
-    const int c0 = (a.chunks * sk) / a.S, c1 = (a.chunks * (sk + 1)) / a.S;     // this workgroup's chunks
-    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int group = fdiv(lin, a.m_S, a.S);            // (n, tile, cg)
+    const int sk = lin - group * a.S;                   // split-K part (fastest: the S parts of a tile share its input)
+    const int gq = fdiv(group, a.m_cgs, a.cgs);
+    const int cg = group - gq * a.cgs;
+    const int n = fdiv(group, a.m_cgsnt, a.cgs * ntile);
+    const int tile = gq - n * ntile;
+    const int c0 = fdiv(a.chunks * sk, a.m_S, a.S), c1 = fdiv(a.chunks * (sk + 1), a.m_S, a.S);     // this workgroup's chunks
+    const int ty = fdiv(tile, a.m_tx, a.tiles_x), tx = tile - ty * a.tiles_x;
     const int tw = FLAT ? a.tw : kTW, th = FLAT ? a.th : kTH, hp = FLAT ? a.hp : kHW_, npx = FLAT ? a.npx : kNP;
     const int x0 = tx * tw, y0 = ty * th;
 
@@ -253,10 +265,10 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
         } else {
             const int rem = npx - kT;                   // halo pixels beyond the first 256 (<= 84)
             used = rem > 0 && tid < 3 * rem;
-            chg = used ? tid / rem : 0;
+            chg = used ? (FLAT ? fdiv(tid, a.m_rem, rem) : tid / rem) : 0;
             p = used ? kT + tid - chg * rem : 0;
         }
-        const int pr = p / hp, pc = p - pr * hp;
+        const int pr = FLAT ? fdiv(p, a.m_hp, hp) : p / hp, pc = p - pr * hp;
         if (KS == 1) used = used && pr >= 1 && pr <= th && pc >= 1 && pc <= tw;       // no halo
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
         s_in[s] = used && gy >= 0 && gy < H && gx >= 0 && gx < W;
@@ -385,7 +397,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
     for (int b = 0; b < 4; ++b) {
         if constexpr (FLAT) {
             const int q = min(64 * wave + 16 * b + nn, tw * th - 1);
-            trow[b] = q / tw;
+            trow[b] = fdiv(q, a.m_tw, tw);
             tcol[b] = q - trow[b] * tw;
         } else {
             trow[b] = 2 * wave + (b >> 1);
@@ -1336,6 +1348,22 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
             a.S = S;
             a.ws = static_cast<float*>(ws);
         }
+    }
+    {
+        const unsigned long long total = (unsigned long long)a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
+        const int ntile = a.tiles_x * a.tiles_y;
+        // every dividend is below `total` (or chunks (S + 1), or 256 + 3 * 84 for the per-thread ones): exact while x d < 2^32
+        auto magic = [&](int d, unsigned long long xmax) -> unsigned {
+            return (d > 1 && xmax * (unsigned long long)d < 0xffffffffull) ? (unsigned)(0x100000000ull / (unsigned)d + 1) : 0u;
+        };
+        const unsigned long long xm = total > (unsigned long long)a.chunks * (a.S + 1) ? total : (unsigned long long)a.chunks * (a.S + 1);
+        a.m_S = magic(a.S, xm);
+        a.m_cgs = magic(a.cgs, xm);
+        a.m_cgsnt = magic(a.cgs * ntile, xm);
+        a.m_tx = magic(a.tiles_x, xm);
+        a.m_hp = magic(a.hp, 1024);
+        a.m_rem = magic(a.npx - kT > 0 ? a.npx - kT : 1, 1024);
+        a.m_tw = magic(a.tw, 1024);
     }
     hipStream_t s = (hipStream_t)stream;
     int rc;
