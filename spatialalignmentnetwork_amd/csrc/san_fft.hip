@@ -209,15 +209,29 @@ __device__ __forceinline__ void stockham_pass_any(float2* __restrict__ src, floa
     }
 }
 
-// Runs all passes; returns the buffer that holds the result.
+// Runs all passes; returns the buffer that holds the result.  flat_rows > 0: the butterflies of the prime radices above 5
+// are numbered over the whole workgroup (flat_rows active sequences) instead of per sequence.
 __device__ __forceinline__ float2* run_fft(const FftArgs& a, float2* bufA, float2* bufB, const float2* tw,
-                                           int seq, int lane, int tps, bool active, float sgn) {
+                                           int seq, int lane, int tps, bool active, float sgn, int flat_rows = 0) {
     float2* src = bufA;
     float2* dst = bufB;
     int Ns = 1;
     for (int p = 0; p < a.nrad; ++p) {
         const int R = a.rad[p];
-        if (active) {
+        if (flat_rows > 0 && (R == 7 || R == 11 || R == 13 || R == 23)) {
+            const int m = a.len / R;
+            for (int g = threadIdx.x; g < flat_rows * m; g += kThreads) {
+                const int sq = g / m, j = g - sq * m;
+                float2* s = src + sq * a.pitch;
+                float2* d = dst + sq * a.pitch;
+                switch (R) {
+                    case 7: stockham_pass_odd<7>(s, d, tw, a.len, Ns, a.ns_shift[p], j, m); break;
+                    case 11: stockham_pass_odd<11>(s, d, tw, a.len, Ns, a.ns_shift[p], j, m); break;
+                    case 13: stockham_pass_odd<13>(s, d, tw, a.len, Ns, a.ns_shift[p], j, m); break;
+                    default: stockham_pass_odd<23>(s, d, tw, a.len, Ns, a.ns_shift[p], j, m); break;
+                }
+            }
+        } else if (active) {
             float2* s = src + seq * a.pitch;
             float2* d = dst + seq * a.pitch;
             switch (R) {
@@ -242,6 +256,10 @@ __device__ __forceinline__ float2* run_fft(const FftArgs& a, float2* bufA, float
 }
 
 extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+#ifndef SAN_DC_PRE
+#define SAN_DC_PRE 1
+#endif
+constexpr int kDcPre = SAN_DC_PRE;   // dc_rows_kernel: S and r requested before (1) or after (0) the inverse transform
 
 // ------------------------------------------------------------------ row pass
 // grid: (ceil(H/B), outer); plane = outer*inner + l for l in [0, inner)
@@ -954,13 +972,255 @@ __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
     }
 }
 
-// Any row length: B rows per workgroup staged in LDS, both transforms with the mixed-radix Stockham passes.
+// ---------------------------------------------------------------- 368-wide rows (the multi-coil 640 x 368 planes)
+// 368 = 16 x 23, as TWO register passes per transform and no workgroup barrier: one wave owns 4 rows of one coil.
+//   n = n1 + 16 n2, k = 23 k1 + k2:   W368^(nk) = W16^(n1 k1) W368^(n1 k2) W23^(n2 k2)
+//   "23-side" task (row t, n1): lane = 16 t + n1 holds the 23 image samples n1 + 16 n2 (128-byte aligned runs of 16 lanes)
+//   "16-side" task (row t, k2): 92 tasks in two rounds hold the 16 frequencies 23 k1 + k2
+// forward: 23-point DFTs over n2 -> LDS -> twiddle, 16-point DFTs over n1 -> mask / k0 in registers -> inverse 16-point
+// -> conj twiddle -> LDS (the same slots) -> inverse 23-point DFTs -> epilogue on x, S, r held in registers since the
+// start of the kernel / of the inverse transform.  One LDS exchange per transform (the general kernel below: three
+// Stockham passes each, eight workgroup barriers, 2-3 workgroups per CU; measured 72 us against this kernel's
+// numbers in DESIGN.md section 3.5).
+constexpr int kN368 = 368;
+constexpr int kL368 = 4;            // rows per wave
+constexpr int kP368 = 400;          // LDS row pitch (float2): slot(t, n1, k2) = t * 400 + k2 * 17 + n1
+
+__device__ __constant__ float kC23[23] = {
+    1.f, 0.962917268f, 0.85441941f, 0.682553172f, 0.460065037f, 0.203456014f, -0.0682424158f, -0.334879607f, -0.576680303f,
+    -0.775711298f, -0.917211294f, -0.99068594f, -0.99068594f, -0.917211294f, -0.775711298f, -0.576680303f, -0.334879607f,
+    -0.0682424158f, 0.203456014f, 0.460065037f, 0.682553172f, 0.85441941f, 0.962917268f};
+__device__ __constant__ float kS23[23] = {
+    0.f, 0.269796759f, 0.519583941f, 0.730835974f, 0.887885213f, 0.979084074f, 0.997668743f, 0.942260921f, 0.816969872f,
+    0.631087959f, 0.398401082f, 0.136166647f, -0.136166647f, -0.398401082f, -0.631087959f, -0.816969872f, -0.942260921f,
+    -0.997668743f, -0.979084074f, -0.887885213f, -0.730835974f, -0.519583941f, -0.269796759f};
+
+template <int INV>
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
+    const float2 r = INV ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);   // -i d13 forward, +i d13 inverse
+    a0 = cadd(s02, s13);
+    a1 = cadd(d02, r);
+    a2 = csub(s02, s13);
+    a3 = csub(d02, r);
+}
+
+// v <- v * W16^m (forward) or its conjugate (INV); m a compile-time constant
+template <int INV, int M>
+__device__ __forceinline__ float2 tw16(float2 v) {
+    constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+    constexpr int m = M & 15;
+    if constexpr (m == 0) {
+        return v;
+    } else if constexpr (m == 4) {
+        return INV ? make_float2(-v.y, v.x) : make_float2(v.y, -v.x);
+    } else {
+        static_assert(m == 1 || m == 2 || m == 3 || m == 6 || m == 9, "twiddle not tabulated");
+        constexpr float co = m == 1 ? c1 : m == 2 ? h : m == 3 ? s1 : m == 6 ? -h : -c1;
+        constexpr float si = m == 1 ? s1 : m == 2 ? h : m == 3 ? c1 : m == 6 ? h : -s1;
+        return cmul(v, make_float2(co, INV ? si : -si));
+    }
+}
+
+// 16-point DFT in registers: n1 = 4 a + b, k1 = c + 4 d:  W16^(n1 k1) = W4^(a c) W16^(b c) W4^(b d).  o[k1] in natural order.
+template <int INV>
+__device__ __forceinline__ void dft16(float2 (&v)[16], float2 (&o)[16]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4<INV>(v[b], v[4 + b], v[8 + b], v[12 + b]);          // over a; result index c at 4 c + b
+    v[5] = tw16<INV, 1>(v[5]);
+    v[6] = tw16<INV, 2>(v[6]);
+    v[7] = tw16<INV, 3>(v[7]);
+    v[9] = tw16<INV, 2>(v[9]);
+    v[10] = tw16<INV, 4>(v[10]);
+    v[11] = tw16<INV, 6>(v[11]);
+    v[13] = tw16<INV, 3>(v[13]);
+    v[14] = tw16<INV, 6>(v[14]);
+    v[15] = tw16<INV, 9>(v[15]);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        dft4<INV>(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);                 // over b; result index d at 4 c + d
+#pragma unroll
+        for (int d = 0; d < 4; ++d) o[c + 4 * d] = v[4 * c + d];
+    }
+}
+
+// 23-point DFT of u[0..22] (registers), outputs written to dst[q * 17] (this lane's LDS slots).  Conjugate-symmetric
+// form: a_r = u_r + u_(23-r), b_r = u_r - u_(23-r); out_q = u_0 + sum a_r cos - i sum b_r sin (forward; + i inverse),
+// out_(23-q) its mirror.  One output pair per iteration (not unrolled: all eleven sums in flight need > 256 registers);
+// the coefficients are wave-uniform scalar loads from the constant tables.
+template <int INV>
+__device__ __forceinline__ void dft23_to_lds(const float2 (&u)[23], float2* __restrict__ dst) {
+    float2 a[11], b[11];
+    float2 s0 = u[0];
+#pragma unroll
+    for (int r = 0; r < 11; ++r) {
+        a[r] = cadd(u[r + 1], u[22 - r]);
+        b[r] = csub(u[r + 1], u[22 - r]);
+        s0 = cadd(s0, a[r]);
+    }
+    dst[0] = s0;
+#pragma unroll 1
+    for (int q = 1; q <= 11; ++q) {
+        float2 P = u[0], Q = make_float2(0.f, 0.f);
+        int qr = 0;
+#pragma unroll
+        for (int r = 0; r < 11; ++r) {
+            qr += q;
+            if (qr >= 23) qr -= 23;
+            const float co = kC23[qr], si = kS23[qr];
+            P.x = fmaf(a[r].x, co, P.x);
+            P.y = fmaf(a[r].y, co, P.y);
+            Q.x = fmaf(b[r].x, si, Q.x);
+            Q.y = fmaf(b[r].y, si, Q.y);
+        }
+        // forward: P - iQ at q, P + iQ at 23 - q;  i Q = (-Q.y, Q.x)
+        const float2 lo = make_float2(P.x + Q.y, P.y - Q.x), hi = make_float2(P.x - Q.y, P.y + Q.x);
+        dst[q * 17] = INV ? hi : lo;
+        dst[(23 - q) * 17] = INV ? lo : hi;
+    }
+}
+
 template <int MODE>
+__global__ void __launch_bounds__(64) dc_rows368_kernel(const FftArgs a) {
+    __shared__ float2 lds[kL368 * kP368];
+    __shared__ float2 tws[kN368];
+    __shared__ float msk[kN368];
+    const int lane = threadIdx.x;
+    const int W = kN368, H = a.H;
+    const int h0 = blockIdx.x * kL368;
+    const int n = blockIdx.y, c = blockIdx.z;
+    const size_t pbase = (size_t)(n * a.C + c) * H * W;
+    // 23-side task of this lane
+    const int tA = lane >> 4, n1 = lane & 15;
+    const int rowA = min(h0 + tA, H - 1);
+    const bool liveA = h0 + tA < H;
+    const size_t eA = pbase + (size_t)rowA * W + n1;
+    float2* slotA = lds + tA * kP368 + n1;                 // + k2 * 17
+    // 16-side tasks (two rounds)
+    int tB[2], k2B[2];
+    bool actB[2], liveB[2];
+    size_t eB[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int id = it * 64 + lane;
+        actB[it] = id < kL368 * 23;
+        tB[it] = actB[it] ? id / 23 : 0;
+        k2B[it] = actB[it] ? id - 23 * tB[it] : 0;
+        liveB[it] = actB[it] && h0 + tB[it] < H;
+        eB[it] = pbase + (size_t)min(h0 + tB[it], H - 1) * W + k2B[it];
+    }
+    // operands: x now (kept for the epilogue), k0 / dk_in for the mask stage
+    float2 xo[23];
+#pragma unroll
+    for (int q = 0; q < 23; ++q) xo[q] = a.in[eA + 16 * q];
+    float2 kq[2][16];
+    {
+        const float2* kp = MODE == 0 ? a.k0 : a.dk_in;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) kq[it][k1] = (kp && actB[it]) ? kp[eB[it] + 23 * k1] : make_float2(0.f, 0.f);
+    }
+    for (int i = lane; i < kN368; i += 64) {
+        tws[i] = a.tw[i];
+        msk[i] = a.mask[i];
+    }
+    const float dcw = a.dcw[0];
+    dft23_to_lds<0>(xo, slotA);
+    __syncthreads();
+    float wsum = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (!actB[it]) continue;
+        float2* slotB = lds + tB[it] * kP368 + k2B[it] * 17;      // + n1
+        float2 v[16], X[16], tw[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            tw[j] = tws[j * k2B[it]];
+            v[j] = cmul(slotB[j], tw[j]);
+        }
+        dft16<0>(v, X);
+#pragma unroll
+        for (int k1 = 0; k1 < 16; ++k1) {
+            const float m = msk[23 * k1 + k2B[it]];
+            const float2 Xs = make_float2(X[k1].x * a.scale, X[k1].y * a.scale);
+            if (MODE == 0) {
+                v[k1] = make_float2(m * (Xs.x - kq[it][k1].x), m * (Xs.y - kq[it][k1].y));
+                if (a.dk_out && liveB[it]) a.dk_out[eB[it] + 23 * k1] = v[k1];
+            } else {
+                v[k1] = make_float2(m * Xs.x, m * Xs.y);
+                if (liveB[it]) wsum += Xs.x * kq[it][k1].x + Xs.y * kq[it][k1].y;
+            }
+        }
+        dft16<1>(v, X);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) slotB[j] = cmul(X[j], make_float2(tw[j].x, -tw[j].y));
+    }
+    __syncthreads();
+    // epilogue operands, requested before the inverse 23-point transforms
+    float2 sv[23];
+    float rre[23], rim[23];
+    {
+        const size_t pe = ((size_t)n * 2 * H + rowA) * W + n1;
+#pragma unroll
+        for (int q = 0; q < 23; ++q) {
+            sv[q] = a.sens[eA + 16 * q];
+            if (MODE == 0 && a.in_planar) {
+                rre[q] = a.in_planar[pe + 16 * q];
+                rim[q] = a.in_planar[pe + 16 * q + (size_t)H * W];
+            } else {
+                rre[q] = rim[q] = 0.f;
+            }
+        }
+    }
+    {
+        float2 u[23];
+#pragma unroll
+        for (int q = 0; q < 23; ++q) u[q] = slotA[q * 17];
+        dft23_to_lds<1>(u, slotA);
+    }
+    // (the 23 results are this lane's own slots: no barrier)
+    const bool comb = a.out_real && a.C == 1;
+    const size_t pr = ((size_t)n * a.out_ctot * H + rowA) * W + n1;
+    if (liveA) {
+#pragma unroll
+        for (int q = 0; q < 23; ++q) {
+            const float2 y = slotA[q * 17];
+            const float2 s = sv[q];
+            float2 v = make_float2(xo[q].x - dcw * (y.x * a.scale), xo[q].y - dcw * (y.y * a.scale));
+            if (MODE == 0) {
+                v.x -= rre[q] * s.x - rim[q] * s.y;
+                v.y -= rre[q] * s.y + rim[q] * s.x;
+            }
+            if (a.out) a.out[eA + 16 * q] = v;
+            if (comb) {
+                const float2 qv = MODE == 0 ? v : xo[q];
+                a.out_real[pr + 16 * q] = (qv.x * s.x + qv.y * s.y) * a.m_scale;
+                a.out_real[pr + 16 * q + (size_t)H * W] = (qv.y * s.x - qv.x * s.y) * a.m_scale;
+            }
+        }
+    }
+    if (MODE == 1 && a.dcw_part) {
+        wsum = san_wave_total(wsum);
+        if (lane == 0) a.dcw_part[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = wsum;
+    }
+}
+
+// Any row length: B rows of ONE coil per workgroup (grid: row blocks, samples, coils) staged in LDS, both transforms with
+// the mixed-radix Stockham passes.  Every element e of the B x W tile belongs to thread e % kThreads in all phases, so the
+// operands travel in registers: x (loaded once, used again by the epilogue), k0 / dk_in requested before the forward
+// transform, S and r before (PRE) or in one batch after the inverse one -- never one dependent HBM round trip per element
+// (measured at 15 x 640 x 368: the per-element load / use loops were ~35 serial round trips per workgroup, 42 us of the
+// 72; the transforms 28 us).  Prime radices above 5 run with the workgroup's butterflies spread over ALL threads
+// (16 butterflies per 368-row leave half of every wave idle in the per-row mapping).
+// With several coils coil_combine_kernel follows; a single-coil launch writes the coil combination itself.
+template <int MODE, int EPT, int PRE>
 __global__ void __launch_bounds__(kThreads, 2) dc_rows_kernel(const FftArgs a) {
     float2* twf = reinterpret_cast<float2*>(smem_raw);
     float2* twi = twf + a.len;
     float2* bufA = twi + a.len;
     float2* bufB = bufA + a.B * a.pitch;
+    float* msk = reinterpret_cast<float*>(bufB + a.B * a.pitch);
     const int tid = threadIdx.x;
     const int W = a.W, H = a.H;
     const int h0 = blockIdx.x * a.B;
@@ -969,70 +1229,98 @@ __global__ void __launch_bounds__(kThreads, 2) dc_rows_kernel(const FftArgs a) {
     const int tps = kThreads >> a.logB;
     const int seq = tid / tps;
     const int lane = tid - seq * tps;
-    const int n = blockIdx.y;
+    const int n = blockIdx.y, c = blockIdx.z;
+    const size_t base = ((size_t)(n * a.C + c) * H + h0) * W;
+    float2 xo[EPT], kq[EPT];
+    {
+        const float2* kp = MODE == 0 ? a.k0 : a.dk_in;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + k * kThreads;
+            xo[k] = e < cnt ? a.in[base + e] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + k * kThreads;
+            kq[k] = (kp && e < cnt) ? kp[base + e] : make_float2(0.f, 0.f);
+        }
+    }
     for (int i = tid; i < a.len; i += kThreads) {
         const float2 t = a.tw[i];
         twf[i] = t;
         twi[i] = make_float2(t.x, -t.y);
     }
+    for (int i = tid; i < W; i += kThreads) msk[i] = a.mask[i];
     const float dcw = a.dcw[0];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * kThreads;
+        if (e < cnt) bufA[e] = xo[k];
+    }
+    __syncthreads();
+    float2* res = run_fft(a, bufA, bufB, twf, seq, lane, tps, seq < rows, 1.f, rows);
     float wsum = 0.f;
-    // multi-coil launches run one coil per workgroup (blockIdx.z) and leave the coil combination to coil_combine_kernel:
-    // a serial coil loop left 80 workgroups with 15 planes each at 640 x 368
-    const bool cpar = gridDim.z > 1;
-    const int c_lo = cpar ? blockIdx.z : 0, c_hi = cpar ? blockIdx.z + 1 : a.C;
-    for (int c = c_lo; c < c_hi; ++c) {
-        const size_t base = ((size_t)(n * a.C + c) * H + h0) * W;
-        __syncthreads();
-        for (int e = tid; e < a.B * W; e += kThreads) bufA[e] = e < cnt ? a.in[base + e] : make_float2(0.f, 0.f);
-        __syncthreads();
-        float2* res = run_fft(a, bufA, bufB, twf, seq, lane, tps, seq < rows, 1.f);
-        {
-            int wi = tid % W;
-            for (int e = tid; e < cnt; e += kThreads) {
+    {
+        int wi = tid % W;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + k * kThreads;
+            if (e < cnt) {
                 const float2 X = make_float2(res[e].x * a.scale, res[e].y * a.scale);
-                const float m = a.mask[wi];
+                const float m = msk[wi];
                 float2 d;
                 if (MODE == 0) {
-                    const float2 k0 = a.k0 ? a.k0[base + e] : make_float2(0.f, 0.f);
-                    d = make_float2(m * (X.x - k0.x), m * (X.y - k0.y));
+                    d = make_float2(m * (X.x - kq[k].x), m * (X.y - kq[k].y));
                     if (a.dk_out) a.dk_out[base + e] = d;
                 } else {
                     d = make_float2(m * X.x, m * X.y);
-                    if (a.dk_in) {
-                        const float2 q = a.dk_in[base + e];
-                        wsum += X.x * q.x + X.y * q.y;
-                    }
+                    wsum += X.x * kq[k].x + X.y * kq[k].y;
                 }
                 res[e] = d;
-                wi += kThreads % W;
-                if (wi >= W) wi -= W;
             }
+            wi += kThreads % W;
+            if (wi >= W) wi -= W;
         }
-        __syncthreads();
-        float2* other = res == bufA ? bufB : bufA;
-        float2* res2 = run_fft(a, res, other, twi, seq, lane, tps, seq < rows, -1.f);
-        const size_t rbase = ((size_t)n * 2 * H + h0) * W;
-        // (single-coil launches write the coil combination here; with several coils every workgroup has ONE coil and
-        // coil_combine_kernel follows: no per-thread accumulators across the transforms)
-        const bool comb = a.out_real && !cpar;
-        const size_t rb = ((size_t)n * a.out_ctot * H + h0) * W;
-        for (int e = tid; e < cnt; e += kThreads) {
-            {
-                const float2 xo = a.in[base + e];
-                const float2 s = a.sens[base + e];
-                float2 v = make_float2(xo.x - dcw * (res2[e].x * a.scale), xo.y - dcw * (res2[e].y * a.scale));
-                if (MODE == 0 && a.in_planar) {
-                    const float rr = a.in_planar[rbase + e], ri = a.in_planar[rbase + e + (size_t)H * W];
-                    v.x -= rr * s.x - ri * s.y;
-                    v.y -= rr * s.y + ri * s.x;
-                }
-                if (a.out) a.out[base + e] = v;
-                if (comb) {
-                    const float2 q = MODE == 0 ? v : xo;
-                    a.out_real[rb + e] = (q.x * s.x + q.y * s.y) * a.m_scale;
-                    a.out_real[rb + e + (size_t)H * W] = (q.y * s.x - q.x * s.y) * a.m_scale;
-                }
+    }
+    __syncthreads();
+    const size_t rbase = ((size_t)n * 2 * H + h0) * W;
+    const bool with_r = MODE == 0 && a.in_planar;
+    float2 sv[EPT];
+    float rre[EPT], rim[EPT];
+    auto load_epi = [&]() {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + k * kThreads;
+            sv[k] = e < cnt ? a.sens[base + e] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + k * kThreads;
+            rre[k] = (with_r && e < cnt) ? a.in_planar[rbase + e] : 0.f;
+            rim[k] = (with_r && e < cnt) ? a.in_planar[rbase + e + (size_t)H * W] : 0.f;
+        }
+    };
+    if (PRE) load_epi();
+    float2* other = res == bufA ? bufB : bufA;
+    float2* res2 = run_fft(a, res, other, twi, seq, lane, tps, seq < rows, -1.f, rows);
+    if (!PRE) load_epi();
+    const bool comb = a.out_real && a.C == 1;
+    const size_t rb = ((size_t)n * a.out_ctot * H + h0) * W;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + k * kThreads;
+        if (e < cnt) {
+            const float2 s = sv[k];
+            float2 v = make_float2(xo[k].x - dcw * (res2[e].x * a.scale), xo[k].y - dcw * (res2[e].y * a.scale));
+            if (MODE == 0) {
+                v.x -= rre[k] * s.x - rim[k] * s.y;
+                v.y -= rre[k] * s.y + rim[k] * s.x;
+            }
+            if (a.out) a.out[base + e] = v;
+            if (comb) {
+                const float2 q = MODE == 0 ? v : xo[k];
+                a.out_real[rb + e] = (q.x * s.x + q.y * s.y) * a.m_scale;
+                a.out_real[rb + e + (size_t)H * W] = (q.y * s.x - q.x * s.y) * a.m_scale;
             }
         }
     }
@@ -1493,6 +1781,8 @@ int san_ifft2_rss_from_cols(const float* k_cols, float* out, int n, int c, int h
 static void dc_rows_geom(int h, int w, int* B, int* gx) {
     if (w == kN320) {
         *B = kL320;
+    } else if (w == kN368) {
+        *B = kL368;
     } else {
         int b = 8;
         while (b > 1 && (size_t)b * w * sizeof(float2) * 2 > 60 * 1024) b >>= 1;
@@ -1563,6 +1853,13 @@ int san_dc_rows(const float* x, const float* sens, const float* k0x, const float
         SAN_LAUNCH_CHECK();
         return SAN_OK;
     }
+    const bool w368 = w == kN368 && !getenv("SAN_DC_GENERIC");
+    if (w368) {
+        const dim3 grid(gx, n, c);
+        if (backward) hipLaunchKernelGGL((dc_rows368_kernel<1>), grid, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL((dc_rows368_kernel<0>), grid, dim3(64), 0, s, a);
+        SAN_LAUNCH_CHECK();
+    } else {
     a.B = B;
     if (a.B * a.W > 24 * kThreads) {
         san_set_error("row length %d too long for the image-domain cascade kernel", w);
@@ -1570,23 +1867,29 @@ int san_dc_rows(const float* x, const float* sens, const float* k0x, const float
     }
     a.logB = ilog2(a.B);
     a.pitch = a.len;
-    const size_t lds = sizeof(float2) * (2 * (size_t)a.len + 2 * (size_t)a.B * a.pitch);
+    const size_t lds = sizeof(float2) * (2 * (size_t)a.len + 2 * (size_t)a.B * a.pitch) + sizeof(float) * (size_t)w;
     if (lds > 160 * 1024) {
         san_set_error("fft row of %d does not fit LDS", a.len);
         return SAN_E_UNSUPPORTED;
     }
-    static std::once_flag once;
-    static hipError_t err = hipSuccess;
-    std::call_once(once, [] {
-        err = hipFuncSetAttribute(reinterpret_cast<const void*>(dc_rows_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (err == hipSuccess)
-            err = hipFuncSetAttribute(reinterpret_cast<const void*>(dc_rows_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    });
-    if (err != hipSuccess) return (int)err;
+    // elements per thread: 12 covers 8 rows of up to 384; the 24 form (long rows) loads S and r after the inverse transform
+    const bool small = a.B * a.W <= 12 * kThreads;
+    const void* fn = small ? (backward ? (const void*)dc_rows_kernel<1, 12, kDcPre> : (const void*)dc_rows_kernel<0, 12, kDcPre>)
+                           : (backward ? (const void*)dc_rows_kernel<1, 24, 0> : (const void*)dc_rows_kernel<0, 24, 0>);
+    {
+        static std::mutex mu;
+        static std::map<const void*, hipError_t> done;
+        std::lock_guard<std::mutex> g(mu);
+        auto it = done.find(fn);
+        if (it == done.end()) it = done.emplace(fn, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)).first;
+        if (it->second != hipSuccess) return (int)it->second;
+    }
     const dim3 grid(gx, n, c);
-    if (backward) hipLaunchKernelGGL((dc_rows_kernel<1>), grid, dim3(kThreads), lds, s, a);
-    else hipLaunchKernelGGL((dc_rows_kernel<0>), grid, dim3(kThreads), lds, s, a);
+    void* params[] = {(void*)&a};
+    hipError_t le = hipLaunchKernel(fn, grid, dim3(kThreads), params, lds, s);
+    if (le != hipSuccess) return (int)le;
     SAN_LAUNCH_CHECK();
+    }
     if (c > 1 && m_out) {
         // coil combination in its own pass: of the result (forward) or of the incoming gradient (backward)
         const float2* q = backward ? (const float2*)x : (const float2*)x_out;
