@@ -38,3 +38,9 @@ for N, C, H, W in shapes:
     own = (4 * C + 2) * N * H * W * 8
     print(f"dc_rows N={N} C={C} {H}x{W}: {t:7.1f} us  {own / t / 1e3:6.0f} GB/s on its own (4C+2) planes, "
           f"{(6 * C + 2) * N * H * W * 8 / t / 1e3:6.0f} GB/s on the SURVEY 8(d) count", flush=True)
+    if os.environ.get("DC_TRAIN"):
+        dk = torch.empty_like(x)
+        t1 = bench(lambda: ops.dc_rows(x, s, k0, mask, dcw, r, xo, m, dk_out=dk))
+        gw = torch.zeros(1, device=dev)
+        t2 = bench(lambda: ops.dc_rows_bwd(x, s, mask, dcw, xo, m, dk, gw))
+        print(f"   training forward (+ dk_out) {t1:7.1f} us   backward {t2:7.1f} us", flush=True)

@@ -986,15 +986,6 @@ constexpr int kN368 = 368;
 constexpr int kL368 = 4;            // rows per wave
 constexpr int kP368 = 400;          // LDS row pitch (float2): slot(t, n1, k2) = t * 400 + k2 * 17 + n1
 
-__device__ __constant__ float kC23[23] = {
-    1.f, 0.962917268f, 0.85441941f, 0.682553172f, 0.460065037f, 0.203456014f, -0.0682424158f, -0.334879607f, -0.576680303f,
-    -0.775711298f, -0.917211294f, -0.99068594f, -0.99068594f, -0.917211294f, -0.775711298f, -0.576680303f, -0.334879607f,
-    -0.0682424158f, 0.203456014f, 0.460065037f, 0.682553172f, 0.85441941f, 0.962917268f};
-__device__ __constant__ float kS23[23] = {
-    0.f, 0.269796759f, 0.519583941f, 0.730835974f, 0.887885213f, 0.979084074f, 0.997668743f, 0.942260921f, 0.816969872f,
-    0.631087959f, 0.398401082f, 0.136166647f, -0.136166647f, -0.398401082f, -0.631087959f, -0.816969872f, -0.942260921f,
-    -0.997668743f, -0.979084074f, -0.887885213f, -0.730835974f, -0.519583941f, -0.269796759f};
-
 template <int INV>
 __device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
     const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = csub(a1, a3);
@@ -1046,10 +1037,19 @@ __device__ __forceinline__ void dft16(float2 (&v)[16], float2 (&o)[16]) {
 
 // 23-point DFT of u[0..22] (registers), outputs written to dst[q * 17] (this lane's LDS slots).  Conjugate-symmetric
 // form: a_r = u_r + u_(23-r), b_r = u_r - u_(23-r); out_q = u_0 + sum a_r cos - i sum b_r sin (forward; + i inverse),
-// out_(23-q) its mirror.  One output pair per iteration (not unrolled: all eleven sums in flight need > 256 registers);
-// the coefficients are wave-uniform scalar loads from the constant tables.
+// out_(23-q) its mirror.  Fully unrolled: every coefficient is an instruction constant (as a rolled loop over q the 22
+// coefficients of an iteration were dependent scalar loads, one s_waitcnt per multiply-add: 9 of the wave's 27 us); the
+// scheduling barrier keeps the eleven output pairs from being interleaved (all sums in flight need > 256 registers).
 template <int INV>
 __device__ __forceinline__ void dft23_to_lds(const float2 (&u)[23], float2* __restrict__ dst) {
+    constexpr float C[23] = {
+        1.f, 0.962917268f, 0.85441941f, 0.682553172f, 0.460065037f, 0.203456014f, -0.0682424158f, -0.334879607f, -0.576680303f,
+        -0.775711298f, -0.917211294f, -0.99068594f, -0.99068594f, -0.917211294f, -0.775711298f, -0.576680303f, -0.334879607f,
+        -0.0682424158f, 0.203456014f, 0.460065037f, 0.682553172f, 0.85441941f, 0.962917268f};
+    constexpr float S[23] = {
+        0.f, 0.269796759f, 0.519583941f, 0.730835974f, 0.887885213f, 0.979084074f, 0.997668743f, 0.942260921f, 0.816969872f,
+        0.631087959f, 0.398401082f, 0.136166647f, -0.136166647f, -0.398401082f, -0.631087959f, -0.816969872f, -0.942260921f,
+        -0.997668743f, -0.979084074f, -0.887885213f, -0.730835974f, -0.519583941f, -0.269796759f};
     float2 a[11], b[11];
     float2 s0 = u[0];
 #pragma unroll
@@ -1059,15 +1059,12 @@ __device__ __forceinline__ void dft23_to_lds(const float2 (&u)[23], float2* __re
         s0 = cadd(s0, a[r]);
     }
     dst[0] = s0;
-#pragma unroll 1
+#pragma unroll
     for (int q = 1; q <= 11; ++q) {
         float2 P = u[0], Q = make_float2(0.f, 0.f);
-        int qr = 0;
 #pragma unroll
         for (int r = 0; r < 11; ++r) {
-            qr += q;
-            if (qr >= 23) qr -= 23;
-            const float co = kC23[qr], si = kS23[qr];
+            const float co = C[(q * (r + 1)) % 23], si = S[(q * (r + 1)) % 23];
             P.x = fmaf(a[r].x, co, P.x);
             P.y = fmaf(a[r].y, co, P.y);
             Q.x = fmaf(b[r].x, si, Q.x);
@@ -1077,6 +1074,7 @@ __device__ __forceinline__ void dft23_to_lds(const float2 (&u)[23], float2* __re
         const float2 lo = make_float2(P.x + Q.y, P.y - Q.x), hi = make_float2(P.x - Q.y, P.y + Q.x);
         dst[q * 17] = INV ? hi : lo;
         dst[(23 - q) * 17] = INV ? lo : hi;
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -373,7 +373,8 @@ def sens_reduce(k: torch.Tensor, sens: torch.Tensor, out: torch.Tensor, cols: Op
             _stream())
     fn = "san_sens_reduce" if cols is None else "san_sens_reduce_from_cols"
     # algorithmic bytes: read k and S (C planes each), write m (1 plane); E = H*W*8
-    _timed("fft_dc", float((2 * c + 1) * n * h * w * 8), "B", lambda: lib().call(fn, *args))
+    # (its own family: one launch per forward pass, not a cascade boundary -- as "fft_dc" it was always the first, sampled, launch)
+    _timed("fft_sens", float((2 * c + 1) * n * h * w * 8), "B", lambda: lib().call(fn, *args))
     return out
 
 
@@ -394,7 +395,7 @@ def sens_expand_dc(r_planar: torch.Tensor, sens: torch.Tensor, k: torch.Tensor, 
     else:
         fn, args = "san_sens_expand_dc_next", head + (_p(_creal(next_cols, "next_cols")),) + tail
     # algorithmic bytes: read r (1 plane), S, k, k0 (C planes each), write k' (C planes)
-    _timed("fft_dc", float((4 * c + 1) * n * h * w * 8), "B", lambda: lib().call(fn, *args))
+    _timed("fft_sens", float((4 * c + 1) * n * h * w * 8), "B", lambda: lib().call(fn, *args))
     return k_out
 
 
