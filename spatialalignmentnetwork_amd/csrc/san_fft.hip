@@ -470,14 +470,20 @@ __global__ void __launch_bounds__(kThreads) fft_cols_kernel(const FftArgs a) {
 // MAP 1 (columns): line = one image column, lanes = 16 rows x 4 adjacent columns
 constexpr int kN320 = 320;
 constexpr int kL320 = 4;           // lines per wave
+constexpr int kDcL320 = 2;         // ... of the cascade kernel (dc_rows320_kernel), see Map320
 constexpr int kP320 = 321;         // LDS pitch (float2)
 
-template <int MAP>
+// L: lines per wave.  4 everywhere (5 radix-4 butterflies per lane and pass) except the cascade kernel dc_rows320_kernel, which
+// runs 2 (three rounds, the last one half empty: its upper lanes repeat their previous round's butterflies -- same loads, same
+// LDS stores): half the serial chain per wave and twice the waves, on a launch that has only 2.5 waves per CU at N = 8.
+template <int MAP, int L = 4>
 struct Map320 {
+    static constexpr int RA = (L * 80 + 63) / 64;      // rounds of the radix-4 passes
     // radix-4 passes: butterfly t of this lane -> (line, j), j in [0, 80)
     __device__ static void r4(int lane, int t, int& line, int& j) {
         if (MAP == 0) {
-            const int b = lane + 64 * t;
+            int b = lane + 64 * t;
+            if (b >= L * 80) b -= 64;                   // (last round: the lane repeats its previous butterfly)
             line = b / 80;
             j = b - line * 80;
         } else {
@@ -529,15 +535,16 @@ __device__ __forceinline__ void bfly5(float2 (&v)[5], float sgn) {
 
 // The FFT core.  in[t][r] : pass-A inputs of butterfly t (element j + 80 r of its line).
 // out[t][r]: final outputs of radix-5 butterfly t (element j + 64 r of its line).
-template <int MAP>
-__device__ __forceinline__ void fft320_core(float2 (&in)[5][4], float2 (&out)[4][5], float2* lds,
+template <int MAP, int L = 4, int RA = (L * 80 + 63) / 64>
+__device__ __forceinline__ void fft320_core(float2 (&in)[RA][4], float2 (&out)[L][5], float2* lds,
                                             const float2* twg, float sgn, int lane) {
-    int lineA[5], jA[5];
+    static_assert(MAP == 0 || L == 4, "the column map is written for four lines");
+    int lineA[RA], jA[RA];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) Map320<MAP>::r4(lane, t, lineA[t], jA[t]);
+    for (int t = 0; t < RA; ++t) Map320<MAP, L>::r4(lane, t, lineA[t], jA[t]);
     // ---- pass A: radix 4, Ns = 1 (no twiddles); out index 4 j + r
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < RA; ++t) {
         bfly4(in[t], sgn);
         float2* d = lds + lineA[t] * kP320 + 4 * jA[t];
 #pragma unroll
@@ -546,14 +553,14 @@ __device__ __forceinline__ void fft320_core(float2 (&in)[5][4], float2 (&out)[4]
     __syncthreads();
     // ---- pass B: radix 4, Ns = 4; twiddle W^(r * kk * 20); out index jq*16 + kk + 4 r
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < RA; ++t) {
         const float2* s = lds + lineA[t] * kP320 + jA[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) in[t][r] = s[80 * r];
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < RA; ++t) {
         const int kk = jA[t] & 3, jq = jA[t] >> 2;
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
@@ -569,14 +576,14 @@ __device__ __forceinline__ void fft320_core(float2 (&in)[5][4], float2 (&out)[4]
     __syncthreads();
     // ---- pass C: radix 4, Ns = 16; twiddle W^(r * kk * 5); out index jq*64 + kk + 16 r
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < RA; ++t) {
         const float2* s = lds + lineA[t] * kP320 + jA[t];
 #pragma unroll
         for (int r = 0; r < 4; ++r) in[t][r] = s[80 * r];
     }
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < RA; ++t) {
         const int kk = jA[t] & 15, jq = jA[t] >> 4;
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
@@ -592,9 +599,9 @@ __device__ __forceinline__ void fft320_core(float2 (&in)[5][4], float2 (&out)[4]
     __syncthreads();
     // ---- pass D: radix 5, Ns = 64; twiddle W^(r * j); out index j + 64 r
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < L; ++t) {
         int line, j;
-        Map320<MAP>::r5(lane, t, line, j);
+        Map320<MAP, L>::r5(lane, t, line, j);
         const float2* s = lds + line * kP320 + j;
 #pragma unroll
         for (int r = 0; r < 5; ++r) out[t][r] = s[64 * r];
@@ -842,42 +849,43 @@ __global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
 //        INPUT g: gradient wrt the regulariser output), and one partial of Re sum conj(fft_x(g)) dk per workgroup.
 template <int MODE>
 __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
-    __shared__ float2 lds[kL320 * kP320];
+    __shared__ float2 lds[kDcL320 * kP320];
     __shared__ float2 tws[kN320];
     const int lane = threadIdx.x;
 #pragma unroll
     for (int r = 0; r < 5; ++r) tws[lane + 64 * r] = a.tw[lane + 64 * r];
     const int W = kN320, H = a.H;
-    const int h0 = blockIdx.x * kL320;
+    constexpr int L = kDcL320, RA = Map320<0, L>::RA;
+    const int h0 = blockIdx.x * L;
     const int n = blockIdx.y;
     const float dcw = a.dcw[0];
     float mk[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) mk[r] = a.mask[lane + 64 * r];
-    float2 macc[4][5];
+    float2 macc[L][5];
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < L; ++t)
 #pragma unroll
         for (int r = 0; r < 5; ++r) macc[t][r] = make_float2(0.f, 0.f);
     float wsum = 0.f;
-    int lineA[5], jA[5];
+    int lineA[RA], jA[RA];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) Map320<0>::r4(lane, t, lineA[t], jA[t]);
+    for (int t = 0; t < RA; ++t) Map320<0, L>::r4(lane, t, lineA[t], jA[t]);
 
     for (int c = 0; c < a.C; ++c) {
         const size_t pbase = (size_t)(n * a.C + c) * H * W;
-        float2 in[5][4], out[4][5];
+        float2 in[RA][4], out[L][5];
         if (c > 0) __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
+        for (int t = 0; t < RA; ++t) {
             const int e = min(h0 + lineA[t], H - 1) * W + jA[t];
 #pragma unroll
             for (int r = 0; r < 4; ++r) in[t][r] = a.in[pbase + e + 80 * r];
         }
         // the k_x-domain operand is requested before the transform so that its latency hides under it
-        float2 kq[4][5];
+        float2 kq[L][5];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < L; ++t) {
             const size_t e = pbase + (size_t)min(h0 + t, H - 1) * W + lane;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
@@ -885,9 +893,9 @@ __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
                 else kq[t][r] = a.dk_in ? a.dk_in[e + 64 * r] : make_float2(0.f, 0.f);
             }
         }
-        fft320_core<0>(in, out, lds, tws, 1.f, lane);
+        fft320_core<0, L>(in, out, lds, tws, 1.f, lane);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < L; ++t) {
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
                 const float2 X = make_float2(out[t][r].x * a.scale, out[t][r].y * a.scale);
@@ -905,20 +913,20 @@ __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
         // one LDS exchange converts the radix-5 output layout (element lane + 64 r) into the pass-A input layout
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < L; ++t)
 #pragma unroll
             for (int r = 0; r < 5; ++r) lds[t * kP320 + lane + 64 * r] = out[t][r];
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
+        for (int t = 0; t < RA; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) in[t][r] = lds[lineA[t] * kP320 + jA[t] + 80 * r];
         __syncthreads();
         // epilogue operands, requested before the inverse transform
-        float2 xo[4][5], sv[4][5];
-        float rre[4][5], rim[4][5];
+        float2 xo[L][5], sv[L][5];
+        float rre[L][5], rim[L][5];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < L; ++t) {
             const int row = min(h0 + t, H - 1);
             const size_t e = pbase + (size_t)row * W + lane;
             const size_t pe = ((size_t)n * 2 * H + row) * W + lane;
@@ -934,9 +942,9 @@ __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
                 }
             }
         }
-        fft320_core<0>(in, out, lds, tws, -1.f, lane);
+        fft320_core<0, L>(in, out, lds, tws, -1.f, lane);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < L; ++t) {
             if (h0 + t >= H) continue;
             const size_t e = pbase + (size_t)(h0 + t) * W + lane;
 #pragma unroll
@@ -956,7 +964,7 @@ __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
     }
     if (a.out_real) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < L; ++t) {
             if (h0 + t >= H) continue;
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
@@ -1778,7 +1786,7 @@ int san_ifft2_rss_from_cols(const float* k_cols, float* out, int n, int c, int h
 // rows per workgroup and grid of the image-domain cascade kernels (also sizes the dc_weight partials)
 static void dc_rows_geom(int h, int w, int* B, int* gx) {
     if (w == kN320) {
-        *B = kL320;
+        *B = kDcL320;
     } else if (w == kN368) {
         *B = kL368;
     } else {
