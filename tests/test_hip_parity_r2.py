@@ -178,12 +178,14 @@ def test_normunet_backward_with_constant_plane(S):
 
 
 # ------------------------------------------------------------------ image-domain cascade boundary
-@pytest.mark.parametrize("n,c,h,w", [(2, 1, 320, 320), (1, 3, 320, 320), (2, 3, 48, 80), (1, 2, 46, 368), (2, 1, 30, 45), (1, 1, 6, 320)])
+@pytest.mark.parametrize("n,c,h,w", [(2, 1, 320, 320), (1, 3, 320, 320), (2, 3, 48, 80), (1, 2, 46, 368), (2, 1, 30, 45), (1, 1, 6, 320),
+                                     (1, 2, 7, 320), (2, 1, 9, 368), (1, 15, 8, 368)])
 def test_dc_rows_vs_kspace_formula(S, n, c, h, w):
     """san_dc_rows (one row-local launch per cascade on x = ifft2(k)) against the reference's k-space update
     k' = k - w where(M, k - k0, 0) - fft2(r S), m' = sum_c ifft2(k')_c conj(S_c) (varnet.py:508-530) evaluated in
-    float64 on the CPU; backward form against autograd of the same expression; row lengths 320 (register kernel),
-    80 / 45 (radix 2-5) and 368 (radix 23)."""
+    float64 on the CPU; backward form against autograd of the same expression; row lengths 320 (register kernel, two rows
+    per wave: odd heights leave a half-empty last wave), 80 / 45 (radix 2-5) and 368 (the 23 x 16 register kernel, four rows
+    per wave, with the in-kernel coil combination of a single coil and the separate pass for several)."""
     F = torch.fft
     x = cplx("dcr.x", (n, c, h, w))
     sens = cplx("dcr.s", (n, c, h, w))
