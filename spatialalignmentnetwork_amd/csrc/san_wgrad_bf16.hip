@@ -699,33 +699,44 @@ struct RJob {
     int P, cin, cout, cin_pad, cout_pad, accumulate, taps, transposed;
 };
 
+// (a thread owns FOUR consecutive output channels: 16-byte loads from the padded tile; the order of the sum per element is
+// unchanged: partitions pp = row, row + 4, ... in four interleaved chains, then the four thread rows in order)
+__host__ __device__ inline int wgrad_reduce_units(const RJob& j) { return ((j.cout + 3) / 4) * j.cin * j.taps; }
 __device__ __forceinline__ void wgrad_reduce_body(const RJob& j, int blk) {
-    __shared__ float red[3][64];
+    __shared__ f4 red[3][64];
     const int lane = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const int cq = (j.cout + 3) / 4;
     const int e = blk * 64 + lane;
-    const bool live = e < j.cout * j.cin * j.taps;
+    const bool live = e < cq * j.cin * j.taps;
     const int ec = live ? e : 0;
-    const int co = ec % j.cout;
-    const int ci = (ec / j.cout) % j.cin;
-    const int tap = ec / (j.cout * j.cin);
+    const int q4 = ec % cq;
+    const int ci = (ec / cq) % j.cin;
+    const int tap = ec / (cq * j.cin);
     const size_t stride = (size_t)j.taps * j.cin_pad * j.cout_pad;
-    const float* p = j.partial + ((size_t)tap * j.cin_pad + ci) * j.cout_pad + co;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* p = j.partial + ((size_t)tap * j.cin_pad + ci) * j.cout_pad + 4 * q4;      // cout_pad % 16 == 0: aligned, in the tile
+    const f4 z = f4{0.f, 0.f, 0.f, 0.f};
+    f4 s0 = z, s1 = z, s2 = z, s3 = z;
     int pp = row;
     for (; pp + 12 < j.P; pp += 16) {
-        s0 += p[(size_t)pp * stride];
-        s1 += p[(size_t)(pp + 4) * stride];
-        s2 += p[(size_t)(pp + 8) * stride];
-        s3 += p[(size_t)(pp + 12) * stride];
+        s0 += *reinterpret_cast<const f4*>(p + (size_t)pp * stride);
+        s1 += *reinterpret_cast<const f4*>(p + (size_t)(pp + 4) * stride);
+        s2 += *reinterpret_cast<const f4*>(p + (size_t)(pp + 8) * stride);
+        s3 += *reinterpret_cast<const f4*>(p + (size_t)(pp + 12) * stride);
     }
-    for (; pp < j.P; pp += 4) s0 += p[(size_t)pp * stride];
-    float s = (s0 + s1) + (s2 + s3);
+    for (; pp < j.P; pp += 4) s0 += *reinterpret_cast<const f4*>(p + (size_t)pp * stride);
+    f4 s = (s0 + s1) + (s2 + s3);
     if (row > 0) red[row - 1][lane] = s;
     __syncthreads();
     if (row == 0 && live) {
         s = ((s + red[0][lane]) + red[1][lane]) + red[2][lane];
-        float* o = j.transposed ? j.dw + ((size_t)ci * j.cout + co) * j.taps + tap : j.dw + ((size_t)co * j.cin + ci) * j.taps + tap;
-        *o = j.accumulate ? *o + s : s;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int co = 4 * q4 + k;
+            if (co < j.cout) {
+                float* o = j.transposed ? j.dw + ((size_t)ci * j.cout + co) * j.taps + tap : j.dw + ((size_t)co * j.cin + ci) * j.taps + tap;
+                *o = j.accumulate ? *o + s[k] : s[k];
+            }
+        }
     }
 }
 
@@ -759,7 +770,7 @@ int reduce_or_defer(const RJob& j, hipStream_t s) {
             return SAN_OK;
         }
     }
-    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(j.cout * j.cin * j.taps, 64)), dim3(256), 0, s, j);
+    hipLaunchKernelGGL(wgrad_bf16x3_reduce_kernel, dim3(san_cdiv(wgrad_reduce_units(j), 64)), dim3(256), 0, s, j);
     return SAN_OK;
 }
 
@@ -1219,7 +1230,7 @@ int san_wgrad_defer_flush(void* stream) {
         for (int k = 0; k < b.n; ++k) {
             b.j[k] = jobs[at + k];
             b.first[k] = total;
-            total += san_cdiv(b.j[k].cout * b.j[k].cin * b.j[k].taps, 64);
+            total += san_cdiv(wgrad_reduce_units(b.j[k]), 64);
         }
         b.first[b.n] = total;
         hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b);
