@@ -964,7 +964,7 @@ sens_grad_prop_kernel(float2* __restrict__ gS, const float* __restrict__ r, cons
             rr = r[(size_t)n * 2 * HW + i];
             ri = r[(size_t)n * 2 * HW + HW + i];
         }
-        for (int c = 0; c < C; ++c) {
+        for (int c = blockIdx.z; c < C; c += gridDim.z) {       // coils are independent: one per workgroup (grid z) when there are several
             const size_t e = ((size_t)n * C + c) * HW + i;
             if (gS) {
                 const float2 t = t1[e], xv = x[e];
@@ -1574,9 +1574,11 @@ int san_sens_grad_prop(float* gs, const float* r_planar, const float* t1, const 
     SAN_CHECK_ARG(gm_planar && gd && sens, "null pointer");
     SAN_CHECK_ARG(!gs || (r_planar && t1 && x), "the sensitivity-map accumulation needs r, t1 and x");
     SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0, "bad dims");
+    // (a serial coil loop per pixel was 15 dependent read-modify-write round trips at 15 x 640 x 368: 78 us for 141 MB)
     int bx = san_cdiv(hw, kThreads);
-    if (bx > 256) bx = 256;
-    hipLaunchKernelGGL(sens_grad_prop_kernel, dim3(bx, n), dim3(kThreads), 0, (hipStream_t)stream, (float2*)gs, r_planar,
+    const int cap = c > 1 ? 2048 : 256;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(sens_grad_prop_kernel, dim3(bx, n, c > 64 ? 64 : c), dim3(kThreads), 0, (hipStream_t)stream, (float2*)gs, r_planar,
                        (const float2*)t1, (const float2*)x, gm_planar, sign1, (float2*)gd, (const float2*)sens, c, hw);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
