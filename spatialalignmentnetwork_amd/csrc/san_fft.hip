@@ -1859,7 +1859,8 @@ int san_dc_rows(const float* x, const float* sens, const float* k0x, const float
         SAN_LAUNCH_CHECK();
         return SAN_OK;
     }
-    const bool w368 = w == kN368 && !getenv("SAN_DC_GENERIC");
+    static const bool no368 = getenv("SAN_DC_GENERIC") != nullptr;      // tuning / A-B hook: the general-width kernel at 368
+    const bool w368 = w == kN368 && !no368;
     if (w368) {
         const dim3 grid(gx, n, c);
         if (backward) hipLaunchKernelGGL((dc_rows368_kernel<1>), grid, dim3(64), 0, s, a);
