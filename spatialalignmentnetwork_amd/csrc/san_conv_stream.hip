@@ -1,0 +1,502 @@
+// 3x3 convolution, "stream" form (round 4): PERSISTENT workgroups for the high-resolution, few-channel layers
+// (18 / 36 channels at 320^2 / 160^2: 60 % of a cascade's convolution time), where the one-tile-per-workgroup kernel of
+// san_conv_bf16.hip spends its life in launch / prologue / load latency / barriers rather than in the matrix cores.
+//
+// Same arithmetic as conv_bf16x3_kernel<.., F16 = true, SWAP = true>: two fp16 parts per fp32 operand, three products per MAC on
+// v_mfma_f32_16x16x32_f16 (fp32-equivalent: DESIGN.md 3.1), 32 x 8 output tiles, 4 waves, 24-channel chunks, 7 K-steps per
+// chunk, the packed weight image of san_conv_bf16x3_pack (mode + 16), the same per-wave statistics records.  What changes:
+//   * a workgroup walks a SEQUENCE of tiles (grid = resident workgroups only); index arithmetic, operand addressing and the
+//     weight fetch happen once per workgroup instead of once per tile;
+//   * the packed weights of ALL chunks live in LDS for the workgroup's lifetime (the partial last block of 16 output channels
+//     -- 18 = 16 + 2, 36 = 32 + 4 -- is stored compacted: lanes of absent channels read one shared zero slot);
+//   * the NEXT work item's raw fp32 input tile is brought into LDS by LDS-DMA (buffer_load_dword ... lds, no VGPRs, issued
+//     from inline asm so that the compiler neither counts nor drains it) while the matrix cores work on the current one; the
+//     only vector-memory operations of the loop besides it are the epilogue's stores, so a COUNTED s_waitcnt vmcnt(stores)
+//     retires exactly the prefetch (vector memory operations of a wave retire in order);
+//   * the staging pass (lazy affine + LeakyReLU + fp16 split) reads the raw tile from LDS.
+// Reference work replaced: nn.Conv2d(3x3, padding 1, bias False) of varnet.py:139-146 (ConvBlock) and its autograd data gradient.
+#include "san_common.h"
+
+#include <cstdint>
+#include <cstdlib>
+
+namespace {
+
+constexpr int kT = 256;
+constexpr int kTW = 32, kTH = 8;
+constexpr int kHP = kTW + 2, kHH = kTH + 2;      // halo tile 34 x 10
+constexpr int kNP = kHP * kHH;                   // 340 staged pixels
+constexpr int kCKC = 24;                         // input channels per chunk
+constexpr int kPS = 48;                          // bytes per staged pixel per part
+constexpr int kPartB = kNP * kPS;                // 16,320 B per part
+constexpr int kSteps = 7;
+constexpr int kRawB = kCKC * kNP * 4;            // 32,640 B: raw fp32 tile [channel][340]
+constexpr int kPieces = (kNP + 63) / 64;         // 6 DMA pieces of 64 pixels per channel (the last: 20 lanes)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float fl2 __attribute__((ext_vector_type(2)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
+union Frag {
+    uint4 u;
+    h8 h;
+};
+
+struct SArgs {
+    const float* x;
+    const float* in_scale;
+    const float* in_shift;
+    const uint4* wp;           // packed weights [chunk][step][block (nblkp)][part (3)][64 lanes] x 16 B, fp16 parts in 0, 1
+    const float* bias;
+    float* y;
+    float* part;               // statistics [n][cout][tiles * 4][3] or null
+    const uint32_t* amax;      // gradient input: amax record (san_common.h) or null
+    float in_slope;
+    int x_ctot, x_coff, cin;
+    int y_ctot, y_coff, cout;
+    int N, H, W;
+    int tiles_x, tiles_y, chunks, nblkp;
+    int total;                 // N * tiles_x * tiles_y
+    unsigned x_bytes;          // extent of the whole input tensor (descriptor range)
+    unsigned m_nt, m_tx;       // multiply-high division by tiles_x * tiles_y and tiles_x (0: plain division)
+    int vm_wait;               // tuning hook: 0 = counted wait, 1 = vmcnt(0) at the top of every item
+};
+
+__device__ __forceinline__ int fdiv(int x, unsigned m, int d) {
+    if (d == 1) return x;
+    return m ? (int)__umulhi((unsigned)x, m) : x / d;
+}
+
+__device__ __forceinline__ uint32_t cvt_pk_h(float f0, float f1) {
+    const fl2 v = {f0, f1};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hf2));
+}
+// a = a1 + a2 with a1 = fp16(a), a2 = fp16(a - a1) (san_conv_bf16.hip: split2h_pair)
+__device__ __forceinline__ void split2h_pair(float f0, float f1, uint32_t& p1, uint32_t& p2) {
+    p1 = cvt_pk_h(f0, f1);
+    const hf2 h = __builtin_bit_cast(hf2, p1);
+    p2 = cvt_pk_h(__builtin_fmaf((float)h[0], -1.f, f0), __builtin_fmaf((float)h[1], -1.f, f1));
+}
+
+// One LDS-DMA piece: 64 lanes x 4 bytes, lane l's dword lands at LDS byte address lds_addr + 4 l.  Issued from asm: the
+// compiler does not know about it (no vmcnt bookkeeping, no drain at barriers); M0 is saved and restored around it.
+__device__ __forceinline__ void dma_dword(uint32_t lds_addr, uint32_t voff, v4i rs, uint32_t soff) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dword %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
+        : "memory");
+}
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// MBF full blocks of 16 output channels + (REM > 0) one partial block of REM channels
+template <int MBF, int REM>
+__global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
+    constexpr int MB = MBF + (REM > 0 ? 1 : 0);
+    constexpr int RS = MBF * 1024 + (REM > 0 ? REM * 64 + 16 : 0);      // LDS bytes of one (chunk, step, part) weight region
+    constexpr int WCH = kSteps * 2 * RS;                                // ... of one chunk
+    constexpr int kStores = MB * 4;                                     // output stores per wave and tile (always issued)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* lds_raw = smem;
+    unsigned char* lds_a = smem + kRawB;
+    float* lds_aff = reinterpret_cast<float*>(smem + kRawB + 2 * kPartB);
+    unsigned char* lds_w = smem + kRawB + 2 * kPartB + a.chunks * 192;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int nn = lane & 15, kg = lane >> 4;
+    const int H = a.H, W = a.W, HWp = H * W;
+    const int ntile = a.tiles_x * a.tiles_y;
+    const bool has_aff = a.in_scale != nullptr;
+    const float lrelu_c = a.in_slope <= 1.f ? __builtin_inff() : -__builtin_inff();
+
+    // ---- this workgroup's tiles: XCD x (= id & 7, the observed placement: speed only) owns the contiguous tile range
+    // [x total / 8, (x + 1) total / 8); its workgroups take tiles round-robin, so that at any time an XCD's L2 holds a compact band
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int t_begin = (int)(((long long)a.total * xcd) >> 3), t_end = (int)(((long long)a.total * (xcd + 1)) >> 3);
+    int t = t_begin + slot;
+    if (t >= t_end) return;                             // (before any barrier: the whole workgroup leaves)
+
+    // ---- once per workgroup: zero the operand image (absent channel groups stay zero = finite), weights -> LDS
+    for (int i = tid; i < 2 * kPartB / 16; i += kT) reinterpret_cast<uint4*>(lds_a)[i] = make_uint4(0u, 0u, 0u, 0u);
+    {
+        const int npieces = a.chunks * kSteps * 2 * MB;
+        for (int q = wave; q < npieces; q += kT / 64) {
+            const int m = q % MB, r = q / MB;
+            const int p = r & 1, cs = r >> 1;           // cs = chunk * 7 + step
+            const uint4 v = a.wp[((size_t)(cs * a.nblkp + m) * 3 + p) * 64 + lane];
+            unsigned char* region = lds_w + (size_t)(cs * 2 + p) * RS;
+            if (m < MBF) {
+                *reinterpret_cast<uint4*>(region + m * 1024 + lane * 16) = v;
+            } else {
+                if (nn < REM) *reinterpret_cast<uint4*>(region + MBF * 1024 + (kg * REM + nn) * 16) = v;
+                if (lane == 0) *reinterpret_cast<uint4*>(region + MBF * 1024 + REM * 64) = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    }
+    // gradient input in the fp16 format: x S rides in the affine table, the accumulators get 1 / S (san_conv_bf16.hip)
+    float inS = 1.f, inInvS = 1.f;
+    if (a.amax) {
+        const uint32_t b = san_amax_read(a.amax);
+        int e = (int)((b >> 23) & 255u);
+        if (b != 0u) {
+            e = e < 14 ? 14 : (e > 250 ? 250 : e);
+            inS = __builtin_bit_cast(float, (uint32_t)(267 - e) << 23);
+            inInvS = __builtin_bit_cast(float, (uint32_t)(e - 13) << 23);
+        }
+    }
+    // lazy-affine table of image n: [chunk][scale 24 | shift 24]
+    auto load_aff = [&](int n) {
+        if (tid < a.chunks * 48) {
+            const int c = tid / 48, j = tid - c * 48;
+            const int ci = min(c * kCKC + (j < 24 ? j : j - 24), a.cin - 1);
+            const float* src = j < 24 ? a.in_scale : a.in_shift;
+            lds_aff[tid] = has_aff ? src[n * a.x_ctot + a.x_coff + ci] * inS : (j < 24 ? inS : 0.f);
+        }
+    };
+
+    // ---- staging units: slots 0..2 = pixel tid of channel group s; slot 3 = pixels 256..339 x 3 groups (tid < 252)
+    const int pr0 = tid / kHP, pc0 = tid - pr0 * kHP;
+    const bool u3 = tid < 3 * (kNP - kT);
+    const int g3 = u3 ? tid / (kNP - kT) : 0;
+    const int p3 = u3 ? kT + tid - g3 * (kNP - kT) : 0;
+    const int pr3 = p3 / kHP, pc3 = p3 - pr3 * kHP;
+
+    // ---- DMA pieces: piece j of a channel = halo pixels 64 j + lane
+    int dpr[kPieces], dpc[kPieces];
+#pragma unroll
+    for (int j = 0; j < kPieces; ++j) {
+        const int p = min(64 * j + lane, kNP - 1);
+        dpr[j] = p / kHP;
+        dpc[j] = p - dpr[j] * kHP;
+    }
+    const uint64_t xa = reinterpret_cast<uint64_t>(a.x);
+    const v4i rs = {__builtin_amdgcn_readfirstlane((int)(uint32_t)xa), __builtin_amdgcn_readfirstlane((int)(uint32_t)(xa >> 32)),
+                    __builtin_amdgcn_readfirstlane((int)a.x_bytes), 0x00020000};
+    const uint32_t raw_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
+
+    // ---- K-loop operand addressing (as conv_bf16x3_kernel, 32 x 8 tile)
+    int tapoff[kSteps];
+#pragma unroll
+    for (int s = 0; s < kSteps; ++s) {
+        const int g = min(4 * s + kg, 26);
+        const int tap = g / 3, chg = g - 3 * tap;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        tapoff[s] = (ky * kHP + kx) * kPS + chg * 16;
+    }
+    int boff[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) boff[b] = ((2 * wave + (b >> 1)) * kHP + 16 * (b & 1) + nn) * kPS;
+    const int wl_full = lane * 16;
+    const int wl_rem = REM > 0 ? (nn < REM ? MBF * 1024 + (kg * REM + nn) * 16 : MBF * 1024 + REM * 64) : 0;
+
+    f4 acc[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- work items (tile, chunk)
+    int n = fdiv(t, a.m_nt, ntile);
+    int tile = t - n * ntile;
+    int ty = fdiv(tile, a.m_tx, a.tiles_x), tx = tile - ty * a.tiles_x;
+    int chunk = 0;
+
+    // issue the LDS-DMA of item (n_, ty_, tx_, chunk_): wave w brings channels w, w + 4, ... of the chunk
+    auto issue_dma = [&](int n_, int ty_, int tx_, int chunk_) {
+        const int y0 = ty_ * kTH - 1, x0 = tx_ * kTW - 1;
+        uint32_t voff[kPieces];
+#pragma unroll
+        for (int j = 0; j < kPieces; ++j) {
+            const int gy = min(max(y0 + dpr[j], 0), H - 1), gx = min(max(x0 + dpc[j], 0), W - 1);     // (clamped: the frame is zeroed by the staging pass)
+            voff[j] = (uint32_t)(gy * W + gx) * 4u;
+        }
+        const int nch = min(kCKC, a.cin - chunk_ * kCKC);
+        const int cbase = n_ * a.x_ctot + a.x_coff + chunk_ * kCKC;
+        for (int cc = wave; cc < nch; cc += kT / 64) {
+            const uint32_t soff = (uint32_t)(cbase + cc) * (uint32_t)HWp * 4u;
+            const uint32_t dst = raw_base + (uint32_t)cc * (kNP * 4);
+#pragma unroll
+            for (int j = 0; j < kPieces - 1; ++j) dma_dword(dst + j * 256, voff[j], rs, soff);
+            if (lane < kNP - 64 * (kPieces - 1)) dma_dword(dst + (kPieces - 1) * 256, voff[kPieces - 1], rs, soff);
+        }
+    };
+
+    load_aff(n);
+    issue_dma(n, ty, tx, 0);
+    bool stores_behind = false;                        // the previous item ended with an epilogue: >= kStores stores were issued after this item's DMA
+    for (;;) {
+        // ---- the raw tile of this item has landed (own DMA: counted wait -- vector memory operations retire in order, so with at
+        // most kStores outstanding every DMA piece, issued before them, is done; the others' pieces: barrier); the K-loop of the
+        // previous item is over for every wave, so the operand image may be rewritten
+        if (stores_behind && !a.vm_wait) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+        const int y0 = ty * kTH, x0 = tx * kTW;
+        const int nch = min(kCKC, a.cin - chunk * kCKC);
+        const float* afc = lds_aff + chunk * 48;
+        const float* rawf = reinterpret_cast<const float*>(lds_raw);
+        auto stage_unit = [&](int g, int p, int pr, int pc, bool uniform_g) {
+            const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+            unsigned char* dst = lds_a + p * kPS + g * 16;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const f4 sc0 = *reinterpret_cast<const f4*>(afc + g * 8), sc1 = *reinterpret_cast<const f4*>(afc + g * 8 + 4);
+                const f4 sh0 = *reinterpret_cast<const f4*>(afc + 24 + g * 8), sh1 = *reinterpret_cast<const f4*>(afc + 24 + g * 8 + 4);
+                uint32_t q1[4], q2[4];
+#pragma unroll
+                for (int i = 0; i < 8; i += 2) {
+                    // channels past the chunk's last are read from its last one (finite) and meet zero weights
+                    const float r0 = rawf[min(g * 8 + i, nch - 1) * kNP + p], r1 = rawf[min(g * 8 + i + 1, nch - 1) * kNP + p];
+                    const float a0 = __builtin_fmaf(r0, i < 4 ? sc0[i] : sc1[i - 4], i < 4 ? sh0[i] : sh1[i - 4]);
+                    const float a1 = __builtin_fmaf(r1, i < 4 ? sc0[i + 1] : sc1[i - 3], i < 4 ? sh0[i + 1] : sh1[i - 3]);
+                    const float v0 = __builtin_amdgcn_fmed3f(a0, a0 * a.in_slope, lrelu_c);
+                    const float v1 = __builtin_amdgcn_fmed3f(a1, a1 * a.in_slope, lrelu_c);
+                    split2h_pair(v0, v1, q1[i >> 1], q2[i >> 1]);
+                }
+                *reinterpret_cast<uint4*>(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
+                *reinterpret_cast<uint4*>(dst + kPartB) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+            } else {
+                *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(dst + kPartB) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            (void)uniform_g;
+        };
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            if (s * 8 < nch) stage_unit(s, tid, pr0, pc0, true);           // (empty groups keep their zeros / stale finite values x zero weights)
+        if (u3 && g3 * 8 < nch) stage_unit(g3, p3, pr3, pc3, false);
+        lds_barrier();
+
+        // ---- the raw tile is free: prefetch the next item
+        int nn_ = n, nty = ty, ntx = tx, nchunk = chunk + 1;
+        bool more = true;
+        if (nchunk == a.chunks) {
+            nchunk = 0;
+            t += per_xcd;
+            more = t < t_end;
+            if (more) {
+                nn_ = fdiv(t, a.m_nt, ntile);
+                const int tl = t - nn_ * ntile;
+                nty = fdiv(tl, a.m_tx, a.tiles_x);
+                ntx = tl - nty * a.tiles_x;
+                if (nn_ != n) load_aff(nn_);            // (every wave is past its last read of the table: the barrier above)
+            }
+        }
+        if (more) issue_dma(nn_, nty, ntx, nchunk);
+
+        // ---- 7 K-steps on the staged image; operands of step s + 1 are requested before the MFMAs of step s
+        {
+            Frag wa[2][MB][2], xa[2][4][2];
+            const unsigned char* wc = lds_w + chunk * WCH;
+            auto load_w = [&](int s, Frag (&wq)[MB][2]) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        wq[m][p].u = *reinterpret_cast<const uint4*>(wc + (s * 2 + p) * RS + (m < MBF ? m * 1024 + wl_full : wl_rem));
+            };
+            auto load_x = [&](int s, Frag (&xq)[4][2]) {
+                const int to = tapoff[s];
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
+            };
+            load_w(0, wa[0]);
+            load_x(0, xa[0]);
+#pragma unroll
+            for (int s = 0; s < kSteps; ++s) {
+                if (s + 1 < kSteps) {
+                    load_w(s + 1, wa[(s + 1) & 1]);
+                    load_x(s + 1, xa[(s + 1) & 1]);
+                }
+#pragma unroll
+                for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                    for (int px = 0; px < 2 - pw; ++px)
+#pragma unroll
+                        for (int m = 0; m < MB; ++m)
+#pragma unroll
+                            for (int b = 0; b < 4; ++b)
+                                acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][px].h, wa[s & 1][m][pw].h, acc[m][b], 0, 0, 0);
+            }
+        }
+
+        // ---- last chunk of the tile: epilogue.  acc[m][b][r] = channel 16 m + nn at tile pixel 64 wave + 16 b + 4 kg + r
+        stores_behind = chunk == a.chunks - 1;
+        if (stores_behind) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[m][b] = acc[m][b] * inInvS;
+            if (a.bias) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const int co = 16 * m + nn;
+                    const float bv = co < a.cout ? a.bias[co] : 0.f;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[m][b] += f4{bv, bv, bv, bv};
+                }
+            }
+            if (a.part) {
+                const int tiles = ntile * 4;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    const float pilot = __shfl(acc[m][0][0], nn, 64);
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = acc[m][b][r] - pilot;
+                            s1 += e;
+                            s2 = fmaf(e, e, s2);
+                        }
+                    s1 += __shfl_xor(s1, 16, 64);
+                    s2 += __shfl_xor(s2, 16, 64);
+                    s1 += __shfl_xor(s1, 32, 64);
+                    s2 += __shfl_xor(s2, 32, 64);
+                    const int co = 16 * m + nn;
+                    if (kg == 0 && co < a.cout) {
+                        float* o = a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
+                        o[0] = 64.f;
+                        o[1] = pilot + s1 * (1.f / 64.f);
+                        o[2] = fmaxf(s2 - s1 * s1 * (1.f / 64.f), 0.f);
+                    }
+                }
+            }
+            float* ybase = a.y + (size_t)(n * a.y_ctot + a.y_coff) * HWp;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int co = 16 * m + nn;
+                float* dst = ybase + (size_t)co * HWp;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int q = 64 * wave + 16 * b + 4 * kg;
+                    if (co < a.cout) *reinterpret_cast<f4*>(dst + (y0 + (q >> 5)) * W + x0 + (q & 31)) = acc[m][b];
+                    acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+        if (!more) break;
+        n = nn_;
+        ty = nty;
+        tx = ntx;
+        tile = ty * a.tiles_x + tx;
+        chunk = nchunk;
+    }
+}
+
+int g_stream = 0;              // SAN_CONV_STREAM=1: on (off until it beats the one-tile kernel)
+int g_stream_wait = 0;         // SAN_CONV_STREAM_WAIT=1: vmcnt(0) instead of the counted wait
+int g_stream_wgs = 0;          // SAN_CONV_STREAM_WGS: workgroups per CU (0: as many as the LDS allows, at most 2)
+struct StreamEnv {
+    StreamEnv() {
+        if (const char* e = getenv("SAN_CONV_STREAM")) g_stream = atoi(e);
+        if (const char* e = getenv("SAN_CONV_STREAM_WAIT")) g_stream_wait = atoi(e);
+        if (const char* e = getenv("SAN_CONV_STREAM_WGS")) g_stream_wgs = atoi(e);
+    }
+} g_stream_env;
+
+template <int MBF, int REM>
+size_t stream_lds(int chunks) {
+    constexpr int RS = MBF * 1024 + (REM > 0 ? REM * 64 + 16 : 0);
+    return (size_t)kRawB + 2 * kPartB + (size_t)chunks * 192 + (size_t)chunks * kSteps * 2 * RS;
+}
+
+template <int MBF, int REM>
+int launch_stream(const SArgs& a, hipStream_t s) {
+    const size_t lds = stream_lds<MBF, REM>(a.chunks);
+    static size_t configured = 0;
+    if (lds > configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel<MBF, REM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            san_set_error("cannot reserve %d bytes of LDS for the stream convolution", (int)lds);
+            return SAN_E_UNSUPPORTED;
+        }
+        configured = lds;
+    }
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;
+    if (g_stream_wgs > 0 && g_stream_wgs < per_cu) per_cu = g_stream_wgs;
+    int grid = 256 * per_cu;
+    const int need = ((a.total + 7) / 8) * 8;           // (a multiple of 8: the tile ranges are per XCD)
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL((conv3x3_stream_kernel<MBF, REM>), dim3(grid), dim3(kT), lds, s, a);
+    return SAN_OK;
+}
+
+}  // namespace
+
+// 1 when the stream form takes this fp16-format 3x3 layer (called by conv_bf16x3_run, san_conv_bf16.hip)
+int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot) {
+    if (!g_stream) return 0;
+    if ((w % kTW) != 0 || (h % kTH) != 0 || w < 64 || h * w < 160 * 160) return 0;
+    if (cin > 3 * kCKC) return 0;
+    if (!(cout == 18 || cout == 32 || cout == 36 || cout == 16 || cout == 48)) return 0;
+    if ((unsigned long long)n * x_ctot * h * w * 4ull >= 0x7fffffffull) return 0;
+    // LDS: everything resident
+    const int chunks = san_cdiv(cin, kCKC);
+    const int mbf = cout / 16, rem = cout % 16;
+    const size_t rs = (size_t)mbf * 1024 + (rem ? rem * 64 + 16 : 0);
+    const size_t lds = (size_t)kRawB + 2 * kPartB + (size_t)chunks * 192 + (size_t)chunks * kSteps * 2 * rs;
+    return lds <= 160 * 1024 ? 1 : 0;
+}
+
+int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
+                        const void* w_packed, int nblkp, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
+                        const void* amax, int n, int h, int w, void* stream) {
+    SArgs a{};
+    a.x = x;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_slope = in_slope;
+    a.wp = static_cast<const uint4*>(w_packed);
+    a.bias = bias;
+    a.y = y;
+    a.part = part_stats;
+    a.amax = static_cast<const uint32_t*>(amax);
+    a.x_ctot = x_ctot;
+    a.x_coff = x_coff;
+    a.cin = cin;
+    a.y_ctot = y_ctot;
+    a.y_coff = y_coff;
+    a.cout = cout;
+    a.N = n;
+    a.H = h;
+    a.W = w;
+    a.tiles_x = w / kTW;
+    a.tiles_y = h / kTH;
+    a.chunks = san_cdiv(cin, kCKC);
+    a.nblkp = nblkp;
+    a.total = n * a.tiles_x * a.tiles_y;
+    a.x_bytes = (unsigned)((size_t)n * x_ctot * h * w * 4);
+    auto magic = [&](int d) -> unsigned {
+        return (d > 1 && (unsigned long long)a.total * (unsigned long long)d < 0xffffffffull) ? (unsigned)(0x100000000ull / (unsigned)d + 1) : 0u;
+    };
+    a.m_nt = magic(a.tiles_x * a.tiles_y);
+    a.m_tx = magic(a.tiles_x);
+    a.vm_wait = g_stream_wait;
+    SAN_CHECK_ARG((reinterpret_cast<uintptr_t>(y) & 15) == 0, "stream convolution: output must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (cout) {
+        case 16: rc = launch_stream<1, 0>(a, s); break;
+        case 18: rc = launch_stream<1, 2>(a, s); break;
+        case 32: rc = launch_stream<2, 0>(a, s); break;
+        case 36: rc = launch_stream<2, 4>(a, s); break;
+        case 48: rc = launch_stream<3, 0>(a, s); break;
+        default: san_set_error("stream convolution: unsupported cout %d", cout); return SAN_E_UNSUPPORTED;
+    }
+    if (rc != SAN_OK) return rc;
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
