@@ -9,11 +9,12 @@
 //     weight fetch happen once per workgroup instead of once per tile;
 //   * the packed weights of ALL chunks live in LDS for the workgroup's lifetime (the partial last block of 16 output channels
 //     -- 18 = 16 + 2, 36 = 32 + 4 -- is stored compacted: lanes of absent channels read one shared zero slot);
-//   * the NEXT work item's raw fp32 input tile is brought into LDS by LDS-DMA (buffer_load_dword ... lds, no VGPRs, issued
-//     from inline asm so that the compiler neither counts nor drains it) while the matrix cores work on the current one; the
-//     only vector-memory operations of the loop besides it are the epilogue's stores, so a COUNTED s_waitcnt vmcnt(stores)
-//     retires exactly the prefetch (vector memory operations of a wave retire in order);
-//   * the staging pass (lazy affine + LeakyReLU + fp16 split) reads the raw tile from LDS.
+//   * the packed weights live in LDS: for the workgroup's lifetime when the layer has one 24-channel chunk, otherwise one chunk at
+//     a time, brought in by 16-byte LDS-DMA (buffer_load_dwordx4 ... lds, from inline asm) behind the item's first barrier;
+//   * the NEXT work item's raw fp32 input (32 values per thread) is requested into registers right after the staging barrier,
+//     a whole K-loop + epilogue ahead of its use; with the weights out of the vector-memory queue nothing queues behind it.
+// (v1 of this file brought the raw tile in by 4-byte LDS-DMA: 30 DMA instructions per wave and tile at ~100 cycles of issue
+// each, plus 32 LDS reads per thread, cost more than the prefetch returned: scratch/attempts/r4_stream_v1_ablation.txt.)
 // Reference work replaced: nn.Conv2d(3x3, padding 1, bias False) of varnet.py:139-146 (ConvBlock) and its autograd data gradient.
 #include "san_common.h"
 
@@ -30,8 +31,7 @@ constexpr int kCKC = 24;                         // input channels per chunk
 constexpr int kPS = 48;                          // bytes per staged pixel per part
 constexpr int kPartB = kNP * kPS;                // 16,320 B per part
 constexpr int kSteps = 7;
-constexpr int kRawB = kCKC * kNP * 4;            // 32,640 B: raw fp32 tile [channel][340]
-constexpr int kPieces = (kNP + 63) / 64;         // 6 DMA pieces of 64 pixels per channel (the last: 20 lanes)
+constexpr int kUnits = 4;                        // (pixel, channel group) staging units per thread
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float fl2 __attribute__((ext_vector_type(2)));
@@ -59,8 +59,11 @@ struct SArgs {
     int tiles_x, tiles_y, chunks, nblkp;
     int total;                 // N * tiles_x * tiles_y
     unsigned x_bytes;          // extent of the whole input tensor (descriptor range)
+    unsigned w_bytes;          // extent of the packed weight image
     unsigned m_nt, m_tx;       // multiply-high division by tiles_x * tiles_y and tiles_x (0: plain division)
-    int vm_wait;               // tuning hook: 0 = counted wait, 1 = vmcnt(0) at the top of every item
+    int stag, stag_mode;       // de-phasing of the workgroups that share a CU: initial delay = phase x stag x 64 cycles; phase from the
+                               // launch order (mode 0: blockIdx / 256) or from the hardware wave slot (mode 1)
+    int abl;                   // tuning hook (SAN_CONV_STREAM_ABL, results WRONG): 1 no DMA, 2 no staging arithmetic, 4 no K-loop, 8 no statistics, 16 no stores
 };
 
 __device__ __forceinline__ int fdiv(int x, unsigned m, int d) {
@@ -79,15 +82,15 @@ __device__ __forceinline__ void split2h_pair(float f0, float f1, uint32_t& p1, u
     p2 = cvt_pk_h(__builtin_fmaf((float)h[0], -1.f, f0), __builtin_fmaf((float)h[1], -1.f, f1));
 }
 
-// One LDS-DMA piece: 64 lanes x 4 bytes, lane l's dword lands at LDS byte address lds_addr + 4 l.  Issued from asm: the
+// One LDS-DMA piece: 64 lanes x 16 bytes, lane l's 16 bytes land at LDS byte address lds_addr + 16 l.  Issued from asm: the
 // compiler does not know about it (no vmcnt bookkeeping, no drain at barriers); M0 is saved and restored around it.
-__device__ __forceinline__ void dma_dword(uint32_t lds_addr, uint32_t voff, v4i rs, uint32_t soff) {
+__device__ __forceinline__ void dma_x4(uint32_t lds_addr, uint32_t voff, v4i rs, uint32_t soff) {
     uint32_t keep;
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %1\n\t"
         "s_nop 0\n\t"
-        "buffer_load_dword %2, %3, %4 offen lds\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff)
@@ -96,18 +99,20 @@ __device__ __forceinline__ void dma_dword(uint32_t lds_addr, uint32_t voff, v4i 
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// MBF full blocks of 16 output channels + (REM > 0) one partial block of REM channels
-template <int MBF, int REM>
-__global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
+// MBF full blocks of 16 output channels + (REM > 0) one partial block of REM channels; OCC = resident waves per SIMD the
+// register allocation aims at
+template <int MBF, int REM, int OCC>
+__global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) {
     constexpr int MB = MBF + (REM > 0 ? 1 : 0);
-    constexpr int RS = MBF * 1024 + (REM > 0 ? REM * 64 + 16 : 0);      // LDS bytes of one (chunk, step, part) weight region
-    constexpr int WCH = kSteps * 2 * RS;                                // ... of one chunk
-    constexpr int kStores = MB * 4;                                     // output stores per wave and tile (always issued)
+    constexpr int RS = MBF * 1024 + (REM > 0 ? REM * 64 + 16 : 0);      // LDS bytes of one (step, part) weight region
+    constexpr int RSL = RS / 16;                                        // ... in 16-byte slots
+    constexpr int NSLOT = kSteps * 2 * RSL;                             // slots of one chunk's weight image
+    constexpr int NWI = (NSLOT + 63) / 64;                              // DMA instructions per chunk
+    constexpr int NWK = (NWI + kT / 64 - 1) / (kT / 64);                // ... per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* lds_raw = smem;
-    unsigned char* lds_a = smem + kRawB;
-    float* lds_aff = reinterpret_cast<float*>(smem + kRawB + 2 * kPartB);
-    unsigned char* lds_w = smem + kRawB + 2 * kPartB + a.chunks * 192;
+    unsigned char* lds_a = smem;
+    float* lds_aff = reinterpret_cast<float*>(smem + 2 * kPartB);
+    unsigned char* lds_w = smem + 2 * kPartB + a.chunks * 192;
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,6 +121,7 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
     const int H = a.H, W = a.W, HWp = H * W;
     const int ntile = a.tiles_x * a.tiles_y;
     const bool has_aff = a.in_scale != nullptr;
+    const bool multi = a.chunks > 1;                    // the weights are then streamed chunk by chunk
     const float lrelu_c = a.in_slope <= 1.f ? __builtin_inff() : -__builtin_inff();
 
     // ---- this workgroup's tiles: XCD x (= id & 7, the observed placement: speed only) owns the contiguous tile range
@@ -125,23 +131,102 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
     int t = t_begin + slot;
     if (t >= t_end) return;                             // (before any barrier: the whole workgroup leaves)
 
-    // ---- once per workgroup: zero the operand image (absent channel groups stay zero = finite), weights -> LDS
-    for (int i = tid; i < 2 * kPartB / 16; i += kT) reinterpret_cast<uint4*>(lds_a)[i] = make_uint4(0u, 0u, 0u, 0u);
-    {
-        const int npieces = a.chunks * kSteps * 2 * MB;
-        for (int q = wave; q < npieces; q += kT / 64) {
-            const int m = q % MB, r = q / MB;
-            const int p = r & 1, cs = r >> 1;           // cs = chunk * 7 + step
-            const uint4 v = a.wp[((size_t)(cs * a.nblkp + m) * 3 + p) * 64 + lane];
-            unsigned char* region = lds_w + (size_t)(cs * 2 + p) * RS;
-            if (m < MBF) {
-                *reinterpret_cast<uint4*>(region + m * 1024 + lane * 16) = v;
-            } else {
-                if (nn < REM) *reinterpret_cast<uint4*>(region + MBF * 1024 + (kg * REM + nn) * 16) = v;
-                if (lane == 0) *reinterpret_cast<uint4*>(region + MBF * 1024 + REM * 64) = make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
+    // ---- co-resident workgroups start out of phase: identical workgroups otherwise march in lockstep through load / stage /
+    // matrix / store phases (measured: the phases of a launch ADD UP), and a persistent workgroup keeps the offset it starts with
+    if (a.stag > 0) {
+        const int phase = a.stag_mode == 0 ? (int)(blockIdx.x >> 8) : (int)(__builtin_amdgcn_s_getreg((3 << 11) | 4) % (unsigned)a.stag_mode);   // HW_ID[3:0] = wave slot
+        for (int i = 0; i < phase * a.stag; ++i) __builtin_amdgcn_s_sleep(1);
     }
+
+    // ---- staging units: slots 0..2 = pixel tid of channel group s (wave-uniform group); slot 3 = pixels 256..339 x 3 groups
+    const int pr0 = tid / kHP, pc0 = tid - pr0 * kHP;
+    const bool u3 = tid < 3 * (kNP - kT);
+    const int g3 = u3 ? tid / (kNP - kT) : 0;
+    const int p3 = u3 ? kT + tid - g3 * (kNP - kT) : 0;
+    const int pr3 = p3 / kHP, pc3 = p3 - pr3 * kHP;
+
+    // whole-tensor buffer descriptor: load address = base + SGPR offset (the channel plane: uniform for slots 0..2) + per-lane pixel offset
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const unsigned hw4 = (unsigned)HWp * 4u;
+
+    int n = fdiv(t, a.m_nt, ntile);
+    int tile = t - n * ntile;
+    int ty = fdiv(tile, a.m_tx, a.tiles_x), tx = tile - ty * a.tiles_x;
+    int chunk = 0;
+
+    // ---- prefetch registers: the raw input of the NEXT item (st), and whether this thread's two pixels lie inside the image
+    float st[kUnits][8];
+    bool in0 = false, in3 = false;
+    auto prefetch = [&](int n_, int ty_, int tx_, int chunk_) {
+        const int gy0 = ty_ * kTH - 1 + pr0, gx0 = tx_ * kTW - 1 + pc0;
+        const int gy3 = ty_ * kTH - 1 + pr3, gx3 = tx_ * kTW - 1 + pc3;
+        in0 = gy0 >= 0 && gy0 < H && gx0 >= 0 && gx0 < W;
+        in3 = u3 && gy3 >= 0 && gy3 < H && gx3 >= 0 && gx3 < W;
+        const unsigned v0 = in0 ? (unsigned)(gy0 * W + gx0) * 4u : 0u, v3 = in3 ? (unsigned)(gy3 * W + gx3) * 4u : 0u;
+        const int nch = min(kCKC, a.cin - chunk_ * kCKC);
+        const unsigned cbase = (unsigned)(n_ * a.x_ctot + a.x_coff + chunk_ * kCKC);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                if (s * 8 + i < nch) {                  // (wave-uniform; nch is even for every layer of the network, odd: clamped)
+                    st[s][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)v0, (int)((cbase + s * 8 + i) * hw4), 0));
+                    st[s][i + 1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)v0, (int)((cbase + min(s * 8 + i + 1, nch - 1)) * hw4), 0));
+                } else {
+                    st[s][i] = 0.f;
+                    st[s][i + 1] = 0.f;
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)                     // (per-lane group: channels past the chunk's last read its last one and meet zero weights)
+            st[3][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(v3 + (unsigned)min(g3 * 8 + i, nch - 1) * hw4), (int)(cbase * hw4), 0));
+    };
+    prefetch(n, ty, tx, 0);
+
+    // ---- once per workgroup: zero the operand image (absent channel groups stay zero = finite)
+    for (int i = tid; i < 2 * kPartB / 16; i += kT) reinterpret_cast<uint4*>(lds_a)[i] = make_uint4(0u, 0u, 0u, 0u);
+
+    // ---- weights: LDS image of a chunk = 14 (step, part) regions of RSL slots: the MBF full blocks lane for lane, then the
+    // partial block's REM channels x 4 k-groups, then one zero slot that the lanes of its absent channels read.  Slot q of the
+    // image is fetched by DMA instruction q / 64, lane q % 64, from the packed image's 16-byte element woff (within the chunk).
+    const uint64_t wa_ = reinterpret_cast<uint64_t>(a.wp);
+    const v4i wrs = {__builtin_amdgcn_readfirstlane((int)(uint32_t)wa_), __builtin_amdgcn_readfirstlane((int)(uint32_t)(wa_ >> 32)),
+                     __builtin_amdgcn_readfirstlane((int)a.w_bytes), 0x00020000};
+    const uint32_t w_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_w;
+    uint32_t wvoff[NWK];
+    bool wok[NWK];
+#pragma unroll
+    for (int k = 0; k < NWK; ++k) {
+        const int q = (wave + k * (kT / 64)) * 64 + lane;
+        wok[k] = q < NSLOT;
+        const int qq = min(q, NSLOT - 1);
+        const int r = qq / RSL, j = qq - r * RSL;
+        const int step = r >> 1, part = r & 1;
+        int m, l;
+        if (j < MBF * 64) {
+            m = j >> 6;
+            l = j & 63;
+        } else if (REM > 0 && j < MBF * 64 + 4 * REM) {
+            const int jj = j - MBF * 64;
+            m = MBF;
+            l = (jj / (REM > 0 ? REM : 1)) * 16 + jj % (REM > 0 ? REM : 1);
+        } else {                                        // the zero slot: a lane of an absent channel of the partial block
+            m = MBF;
+            l = 15;
+        }
+        wvoff[k] = (uint32_t)(((step * a.nblkp + m) * 3 + part) * 64 + l) * 16u;
+    }
+    const uint32_t wchunk_bytes = (uint32_t)(kSteps * a.nblkp * 3 * 64) * 16u;
+    auto issue_w = [&](int chunk_) {
+        const uint32_t soff = (uint32_t)chunk_ * wchunk_bytes;
+#pragma unroll
+        for (int k = 0; k < NWK; ++k)
+            if (wave + k * (kT / 64) < NWI) {           // (wave-uniform)
+                if (wok[k]) dma_x4(w_lds + (uint32_t)(wave + k * (kT / 64)) * 1024u, wvoff[k], wrs, soff);
+            }
+    };
+    if (!multi) issue_w(0);
+
     // gradient input in the fp16 format: x S rides in the affine table, the accumulators get 1 / S (san_conv_bf16.hip)
     float inS = 1.f, inInvS = 1.f;
     if (a.amax) {
@@ -154,34 +239,15 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
         }
     }
     // lazy-affine table of image n: [chunk][scale 24 | shift 24]
-    auto load_aff = [&](int n) {
+    auto load_aff = [&](int n_) {
         if (tid < a.chunks * 48) {
             const int c = tid / 48, j = tid - c * 48;
             const int ci = min(c * kCKC + (j < 24 ? j : j - 24), a.cin - 1);
             const float* src = j < 24 ? a.in_scale : a.in_shift;
-            lds_aff[tid] = has_aff ? src[n * a.x_ctot + a.x_coff + ci] * inS : (j < 24 ? inS : 0.f);
+            lds_aff[tid] = has_aff ? src[n_ * a.x_ctot + a.x_coff + ci] * inS : (j < 24 ? inS : 0.f);
         }
     };
-
-    // ---- staging units: slots 0..2 = pixel tid of channel group s; slot 3 = pixels 256..339 x 3 groups (tid < 252)
-    const int pr0 = tid / kHP, pc0 = tid - pr0 * kHP;
-    const bool u3 = tid < 3 * (kNP - kT);
-    const int g3 = u3 ? tid / (kNP - kT) : 0;
-    const int p3 = u3 ? kT + tid - g3 * (kNP - kT) : 0;
-    const int pr3 = p3 / kHP, pc3 = p3 - pr3 * kHP;
-
-    // ---- DMA pieces: piece j of a channel = halo pixels 64 j + lane
-    int dpr[kPieces], dpc[kPieces];
-#pragma unroll
-    for (int j = 0; j < kPieces; ++j) {
-        const int p = min(64 * j + lane, kNP - 1);
-        dpr[j] = p / kHP;
-        dpc[j] = p - dpr[j] * kHP;
-    }
-    const uint64_t xa = reinterpret_cast<uint64_t>(a.x);
-    const v4i rs = {__builtin_amdgcn_readfirstlane((int)(uint32_t)xa), __builtin_amdgcn_readfirstlane((int)(uint32_t)(xa >> 32)),
-                    __builtin_amdgcn_readfirstlane((int)a.x_bytes), 0x00020000};
-    const uint32_t raw_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw;
+    load_aff(n);
 
     // ---- K-loop operand addressing (as conv_bf16x3_kernel, 32 x 8 tile)
     int tapoff[kSteps];
@@ -204,62 +270,31 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- work items (tile, chunk)
-    int n = fdiv(t, a.m_nt, ntile);
-    int tile = t - n * ntile;
-    int ty = fdiv(tile, a.m_tx, a.tiles_x), tx = tile - ty * a.tiles_x;
-    int chunk = 0;
-
-    // issue the LDS-DMA of item (n_, ty_, tx_, chunk_): wave w brings channels w, w + 4, ... of the chunk
-    auto issue_dma = [&](int n_, int ty_, int tx_, int chunk_) {
-        const int y0 = ty_ * kTH - 1, x0 = tx_ * kTW - 1;
-        uint32_t voff[kPieces];
-#pragma unroll
-        for (int j = 0; j < kPieces; ++j) {
-            const int gy = min(max(y0 + dpr[j], 0), H - 1), gx = min(max(x0 + dpc[j], 0), W - 1);     // (clamped: the frame is zeroed by the staging pass)
-            voff[j] = (uint32_t)(gy * W + gx) * 4u;
-        }
-        const int nch = min(kCKC, a.cin - chunk_ * kCKC);
-        const int cbase = n_ * a.x_ctot + a.x_coff + chunk_ * kCKC;
-        for (int cc = wave; cc < nch; cc += kT / 64) {
-            const uint32_t soff = (uint32_t)(cbase + cc) * (uint32_t)HWp * 4u;
-            const uint32_t dst = raw_base + (uint32_t)cc * (kNP * 4);
-#pragma unroll
-            for (int j = 0; j < kPieces - 1; ++j) dma_dword(dst + j * 256, voff[j], rs, soff);
-            if (lane < kNP - 64 * (kPieces - 1)) dma_dword(dst + (kPieces - 1) * 256, voff[kPieces - 1], rs, soff);
-        }
-    };
-
-    load_aff(n);
-    issue_dma(n, ty, tx, 0);
-    bool stores_behind = false;                        // the previous item ended with an epilogue: >= kStores stores were issued after this item's DMA
+    if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the resident weight image (and, once, the first prefetch)
     for (;;) {
-        // ---- the raw tile of this item has landed (own DMA: counted wait -- vector memory operations retire in order, so with at
-        // most kStores outstanding every DMA piece, issued before them, is done; the others' pieces: barrier); the K-loop of the
-        // previous item is over for every wave, so the operand image may be rewritten
-        if (stores_behind && !a.vm_wait) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kStores) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ---- every wave has left the previous item's K-loop: the operand image (and the streamed weight chunk) may be rewritten
         lds_barrier();
-        const int y0 = ty * kTH, x0 = tx * kTW;
+        if (multi) issue_w(chunk);
         const int nch = min(kCKC, a.cin - chunk * kCKC);
         const float* afc = lds_aff + chunk * 48;
-        const float* rawf = reinterpret_cast<const float*>(lds_raw);
-        auto stage_unit = [&](int g, int p, int pr, int pc, bool uniform_g) {
-            const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        // registers -> LDS: lazy affine + LeakyReLU (one v_med3 per element), split into two fp16 parts, [pixel][channel] image
+        auto stage_unit = [&](const float (&raw)[8], int g, int p, bool in, int npair) {
             unsigned char* dst = lds_a + p * kPS + g * 16;
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (in) {
                 const f4 sc0 = *reinterpret_cast<const f4*>(afc + g * 8), sc1 = *reinterpret_cast<const f4*>(afc + g * 8 + 4);
                 const f4 sh0 = *reinterpret_cast<const f4*>(afc + 24 + g * 8), sh1 = *reinterpret_cast<const f4*>(afc + 24 + g * 8 + 4);
                 uint32_t q1[4], q2[4];
 #pragma unroll
                 for (int i = 0; i < 8; i += 2) {
-                    // channels past the chunk's last are read from its last one (finite) and meet zero weights
-                    const float r0 = rawf[min(g * 8 + i, nch - 1) * kNP + p], r1 = rawf[min(g * 8 + i + 1, nch - 1) * kNP + p];
-                    const float a0 = __builtin_fmaf(r0, i < 4 ? sc0[i] : sc1[i - 4], i < 4 ? sh0[i] : sh1[i - 4]);
-                    const float a1 = __builtin_fmaf(r1, i < 4 ? sc0[i + 1] : sc1[i - 3], i < 4 ? sh0[i + 1] : sh1[i - 3]);
-                    const float v0 = __builtin_amdgcn_fmed3f(a0, a0 * a.in_slope, lrelu_c);
-                    const float v1 = __builtin_amdgcn_fmed3f(a1, a1 * a.in_slope, lrelu_c);
-                    split2h_pair(v0, v1, q1[i >> 1], q2[i >> 1]);
+                    q1[i >> 1] = 0u;
+                    q2[i >> 1] = 0u;
+                    if ((i >> 1) < npair) {
+                        const float a0 = __builtin_fmaf(raw[i], i < 4 ? sc0[i] : sc1[i - 4], i < 4 ? sh0[i] : sh1[i - 4]);
+                        const float a1 = __builtin_fmaf(raw[i + 1], i < 4 ? sc0[i + 1] : sc1[i - 3], i < 4 ? sh0[i + 1] : sh1[i - 3]);
+                        const float v0 = __builtin_amdgcn_fmed3f(a0, a0 * a.in_slope, lrelu_c);
+                        const float v1 = __builtin_amdgcn_fmed3f(a1, a1 * a.in_slope, lrelu_c);
+                        split2h_pair(v0, v1, q1[i >> 1], q2[i >> 1]);
+                    }
                 }
                 *reinterpret_cast<uint4*>(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
                 *reinterpret_cast<uint4*>(dst + kPartB) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
@@ -267,15 +302,18 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
                 *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
                 *reinterpret_cast<uint4*>(dst + kPartB) = make_uint4(0u, 0u, 0u, 0u);
             }
-            (void)uniform_g;
         };
+        if (!(a.abl & 2)) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-            if (s * 8 < nch) stage_unit(s, tid, pr0, pc0, true);           // (empty groups keep their zeros / stale finite values x zero weights)
-        if (u3 && g3 * 8 < nch) stage_unit(g3, p3, pr3, pc3, false);
+            for (int s = 0; s < 3; ++s)
+                if (s * 8 < nch) stage_unit(st[s], s, tid, in0, min(4, (nch - s * 8 + 1) >> 1));     // (wave-uniform pair count)
+            if (u3 && g3 * 8 < nch) stage_unit(st[3], g3, p3, in3, 4);
+        }
+        if (multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the weight chunk have landed
         lds_barrier();
 
-        // ---- the raw tile is free: prefetch the next item
+        // ---- the staging registers are free: request the next item's input
+        const int y0 = ty * kTH, x0 = tx * kTW;
         int nn_ = n, nty = ty, ntx = tx, nchunk = chunk + 1;
         bool more = true;
         if (nchunk == a.chunks) {
@@ -290,18 +328,17 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
                 if (nn_ != n) load_aff(nn_);            // (every wave is past its last read of the table: the barrier above)
             }
         }
-        if (more) issue_dma(nn_, nty, ntx, nchunk);
+        if (more && !(a.abl & 1)) prefetch(nn_, nty, ntx, nchunk);
 
         // ---- 7 K-steps on the staged image; operands of step s + 1 are requested before the MFMAs of step s
-        {
+        if (!(a.abl & 4)) {
             Frag wa[2][MB][2], xa[2][4][2];
-            const unsigned char* wc = lds_w + chunk * WCH;
             auto load_w = [&](int s, Frag (&wq)[MB][2]) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
-                        wq[m][p].u = *reinterpret_cast<const uint4*>(wc + (s * 2 + p) * RS + (m < MBF ? m * 1024 + wl_full : wl_rem));
+                        wq[m][p].u = *reinterpret_cast<const uint4*>(lds_w + (s * 2 + p) * RS + (m < MBF ? m * 1024 + wl_full : wl_rem));
             };
             auto load_x = [&](int s, Frag (&xq)[4][2]) {
                 const int to = tapoff[s];
@@ -331,12 +368,13 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
         }
 
         // ---- last chunk of the tile: epilogue.  acc[m][b][r] = channel 16 m + nn at tile pixel 64 wave + 16 b + 4 kg + r
-        stores_behind = chunk == a.chunks - 1;
-        if (stores_behind) {
+        if (chunk == a.chunks - 1) {
+            if (a.amax) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[m][b] = acc[m][b] * inInvS;
+                    for (int b = 0; b < 4; ++b) acc[m][b] = acc[m][b] * inInvS;
+            }
             if (a.bias) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
@@ -346,7 +384,7 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
                     for (int b = 0; b < 4; ++b) acc[m][b] += f4{bv, bv, bv, bv};
                 }
             }
-            if (a.part) {
+            if (a.part && !(a.abl & 8)) {
                 const int tiles = ntile * 4;
 #pragma unroll
                 for (int m = 0; m < MB; ++m) {
@@ -381,7 +419,7 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int q = 64 * wave + 16 * b + 4 * kg;
-                    if (co < a.cout) *reinterpret_cast<f4*>(dst + (y0 + (q >> 5)) * W + x0 + (q & 31)) = acc[m][b];
+                    if (co < a.cout && !(a.abl & 16)) *reinterpret_cast<f4*>(dst + (y0 + (q >> 5)) * W + x0 + (q & 31)) = acc[m][b];
                     acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -395,29 +433,33 @@ __global__ void __launch_bounds__(kT, 2) conv3x3_stream_kernel(const SArgs a) {
     }
 }
 
-int g_stream = 0;              // SAN_CONV_STREAM=1: on (off until it beats the one-tile kernel)
-int g_stream_wait = 0;         // SAN_CONV_STREAM_WAIT=1: vmcnt(0) instead of the counted wait
+int g_stream = 1;              // SAN_CONV_STREAM=0: off
 int g_stream_wgs = 0;          // SAN_CONV_STREAM_WGS: workgroups per CU (0: as many as the LDS allows, at most 2)
+int g_stream_abl = 0;
+int g_stream_stag = 0, g_stream_stag_mode = 0;
 struct StreamEnv {
     StreamEnv() {
         if (const char* e = getenv("SAN_CONV_STREAM")) g_stream = atoi(e);
-        if (const char* e = getenv("SAN_CONV_STREAM_WAIT")) g_stream_wait = atoi(e);
         if (const char* e = getenv("SAN_CONV_STREAM_WGS")) g_stream_wgs = atoi(e);
+        if (const char* e = getenv("SAN_CONV_STREAM_ABL")) g_stream_abl = atoi(e);
+        if (const char* e = getenv("SAN_CONV_STREAM_STAG")) g_stream_stag = atoi(e);
+        if (const char* e = getenv("SAN_CONV_STREAM_STAGMODE")) g_stream_stag_mode = atoi(e);
     }
 } g_stream_env;
 
-template <int MBF, int REM>
-size_t stream_lds(int chunks) {
-    constexpr int RS = MBF * 1024 + (REM > 0 ? REM * 64 + 16 : 0);
-    return (size_t)kRawB + 2 * kPartB + (size_t)chunks * 192 + (size_t)chunks * kSteps * 2 * RS;
+size_t stream_lds_bytes(int cin, int cout) {
+    const int chunks = san_cdiv(cin, kCKC);
+    const int mbf = cout / 16, rem = cout % 16;
+    const size_t rs = (size_t)mbf * 1024 + (rem ? rem * 64 + 16 : 0);
+    return 2 * (size_t)kPartB + (size_t)chunks * 192 + (size_t)kSteps * 2 * rs;        // operand image, affine table, one chunk of weights
 }
 
-template <int MBF, int REM>
+template <int MBF, int REM, int OCC>
 int launch_stream(const SArgs& a, hipStream_t s) {
-    const size_t lds = stream_lds<MBF, REM>(a.chunks);
+    const size_t lds = stream_lds_bytes(a.cin, a.cout);
     static size_t configured = 0;
     if (lds > configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel<MBF, REM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel<MBF, REM, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the stream convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -425,12 +467,12 @@ int launch_stream(const SArgs& a, hipStream_t s) {
         configured = lds;
     }
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > OCC) per_cu = OCC;
     if (g_stream_wgs > 0 && g_stream_wgs < per_cu) per_cu = g_stream_wgs;
     int grid = 256 * per_cu;
     const int need = ((a.total + 7) / 8) * 8;           // (a multiple of 8: the tile ranges are per XCD)
     if (grid > need) grid = need;
-    hipLaunchKernelGGL((conv3x3_stream_kernel<MBF, REM>), dim3(grid), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_stream_kernel<MBF, REM, OCC>), dim3(grid), dim3(kT), lds, s, a);
     return SAN_OK;
 }
 
@@ -440,15 +482,10 @@ int launch_stream(const SArgs& a, hipStream_t s) {
 int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot) {
     if (!g_stream) return 0;
     if ((w % kTW) != 0 || (h % kTH) != 0 || w < 64 || h * w < 160 * 160) return 0;
-    if (cin > 3 * kCKC) return 0;
+    if (cin > 4 * kCKC) return 0;
     if (!(cout == 18 || cout == 32 || cout == 36 || cout == 16 || cout == 48)) return 0;
     if ((unsigned long long)n * x_ctot * h * w * 4ull >= 0x7fffffffull) return 0;
-    // LDS: everything resident
-    const int chunks = san_cdiv(cin, kCKC);
-    const int mbf = cout / 16, rem = cout % 16;
-    const size_t rs = (size_t)mbf * 1024 + (rem ? rem * 64 + 16 : 0);
-    const size_t lds = (size_t)kRawB + 2 * kPartB + (size_t)chunks * 192 + (size_t)chunks * kSteps * 2 * rs;
-    return lds <= 160 * 1024 ? 1 : 0;
+    return stream_lds_bytes(cin, cout) <= 160 * 1024 ? 1 : 0;      // everything resident
 }
 
 int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
@@ -479,21 +516,24 @@ int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const f
     a.nblkp = nblkp;
     a.total = n * a.tiles_x * a.tiles_y;
     a.x_bytes = (unsigned)((size_t)n * x_ctot * h * w * 4);
+    a.w_bytes = (unsigned)((size_t)a.chunks * kSteps * nblkp * 3 * 64 * 16);
     auto magic = [&](int d) -> unsigned {
         return (d > 1 && (unsigned long long)a.total * (unsigned long long)d < 0xffffffffull) ? (unsigned)(0x100000000ull / (unsigned)d + 1) : 0u;
     };
     a.m_nt = magic(a.tiles_x * a.tiles_y);
     a.m_tx = magic(a.tiles_x);
-    a.vm_wait = g_stream_wait;
+    a.abl = g_stream_abl;
+    a.stag = g_stream_stag;
+    a.stag_mode = g_stream_stag_mode;
     SAN_CHECK_ARG((reinterpret_cast<uintptr_t>(y) & 15) == 0, "stream convolution: output must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     int rc;
     switch (cout) {
-        case 16: rc = launch_stream<1, 0>(a, s); break;
-        case 18: rc = launch_stream<1, 2>(a, s); break;
-        case 32: rc = launch_stream<2, 0>(a, s); break;
-        case 36: rc = launch_stream<2, 4>(a, s); break;
-        case 48: rc = launch_stream<3, 0>(a, s); break;
+        case 16: rc = launch_stream<1, 0, 2>(a, s); break;
+        case 18: rc = launch_stream<1, 2, 2>(a, s); break;
+        case 32: rc = launch_stream<2, 0, 2>(a, s); break;
+        case 36: rc = launch_stream<2, 4, 2>(a, s); break;
+        case 48: rc = launch_stream<3, 0, 2>(a, s); break;
         default: san_set_error("stream convolution: unsupported cout %d", cout); return SAN_E_UNSUPPORTED;
     }
     if (rc != SAN_OK) return rc;
