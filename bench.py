@@ -8,10 +8,12 @@
 ``python bench.py --gpus N`` with N > 1 and no torch.distributed.run environment re-launches itself under
 ``torch.distributed.run`` (one process per GPU, 127.0.0.1 rendezvous); both invocations print the same line.
 
-The timed training steps are REPLAYS of one recorded step (CSModel.record_update: the step's ~2,000 C-ABI calls, stream /
-event operations and torch operations with their arguments as a flat call list; nothing is skipped or cached -- every kernel of
-set_input + forward + backward + exchange + AdamW is launched again, the Python between the launches is not).  The eager step
-is host-limited by ~5 % on this workload (`--eager` times it; `--graph` times a hipGraph of it).
+The timed training steps are the reference's own calls, ``net.set_input(*batch); net.update()`` (train.py:212-217).
+CSModel.update() runs its first two calls eagerly, records the third (the step's ~2,000 C-ABI calls, stream / event operations
+and torch operations with their arguments as a flat call list) and replays it from then on; nothing is skipped or cached --
+every kernel of set_input + forward + backward + exchange + AdamW is launched again, the Python between the launches is not.
+`config.step_mode` states the form; `eager_step` is the same call with the recording switched off (also `--eager` for the whole
+run); `--graph` times a hipGraph of the step.
 
 One "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
 CSModel.set_input (fft2 -> column mask -> ifft2 -> rss) + CSModel.update() = forwardT (alignment U-Net + bilinear warp
@@ -30,9 +32,12 @@ Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max ran
                    three bf16 parts with SAN_NO_F16X2=1): `executed_tflops` and `frac_of_bf16x3_ceiling` (ceiling =
                    2500 / products TFLOP/s fp32-equivalent; fp16 and bf16 dense MFMA peaks are equal) are extras.
                    The LAST timed step is a second recording of the same step that carries an event pair around every 5th
-                   launch of a family (run alone: the two streams are joined around it); the other timed steps run without
-                   brackets.  Eager mode: every 29th launch of every step.
-  roofline_*     : the same for the fused FFT + data-consistency kernels (HBM) and the other conv families.
+                   launch of a conv family and around EVERY cascade-boundary launch (run alone: the two streams are joined
+                   around it); the other timed steps run without brackets.  Eager mode: every 29th launch of every step.
+  roofline_*     : the same for the fused FFT + data-consistency kernels (HBM; forward and backward boundary: `frac` = one
+                   event pair around 12 back-to-back launches right after the timed region, the in-step single-launch
+                   brackets under `per_launch_brackets`), the norm + LeakyReLU backward family (HBM, bytes = the plane
+                   passes each call really makes) and the other conv families.
                    `event_pair_overhead_us` = the elapsed time of an event pair with nothing in between, measured in
                    the same run, and `frac_net_of_event_overhead` = frac with that subtracted from the launch time
                    (a 16 us kernel reads ~19.5 us between its events); `achieved` / `frac` are the RAW event figures.
@@ -175,7 +180,7 @@ def cpu_baseline(num_cascades, h, w, mode="train", coils=1, sparsity=0.25, batch
     """The oracle on host cores: the same arithmetic as the reference's CPU path (same ATen
     kernels).  Train mode = forward + autograd backward + torch.optim.AdamW step for both networks (model.py:206-216),
     i.e. the same work as the GPU leg.  Legs: N = 1 on all usable cores, N = `batch` on all usable cores, N = 1 on one
-    thread; each leg runs whole steps until its share of ~budget_s is spent (at least one)."""
+    thread; each leg runs whole steps until its share of ~budget_s is spent (at least one; the N = `batch` leg at least two)."""
     from oracle import cpu_ref as O
     from spatialalignmentnetwork_amd import synth
     from spatialalignmentnetwork_amd.cross import SpatialTransformer
@@ -221,7 +226,7 @@ def cpu_baseline(num_cascades, h, w, mode="train", coils=1, sparsity=0.25, batch
             while True:
                 run(n)
                 done += 1
-                if time.perf_counter() - t0 > budget_s * share or done >= 64:
+                if (time.perf_counter() - t0 > budget_s * share and done >= (2 if n > 1 else 1)) or done >= 64:
                     break
             dt = time.perf_counter() - t0
             legs.append({"n": n, "threads": threads, "steps": done, "seconds": round(dt, 2), "slices_per_s": n * done / dt})
@@ -358,32 +363,36 @@ def main(argv=None):
     graph = None
     timer = None
     step_mode = "eager"
+    if args.mode == "train" and args.eager:
+        net.auto_record = False                     # every timed step launched from Python
     if args.mode == "train" and not args.eager and not args.graph:
-        # Default: record one training step and time replays of it.  Nothing is skipped or cached: a replay re-issues every kernel of set_input + forward + backward +
-        # exchange + AdamW; only the Python between the launches is not run again.  Falls back to eager launching if the
-        # recording cannot be made.
-        try:
-            graph = net.record_update(img_full, img_aux, warmup=1, restore=False)
-            marked = graph
-            if not args.no_kernel_timer:
-                # a second recording of the same step WITH the roofline event brackets (every 5th launch of a family, run
-                # alone): it is the LAST of the timed steps, so the HIP-event figures come from inside the timed region while
-                # the other steps run without the brackets' stream joins
-                timer = ops.KernelTimer(stride=5)
+        # Default: the timed steps are the reference's own calls, ``net.set_input(*batch); net.update()`` (train.py:212-217).
+        # update() records the step after two eager calls and replays it from then on (CSModel.update); nothing is skipped
+        # or cached: a replay re-issues every kernel of set_input + forward + backward + exchange + AdamW, only the Python
+        # between the launches is not run again.  Make sure the switch has happened before the timed region.
+        tries = 0
+        while not str(getattr(net, "step_mode", "")).startswith("replay") and tries < 4:
+            step()
+            tries += 1
+        torch.cuda.synchronize()
+        step_mode = "CSModel.update(): " + str(getattr(net, "step_mode", "eager"))
+        if str(getattr(net, "step_mode", "")).startswith("replay") and not args.no_kernel_timer:
+            try:
+                # a second recording of the same step WITH the roofline event brackets (every 5th launch of a conv family,
+                # EVERY cascade-boundary launch, each run alone): it is the LAST of the timed steps, so the HIP-event
+                # figures come from inside the timed region while the other steps run without the brackets' stream joins
+                timer = ops.KernelTimer(stride=5, strides={"fft_dc": 1, "fft_dc_bwd": 1})
                 marked = net.record_update(img_full, img_aux, warmup=1, restore=False, timer=timer)
-            graph.replay()
-            torch.cuda.synchronize()
-            clean_replay, marked_replay, left = graph.replay, marked.replay, [args.steps]
+                graph = marked
+                torch.cuda.synchronize()
+                plain_step, marked_replay, left = step, marked.replay, [args.steps]
 
-            def step():
-                left[0] -= 1
-                (marked_replay if left[0] == 0 else clean_replay)()
-
-            step_mode = "replay of a recorded step (CSModel.record_update)"
-        except Exception as e:                      # pragma: no cover
-            print(f"[bench] record_update failed ({type(e).__name__}: {e}); timing eager steps", file=sys.stderr, flush=True)
-            graph, timer = None, None
-            step_mode = f"eager (record_update failed: {type(e).__name__})"
+                def step():
+                    left[0] -= 1
+                    (marked_replay if left[0] == 0 else plain_step)()
+            except Exception as e:                  # pragma: no cover
+                print(f"[bench] the bracketed recording failed ({type(e).__name__}: {e}); no roofline figures", file=sys.stderr, flush=True)
+                timer = None
     if args.graph:
         # the arena, packed weights, twiddles and masks exist after warm-up, so the step neither
         # allocates through the library nor synchronises: it is capture-safe
@@ -404,7 +413,7 @@ def main(argv=None):
         step = graph.replay
         args.no_kernel_timer = True
     barrier()
-    replaying = step_mode.startswith("replay")
+    replaying = "replay" in step_mode
     if args.graph:
         step_mode = "hipGraph replay"
     if not args.no_kernel_timer and not replaying:
@@ -432,6 +441,24 @@ def main(argv=None):
     if args.mode == "train" and dist is not None and not args.graph:
         # (a recorded step holds ONE set of event pairs, re-recorded by every replay: the last replay's duration)
         allreduce_ms = sdist.max_over_ranks(net.exchange_ms(), dist, dev) / (1 if replaying else args.steps)
+
+    eager_leg = None
+    if args.mode == "train" and replaying and not args.graph and not args.main_only:
+        # the same call with the recording switched off (every launch issued from Python): reported next to the headline
+        net.auto_record = False
+        esteps = max(3, args.steps // 3)
+        train_step(net, img_full, img_aux)
+        torch.cuda.synchronize()
+        barrier()
+        te = time.perf_counter()
+        for _ in range(esteps):
+            train_step(net, img_full, img_aux)
+        torch.cuda.synchronize()
+        barrier()
+        dte = sdist.max_over_ranks(time.perf_counter() - te, dist, dev)
+        net.auto_record = True
+        eager_leg = {"value": n * world * esteps / dte, "unit": "slices/s", "ms_per_step": 1e3 * dte / esteps, "steps": esteps,
+                     "step_mode": "CSModel.update(): eager (auto_record = False)"}
 
     infer = None
     if args.mode == "train" and not args.main_only:
@@ -544,6 +571,8 @@ def main(argv=None):
             # bucket overlaps the alignment network's backward); null on one GPU and in --graph mode
             "allreduce_ms": allreduce_ms,
         }
+        if eager_leg is not None:
+            out["eager_step"] = eager_leg
         if infer is not None:
             out["inference"] = infer
         if variants is not None:
@@ -565,13 +594,29 @@ def main(argv=None):
                 v.setdefault("source", f"profiles/{pmc_file}")
             match = args.mode == "train" and (n, h, w, c, args.cascades) == (8, 320, 320, 1, 12)
             ev_us = ops.KernelTimer.event_pair_overhead_us()
-            for key, field in ((dom, "roofline"), ("fft_dc", "roofline_fft_dc"), ("conv3x3", "roofline_conv_fp32"),
+            for key, field in ((dom, "roofline"), ("fft_dc", "roofline_fft_dc"), ("fft_dc_bwd", "roofline_fft_dc_bwd"),
+                               ("conv3x3", "roofline_conv_fp32"),
                                ("conv3x3_bf16x3", "roofline_conv_bf16x3"), ("wgrad3x3_bf16x3", "roofline_wgrad_bf16x3"),
-                               ("wgrad3x3", "roofline_wgrad_fp32")):
+                               ("wgrad3x3", "roofline_wgrad_fp32"), ("act_bwd", "roofline_act_bwd")):
                 if key not in tot or (field != "roofline" and key == dom) or tot[key]["sampled_launches"] == 0:
                     continue
                 out[field] = roofline_entry(key, tot[key], dt, args.steps, pmc, match and args.dtype == "fp32",
                                             {"fp32": 6.0, "bf16x2": 3.0, "bf16": 1.0, "fp8": 1.0}[args.dtype], ev_us)
+            # The cascade boundary: every forward and backward launch of the marked step carries its own event pair (the pair's
+            # ~5 us are a quarter of a 14 us kernel), and ONE pair around 12 back-to-back re-issues of the step's last
+            # boundary launch right after the timed region amortises them: `frac` / `achieved` / `avg_launch_us` are that
+            # batch's raw figures, the in-step single-launch brackets stay next to them.
+            for fam in ("fft_dc", "fft_dc_bwd"):
+                ent = out.get("roofline" if dom == fam else "roofline_" + fam)
+                b = timer.batch(fam, 12) if ent is not None else None
+                if b is not None:
+                    us, work = b
+                    ent["per_launch_brackets"] = {k: ent[k] for k in ("achieved", "frac", "avg_launch_us", "timed_launches") if k in ent}
+                    ent["avg_launch_us"] = us
+                    ent["achieved"] = work / (us * 1e-6) / 1e9
+                    ent["frac"] = ent["achieved"] / HBM_PEAK_GBS
+                    ent["timing"] = "one HIP-event pair around 12 back-to-back launches (best of 5 batches), raw"
+                    ent.pop("frac_net_of_event_overhead", None)
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)

@@ -481,6 +481,14 @@ int san_gradient_loss_fwd(const float* offset, float* loss, int n, int h, int w,
  * san_conv_bf16x3_pack_job / _pack_batch: the batched form (host table entry, one launch), as for
  * san_conv_pack_job / san_conv_pack_batch. */
 int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks);
+/* Persistent ("stream") form of the fp16-part 3x3 convolution (csrc/san_conv_stream.hip, round 4): workgroups walk a sequence of
+ * 32 x 8 tiles with the packed weights resident in LDS and the next tile's input requested a whole K-loop ahead.  Taken
+ * automatically by san_conv2d_bf16x3_fwd / _fwd_ws / _fwd_ws_in / san_conv_bf16x3_dgrad_amax (same arguments, same statistics
+ * records) where san_conv_stream_eligible() says 1: fp16-format weights, h % 8 == 0, w % 32 == 0, h * w >= 160^2, cin <= 96,
+ * cout in {16, 18, 32, 36, 48}.  Replaces nn.Conv2d(3x3, padding 1) of varnet.py:139-146 and its autograd data gradient on the
+ * 320^2 / 160^2 levels.  san_conv_stream_set_tuning(0) sends every layer to the one-tile-per-workgroup kernel (tests). */
+int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot);
+int san_conv_stream_set_tuning(int on);
 int san_conv_bf16x3_debug_timeline(void* buf);   /* tuning: per-workgroup clock marks of the next launches (8 x u64 each; NULL = off), scratch/conv_timeline.py */
 int san_conv_bf16x3_set_tuning(int wd, int mb);   /* tests / tuning: weights-direct form (-1 auto, 0, 1), channel blocks per workgroup (-1 auto, 2..5) */
 size_t san_conv_bf16x3_packed_bytes(int cout, int cin);

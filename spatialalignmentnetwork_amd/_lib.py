@@ -26,7 +26,8 @@ LIB_PATH = os.path.join(HERE, "libsan_hip.so")
 # over those pairs -- the Python between the calls (layer logic, arena look-ups, argument marshalling decisions: three
 # quarters of the ~45 ms a step costs the host) is not run again.  Unlike a hipGraph this keeps ordinary stream semantics (and
 # ROCm's graph launch was measured to cost the host as much as eager launching).
-REC = None          # list of (callable, args) while recording
+REC = None          # list of (callable, args, kind) while recording; kind 0 = Python callable, 1 = C-ABI call (returns an rc that a
+                    # replay checks), 2 = C-ABI weight-packing launch (a forward-only replay skips it while the weights are unchanged)
 KEEP = None         # objects whose addresses were recorded (host scratch of C calls)
 IN_REC = [0]        # > 0 inside rec(): torch operations seen by the recording's dispatch mode are accounted for
 UNTRACKED = [0]     # > 0 inside untracked(): torch operations that need no replay (constants, host-side scalars)
@@ -40,7 +41,7 @@ def rec(fn, *args):
     finally:
         IN_REC[0] -= 1
     if REC is not None:
-        REC.append((fn, args))
+        REC.append((fn, args, 0))
     return out
 
 
@@ -129,14 +130,14 @@ class SanLibrary:
             kind = "argument error" if rc < 0 else "hipError_t"
             raise RuntimeError(f"{name} failed ({kind} {rc}): {self.last_error()}")
         if REC is not None:
-            REC.append((fn, args))
+            REC.append((fn, args, 2 if "_pack" in name else 1))
 
     def query(self, name: str, *args):
         """Call a size/count query (returns its value)."""
         if name in self._STATEFUL:
             fn = getattr(self, "_" + name)
             if REC is not None and name == "san_wgrad_defer":      # switches the library's deferred-reduction mode: part of the step
-                REC.append((fn, args))
+                REC.append((fn, args, 0))         # (returns the previous mode, not an rc)
             return fn(*args)
         key = (name, args)
         try:

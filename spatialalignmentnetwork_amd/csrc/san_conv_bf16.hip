@@ -33,7 +33,6 @@
 
 void san_wgrad_set_parts(int parts);             // san_wgrad_bf16.hip
 // san_conv_stream.hip: the persistent form for the high-resolution few-channel layers (fp16-format weights)
-int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot);
 int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
                         const void* w_packed, int nblkp, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
                         const void* amax, int n, int h, int w, void* stream);

@@ -478,6 +478,14 @@ int launch_stream(const SArgs& a, hipStream_t s) {
 
 }  // namespace
 
+extern "C" {
+
+// tests / tuning: 0 = every layer on the one-tile-per-workgroup kernel, 1 = the stream form where eligible
+int san_conv_stream_set_tuning(int on) {
+    g_stream = on ? 1 : 0;
+    return SAN_OK;
+}
+
 // 1 when the stream form takes this fp16-format 3x3 layer (called by conv_bf16x3_run, san_conv_bf16.hip)
 int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot) {
     if (!g_stream) return 0;
@@ -487,6 +495,8 @@ int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot)
     if ((unsigned long long)n * x_ctot * h * w * 4ull >= 0x7fffffffull) return 0;
     return stream_lds_bytes(cin, cout) <= 160 * 1024 ? 1 : 0;      // everything resident
 }
+
+}  // extern "C"
 
 int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
                         const void* w_packed, int nblkp, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,

@@ -12,6 +12,7 @@ model.py:64-71) instead of being hard-coded.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -33,6 +34,28 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
     return autograd.gradient_loss_nchw(s.permute(0, 3, 1, 2))     # differentiable (autograd._GradientLossFn)
 
 
+# CSModel.update() records the step (record_update) once it has seen AUTO_AFTER identical eager steps and replays it from then
+# on, so that the reference's own training loop (train.py:212-217: ``net.set_input(*batch); net.update()``) runs at the
+# recorded step's speed.  SAN_AUTO_RECORD=0 or cfg.auto_record = False: always eager.
+AUTO_RECORD = [os.environ.get("SAN_AUTO_RECORD", "1") != "0"]
+AUTO_AFTER = 2
+
+
+def _no_auto(fn):
+    """The explicit recorders / capturers run their warm-up and recorded steps eagerly (no nested auto-recording)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        prev = getattr(self, "_auto_busy", False)
+        self._auto_busy = True
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self._auto_busy = prev
+    return wrapped
+
+
 def _own_arena(fn):
     """Run a CSModel method with the model's own arena current (ops.use_arena): two models in one process never share
     activation tapes."""
@@ -49,7 +72,7 @@ class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena", "_exchange",
-                                                         "_exchange_events", "_split_capture", "time_exchange"}
+                                                         "_exchange_events", "_split_capture", "time_exchange", "_auto", "_auto_busy", "auto_record", "step_mode"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -160,10 +183,74 @@ class CSModel(BaseModel):
         ops.gradient_loss_bwd(off, g_off, float(self.cfg.weight_smooth), True)
         self.net_T.backward(g_off)
 
-    @_own_arena
     def update(self):
+        """One optimisation step (model.py:193-216).  The first AUTO_AFTER calls with a given configuration run eagerly; the
+        next one records the step (``record_update`` on private copies of the inputs; the recording itself does not advance
+        the model) and from then on every call copies the current ``img_full`` / ``img_aux`` into the recording's static inputs
+        and replays it -- bit-identical to the eager step (tests/test_hip_parity_r4.py).  Anything the recording depends on
+        (shapes, regime, loss weights, convolution precision, world size, train / eval flags, requires_grad pattern, parameter
+        and mask storage) is part of a key that is compared on every call: a change drops the recording and the step runs
+        eagerly again.  ``step_mode`` says which form the last call took."""
+        st = self._auto_state()
+        if st is not None:
+            if st["step"] is None and st["seen"] >= AUTO_AFTER and not st["failed"]:
+                try:
+                    self._auto_make(st)
+                except Exception as e:              # the step cannot be recorded (a stray torch operation, ...): stay eager
+                    st["failed"] = f"{type(e).__name__}: {e}"
+                    import warnings
+                    warnings.warn(f"CSModel.update(): recording the step failed, staying eager ({st['failed']})")
+            if st["step"] is not None:
+                return self._auto_replay(st)
+            st["seen"] += 1
+        self.step_mode = "eager"
+        return self._update_eager()
+
+    @_own_arena
+    def _update_eager(self):
         with ops.conv_precision(self._conv_mode()):
             return self._update()
+
+    def _auto_state(self):
+        """The auto-record state for the current configuration, or None when this call must run eagerly."""
+        if (not AUTO_RECORD[0] or not getattr(self, "auto_record", True) or getattr(self, "_auto_busy", False) or not self.training
+                or _lib.REC is not None or ops.TIMER is not None or self.device.type != "cuda" or not hasattr(self, "img_full")
+                or self.cfg.reg not in ("None", "Rec") or torch.cuda.is_current_stream_capturing()
+                or getattr(self, "_split_capture", False)):
+            return None
+        dist = _active_dist()
+        pr = self.net_mask.pruned
+        key = (tuple(self.img_full.shape), self.img_full.dtype, tuple(self.img_aux.shape), str(self.img_full.device), self.cfg.reg,
+               float(self.cfg.weight_sim), float(self.cfg.weight_smooth), self._conv_mode(), self.bwd_dtype,
+               dist.get_world_size() if dist is not None else 1, self.net_T.training, self.net_R.training,
+               tuple(p.requires_grad for o in (self.optim_R, self.optim_T) for p in o._params()),
+               tuple(o.bucket().flat_p.data_ptr() for o in (self.optim_R, self.optim_T)), pr.data_ptr(), pr._version,
+               ops.F16_FWD[0], ops.F16_BWD[0], ops.USE_BF16X3[0], ops.WGRAD_OVERLAP[0], ops.WGRAD_DEFER[0],
+               bool(getattr(self, "time_exchange", False)))
+        st = getattr(self, "_auto", None)
+        if st is None or st["key"] != key:
+            st = self._auto = {"key": key, "seen": 0, "step": None, "full": None, "aux": None, "attrs": None, "failed": None}
+        return st
+
+    def _auto_make(self, st) -> None:
+        full, aux = self.img_full.clone(), self.img_aux.clone()
+        st["step"] = self.record_update(full, aux, warmup=1, restore=True)
+        st["full"], st["aux"] = full, aux
+        # the recording's img_* / loss_* tensors: every replay refreshes them in place
+        st["attrs"] = {k: v for k, v in self.__dict__.items() if k.startswith(("img_", "loss_", "metric_")) and k != "loss_all"}
+
+    def _auto_replay(self, st) -> None:
+        if self.img_full is not st["full"]:
+            _lib.rec(st["full"].copy_, self.img_full)
+        if self.img_aux is not st["aux"]:
+            _lib.rec(st["aux"].copy_, self.img_aux)
+        for o in (self.optim_R, self.optim_T):
+            o.sync_hyper()                              # a learning-rate change since the last step reaches the device copy
+        st["step"].replay()
+        for name in [k for k in self.__dict__ if k.startswith(("loss_", "img_", "metric_"))]:
+            delattr(self, name)
+        self.__dict__.update(st["attrs"])
+        self.step_mode = "replay of a recorded step (auto-recorded by update())"
 
     def _conv_mode(self) -> str:
         return self.conv_dtype or ("bf16" if self.use_amp else "bf16x3")
@@ -234,6 +321,7 @@ class CSModel(BaseModel):
             self._exchange_events = []
         return ms
 
+    @_no_auto
     def capture_update(self, img_full, img_aux=None, warmup: int = 3, restore: bool = True):
         """Capture ``set_input(img_full, img_aux); update()`` into a hipGraph and return an object whose ``replay()`` runs
         one optimisation step on whatever the two input tensors hold at that time (refill them in place between
@@ -310,6 +398,7 @@ class CSModel(BaseModel):
             self._split_capture = False
         return CapturedStep([g1, g2], self._exchange_eager, "two graphs around an eager exchange")
 
+    @_no_auto
     def record_update(self, img_full, img_aux=None, warmup: int = 2, restore: bool = True, timer=None):
         """Record ``set_input(img_full, img_aux); update()`` once and return an object whose ``replay()`` re-issues exactly
         that step's ~2,000 C-ABI calls, stream / event operations and the handful of torch operations as a flat loop over
@@ -346,6 +435,7 @@ class CSModel(BaseModel):
             torch.cuda.synchronize()
         return step
 
+    @_no_auto
     def record_forward(self, img_full, img_aux=None, warmup: int = 1):
         """The inference pass (``set_input; forwardT; forwardR`` under ``no_grad``, as ``test()`` runs it minus the host-side
         metrics) as a recorded step: ``replay()`` refreshes ``img_rec`` / ``img_warped`` / ``loss_sim`` ... in place for
@@ -358,18 +448,22 @@ class CSModel(BaseModel):
                 self.loss_all = 0
                 self.forwardR()
 
+        for o in (self.optim_R, self.optim_T):
+            o.bucket()                          # parameters move into the flat buffers now: the recording holds their final addresses
         for _ in range(max(1, warmup)):
             run()
         torch.cuda.synchronize()
-        return self._record(run, "record_forward", None)
+        ops.bump_weight_epoch()                 # the recorded pass then contains the batched weight-packing launches: a replay
+        return self._record(run, "record_forward", None)     # after an optimiser step / load() re-packs (RecordedStep.replay)
 
     def _record(self, run, what: str, timer):
         """Execute ``run()`` under the recorder (``_lib.REC``) and a dispatch mode that keeps every tensor it creates alive
         and refuses stray torch operations; returns the RecordedStep."""
         from torch.utils._python_dispatch import TorchDispatchMode
+        keep, stray = [], []
         for reg in (ops.PACKS, ops.PACKS16):   # the pack job tables are uploaded now (a host-to-device copy), not inside the step
             reg.ensure_table(self.device)
-        keep, stray = [], []
+            keep.append(reg.table)              # the recorded packing launch reads THIS table: it must outlive a later re-registration
 
         class _Watch(TorchDispatchMode):
             """Keeps every tensor the step creates alive (their addresses are in the recording) and notes torch operations
@@ -404,7 +498,7 @@ class CSModel(BaseModel):
         if stray:
             raise RuntimeError(f"{what}: torch operations outside _lib.rec / _lib.untracked in the step (a host "
                                "synchronisation such as .item() counts): " + ", ".join(sorted(set(stray))))
-        return RecordedStep(calls, keep)
+        return RecordedStep(calls, keep, training=what == "record_update")
 
     def _state_tensors(self):
         ts = []
@@ -510,15 +604,36 @@ class CSModel(BaseModel):
 
 
 class RecordedStep:
-    """What CSModel.record_update returns: ``replay()`` re-issues the recorded step."""
+    """What CSModel.record_update / record_forward return: ``replay()`` re-issues the recorded step.
 
-    def __init__(self, calls, keep):
-        self.calls, self.keep = calls, keep
+    Every C-ABI call of a replay has its return code checked (a failed launch raises, as it does in the eager step).
+    ``training`` steps change the weights, so a replay ends with ``ops.bump_weight_epoch()``: the next eager forward re-packs
+    its weight images (the optimiser's own bump is host code and not part of the recording).  Forward-only recordings
+    contain the batched weight-packing launches and run them only when the weights changed since their last replay."""
+
+    def __init__(self, calls, keep, training: bool = True):
+        self.calls, self.keep, self.training = calls, keep, training
         self.mode = f"recorded step: {len(calls)} calls"
+        self._packed_epoch = None
 
     def replay(self) -> None:
-        for fn, args in self.calls:
-            fn(*args)
+        skip_packs = (not self.training) and self._packed_epoch == ops.WEIGHT_EPOCH[0]
+        for fn, args, kind in self.calls:
+            if kind:
+                if kind == 2 and skip_packs:
+                    continue
+                rc = fn(*args)
+                if rc:
+                    raise RuntimeError(f"recorded step: {getattr(fn, '__name__', fn)} failed ({'argument error' if rc < 0 else 'hipError_t'} "
+                                       f"{rc}): {_lib.lib().last_error()}")
+            else:
+                fn(*args)
+        if self.training:
+            ops.bump_weight_epoch()
+        else:
+            # (the registries' own epoch is left alone: the recording's job table covers the jobs that existed when it was made,
+            # an eager step may have registered more since -- data-gradient images -- and re-packs all of them itself)
+            self._packed_epoch = ops.WEIGHT_EPOCH[0]
 
 
 class CapturedStep:
@@ -533,6 +648,7 @@ class CapturedStep:
             if self.between is not None:
                 self.between()
             g.replay()
+        ops.bump_weight_epoch()                 # the captured optimiser step changed the weights (its host-side bump is not in the graph)
 
 
 def _active_dist():

@@ -31,10 +31,12 @@ class KernelTimer:
     all layers of the periodic cascade structure);
     every launch is still counted, and totals() scales the sampled time up."""
 
-    def __init__(self, stride: int = 29):
+    def __init__(self, stride: int = 29, strides: Optional[dict] = None):
         self.stride = max(1, int(stride))
+        self.strides = dict(strides or {})      # per-family override (bench.py brackets EVERY cascade-boundary launch)
         self.recs = []
         self.seen = {}
+        self.last = {}                          # family -> (fn, work) of its most recent launch (batch())
 
     def bracket(self, name, work, unit, fn, abytes=0.0, xwork=0.0):
         d = self.seen.setdefault(name, {"launches": 0, "work": 0.0, "unit": unit, "abytes": 0.0, "xwork": 0.0})
@@ -42,7 +44,8 @@ class KernelTimer:
         d["work"] += work
         d["abytes"] += abytes
         d["xwork"] += xwork
-        if (d["launches"] - 1) % self.stride:
+        self.last[name] = (fn, work)
+        if (d["launches"] - 1) % self.strides.get(name, self.stride):
             fn()
             return
         e0 = torch.cuda.Event(enable_timing=True)
@@ -62,6 +65,26 @@ class KernelTimer:
         if other is not None:
             _lib.rec(other.wait_stream, cur)
         self.recs.append((name, work, e0, e1))
+
+    def batch(self, name: str, count: int = 12, rounds: int = 5):
+        """ONE event pair around ``count`` back-to-back re-issues of the family's most recent launch (same arguments, on the
+        current stream, nothing else running): the pair's own few microseconds amortise over the batch.  Returns
+        (average microseconds per launch -- the best of ``rounds`` batches --, work per launch) or None."""
+        if name not in self.last:
+            return None
+        fn, work = self.last[name]
+        best = None
+        for _ in range(rounds):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(count):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e3 / count
+            best = t if best is None else min(best, t)
+        return best, work
 
     @staticmethod
     def event_pair_overhead_us(pairs: int = 64) -> float:
@@ -98,7 +121,7 @@ class KernelTimer:
 TIMER: Optional[KernelTimer] = None
 
 
-TIMED_KERNELS = ("conv3x3", "conv3x3_bf16x3", "wgrad3x3", "wgrad3x3_bf16x3", "fft_dc")     # event pairs serialise neighbouring kernels: time only what the roofline needs
+TIMED_KERNELS = ("conv3x3", "conv3x3_bf16x3", "wgrad3x3", "wgrad3x3_bf16x3", "fft_dc", "fft_dc_bwd", "act_bwd")     # event pairs serialise neighbouring kernels: time only what the roofline needs
 
 
 def _timed(name, work, unit, fn, abytes=0.0, products=0):
@@ -432,9 +455,12 @@ def dc_rows_bwd(g: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, dc_w: t
     fp32 tensor) on the device, or returned as a 0-d tensor."""
     n, c, h, w = g.shape
     part = GLOBAL_ARENA.get("dcw_part", (lib().query("san_dc_rows_partials", n, c, h, w),), g.device)
-    lib().call("san_dc_rows", _p(_creal(g, "g")), _p(_creal(sens, "sens")), _p(None), _p(_chk(mask, name="mask")),
-               _p(_chk(dc_w, name="dc_w")), _p(None), _p(_creal(g_out, "g_out")), _p(_chk(h_out, name="h_out")),
-               int(h_out.shape[1]), _p(None), _p(_creal(dk, "dk")), _p(part), 1, n, c, h, w, _stream())
+    bargs = (_p(_creal(g, "g")), _p(_creal(sens, "sens")), _p(None), _p(_chk(mask, name="mask")),
+             _p(_chk(dc_w, name="dc_w")), _p(None), _p(_creal(g_out, "g_out")), _p(_chk(h_out, name="h_out")),
+             int(h_out.shape[1]), _p(None), _p(_creal(dk, "dk")), _p(part), 1, n, c, h, w, _stream())
+    # the adjoint launch does the forward boundary's work on the gradient: same SURVEY 8(d) count, its own family
+    _timed("fft_dc_bwd", float((6 * c + 2) * n * h * w * 8), "B", lambda: lib().call("san_dc_rows", *bargs),
+           float((5 * c + 2) * n * h * w * 8))
     if dcw_grad is not None:
         assert dcw_grad.numel() == 1 and dcw_grad.dtype == torch.float32 and dcw_grad.is_contiguous()
         lib().call("san_partials_add", _p(part), int(part.numel()), -1.0, _p(dcw_grad), _stream())
@@ -1364,6 +1390,14 @@ def _conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool 
             restore()
 
 
+def _act_bwd_bytes(y: Act, instance_norm: bool, extra: float = 0.0) -> float:
+    """HBM bytes one norm + LeakyReLU backward call really moves: planes up to 160^2 are read once (g, y) and written once (one
+    workgroup holds the plane); larger planes take the two reductions and the apply pass separately (g, y twice + dy); without
+    a norm there are no reductions.  ``extra`` = further planes (the half-resolution second source, an accumulated destination)."""
+    planes = 3.0 if (not instance_norm or y.h * y.w <= 160 * 160) else 5.0
+    return 4.0 * y.n * y.c * y.h * y.w * (planes + extra)
+
+
 def act_bwd_up_ok(y: Act) -> bool:
     """True where act_bwd can take a half-resolution second gradient source (even height, width % 4 == 0)."""
     return (y.h & 1) == 0 and (y.w & 3) == 0 and y.h * y.w // 4 < (1 << 22)
@@ -1380,9 +1414,10 @@ def act_bwd_ex(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOB
     if instance_norm:
         part = arena.get("bwd_part", (y.n, y.c, lib().query("san_bwd_stat_tiles", hw), 2), y.buf.device)
     dy.amax = AMAX.next(y.buf.device)
-    lib().call("san_act_bwd_ex_amax", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
-               float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, y.w,
-               (1 if unshuffle else 0) | (2 if accumulate else 0), _stream())
+    eargs = (_p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+             float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, y.w,
+             (1 if unshuffle else 0) | (2 if accumulate else 0), _stream())
+    _timed("act_bwd", _act_bwd_bytes(y, instance_norm, 1.0 if accumulate else 0.0), "B", lambda: lib().call("san_act_bwd_ex_amax", *eargs))
 
 
 def act_bwd_unshuffle_ok(y: Act) -> bool:
@@ -1403,17 +1438,21 @@ def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_
     dy.amax = AMAX.next(y.buf.device)
     if g2 is not None:
         assert g2.c == y.c and (2 * g2.h, 2 * g2.w) == (y.h, y.w) and act_bwd_up_ok(y)
-        lib().call("san_act_bwd_up_amax", _p(g.buf), g.ctot, g.coff, _p(g2.buf), g2.ctot, g2.coff, float(g2_scale), _p(y.buf),
-                   y.ctot, y.coff, _p(y.scale), _p(y.shift), float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf),
-                   dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, y.w, _stream())
+        uargs = (_p(g.buf), g.ctot, g.coff, _p(g2.buf), g2.ctot, g2.coff, float(g2_scale), _p(y.buf),
+                 y.ctot, y.coff, _p(y.scale), _p(y.shift), float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf),
+                 dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, y.w, _stream())
+        _timed("act_bwd", _act_bwd_bytes(y, instance_norm, 0.25 * (1.0 if y.h * y.w <= 160 * 160 else 2.0)), "B",
+               lambda: lib().call("san_act_bwd_up_amax", *uargs))
         return
     if dy.amax is None:
-        lib().call("san_act_bwd", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
-                   float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, hw, _stream())
+        aargs = (_p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+                 float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, y.n, y.c, hw, _stream())
+        _timed("act_bwd", _act_bwd_bytes(y, instance_norm), "B", lambda: lib().call("san_act_bwd", *aargs))
     else:
-        lib().call("san_act_bwd_amax", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
-                   float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax),
-                   y.n, y.c, hw, _stream())
+        aargs = (_p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
+                 float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax),
+                 y.n, y.c, hw, _stream())
+        _timed("act_bwd", _act_bwd_bytes(y, instance_norm), "B", lambda: lib().call("san_act_bwd_amax", *aargs))
 
 
 def unshuffle2(x: Act, y: Act) -> None:

@@ -1,0 +1,251 @@
+"""Round-4 GPU parity tests (through the C ABI): the reference's training loop on ``CSModel.update()`` with the auto-recorded step,
+the checked replay, packed-weight freshness across replays, the persistent ("stream") convolution against float64 and against
+the one-tile-per-workgroup kernel.  Tolerances are written next to each assertion together with what was measured."""
+import os
+
+import pytest
+import torch
+
+from conftest import philox
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def S():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spatialalignmentnetwork_amd import ops, synth, model, basemodel, _lib
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.ops, ns.synth, ns.model, ns.base, ns.lib = ops, synth, model, basemodel, _lib
+    return ns
+
+
+def g(t):
+    return t.to(DEV).contiguous()
+
+
+def _fill(S, m, seed, damp=1.0):
+    m.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=seed, damp=damp))
+
+
+def _model(S, w, c, reg="Rec", chans=18, **kw):
+    cfg = S.base.Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg=reg, mask="equispaced", weight_smooth=1000.0,
+                        weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=2, chans=chans,
+                        sens_chans=8, pools=2, sens_pools=2, **kw)
+    net = S.model.CSModel(cfg)
+    net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+    _fill(S, net.net_T, 41)
+    _fill(S, net.net_R, 42)
+    return net.to(DEV)
+
+
+def _state(net):
+    return {f"{s_}.{k}": v.detach().cpu().clone() for s_ in ("net_R", "net_T") for k, v in getattr(net, s_).state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------------- the reference's training loop
+@pytest.mark.parametrize("reg", ["Rec", "None"])
+def test_reference_train_loop_on_update_auto_records_bit_identically(S, reg):
+    """/root/reference/train.py:212-217 verbatim: ``net.set_input(*batch); net.update()`` with a NEW batch every iteration.
+    ``update()`` runs two steps eagerly, records the third (the recording does not advance the model) and replays from then
+    on; a validation pass (``eval(); set_input; test(); train()``) in between, a learning-rate change and a change of the loss
+    weight (which drops the recording) are followed.  Parameters, BatchNorm buffers, the reconstruction and the scalar losses
+    are BIT-identical to the same loop with auto-recording switched off."""
+    n, c, h, w = 2, 3, 48, 80
+    batches = [tuple(g(t) for t in S.synth.phantom_pair(n, c, h, w, seed=100 + i)) for i in range(8)]
+
+    def loop(auto):
+        net = _model(S, w, c, reg=reg)
+        net.auto_record = auto
+        modes, vis = [], None
+        for it, batch in enumerate(batches):
+            net.train()
+            net.set_input(*batch)
+            net.update()
+            modes.append(net.step_mode)
+            if it == 3:                                 # validation in between (eval.py / train.py:240-260)
+                net.eval()
+                net.set_input(*batches[0])
+                psnr = net.test()
+                vis = (psnr, net.img_rec.detach().clone())
+            if it == 4:
+                for o in (net.optim_R, net.optim_T):
+                    o.param_groups[0]["lr"] = 3e-5
+            if it == 5:
+                net.cfg.weight_smooth = 500.0           # part of the recording's key: back to eager, re-recorded two steps later
+        torch.cuda.synchronize()
+        scal = net.get_vis("scalars")["scalars"]
+        return net, modes, vis, scal
+
+    ref, modes_e, vis_e, scal_e = loop(False)
+    net, modes_a, vis_a, scal_a = loop(True)
+    assert all(m == "eager" for m in modes_e)
+    assert modes_a[0] == modes_a[1] == "eager" and all(m.startswith("replay") for m in modes_a[2:6]), modes_a
+    assert modes_a[6] == "eager" and modes_a[7] == "eager", modes_a        # the new key has seen two steps only
+    want, got = _state(ref), _state(net)
+    bad = [k for k in want if not torch.equal(want[k], got[k])]
+    assert not bad, bad[:5]
+    assert torch.equal(ref.img_rec, net.img_rec) and torch.equal(ref.img_warped, net.img_warped)
+    assert vis_e[0] == vis_a[0] and torch.equal(vis_e[1], vis_a[1])        # the eager validation pass saw the replayed weights
+    assert scal_e == scal_a, (scal_e, scal_a)
+    assert net.optim_R.steps_taken() == len(batches)
+
+
+def test_replay_checks_return_codes(S):
+    """A recorded C-ABI call that fails inside a replay raises (RecordedStep.replay dropped every return code)."""
+    n, c, h, w = 1, 1, 32, 32
+    net = _model(S, w, c, chans=4).train()
+    xf, xa = (g(t) for t in S.synth.phantom_pair(n, c, h, w, seed=3))
+    step = net.record_update(xf, xa, warmup=1)
+    step.replay()
+    torch.cuda.synchronize()
+    # corrupt one recorded call: a null pointer makes the entry point return SAN_E_ARG
+    idx = next(i for i, (fn, args, kind) in enumerate(step.calls) if kind == 1 and getattr(fn, "__name__", "") == "san_norm_finalize")
+    fn, args, kind = step.calls[idx]
+    step.calls[idx] = (fn, (None,) + tuple(args[1:]), kind)
+    with pytest.raises(RuntimeError, match="san_norm_finalize failed"):
+        step.replay()
+    torch.cuda.synchronize()
+
+
+def test_recorded_forward_follows_weight_changes(S):
+    """a recorded forward pass re-packs its weight images when the weights changed since its last replay
+    (optimiser step, load_state_dict), and an eager forward after training replays sees the new weights."""
+    n, c, h, w = 2, 1, 64, 64
+    net = _model(S, w, c).eval()
+    xf, xa = (g(t) for t in S.synth.phantom_pair(n, c, h, w, seed=40))
+    rec = net.record_forward(xf, xa)
+    out_rec = net.img_rec                               # the recording's output tensor: every replay refreshes it in place
+    rec.replay()
+    torch.cuda.synchronize()
+    first = out_rec.detach().clone()
+    # a training step changes every weight (and re-points net.img_* at its own tensors)
+    net.train()
+    net.set_input(xf, xa)
+    net.update()
+    net.eval()
+    rec.replay()
+    torch.cuda.synchronize()
+    got = out_rec.detach().clone()
+    with torch.no_grad():
+        net.set_input(xf, xa)
+        net.loss_all = 0
+        net.forwardT()
+        net.forwardR()
+    torch.cuda.synchronize()
+    assert not torch.equal(first, got), "the step did not change the reconstruction"
+    assert torch.equal(got, net.img_rec), "the replayed forward pass ran on stale packed weights"
+    # recorded TRAINING replays followed by an eager forward pass
+    net.train()
+    step = net.record_update(xf, xa, warmup=1)
+    with torch.no_grad():                               # an eager pass brings the pack registries up to date ...
+        net.eval()
+        net.set_input(xf, xa)
+        net.loss_all = 0
+        net.forwardT()
+        net.forwardR()
+    for _ in range(2):                                  # ... then the weights move under replays
+        step.replay()
+    torch.cuda.synchronize()
+    ref = _model(S, w, c).eval()
+    for s_ in ("net_T", "net_R"):
+        getattr(ref, s_).load_state_dict(getattr(net, s_).state_dict())
+    with torch.no_grad():
+        for m in (net, ref):
+            m.eval()
+            m.set_input(xf, xa)
+            m.loss_all = 0
+            m.forwardT()
+            m.forwardR()
+    torch.cuda.synchronize()
+    assert torch.equal(net.img_rec, ref.img_rec), "the eager pass after replays ran on stale packed weights"
+
+
+# ------------------------------------------------------------------------------------------- stream convolution
+def _conv_ref64(x, sc, sh, slope, wt, bias):
+    a = x.double() * sc.double()[:, :, None, None] + sh.double()[:, :, None, None]
+    a = torch.where(a >= 0, a, a * slope)
+    return torch.nn.functional.conv2d(a, wt.double(), None if bias is None else bias.double(), padding=1)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,bias", [(18, 18, 160, 192, False), (36, 18, 160, 160, False), (18, 36, 160, 160, False),
+                                               (36, 36, 168, 160, True), (72, 36, 160, 160, False), (96, 32, 160, 160, True),
+                                               (20, 16, 160, 160, False), (48, 48, 160, 160, False)])
+def test_stream_convolution_vs_float64_and_tile_kernel(S, cin, cout, h, w, bias):
+    """conv3x3_stream_kernel (persistent workgroups; csrc/san_conv_stream.hip) on every template form, one to four 24-channel
+    chunks, partial last chunks, a channel view with offset, bias, statistics: <= 3e-6 relative L2 of float64 (measured
+    3.5-4.5e-7), statistics records that merge to the plane's mean / variance, and the same layer on the one-tile kernel
+    (SAN_CONV_STREAM off via the tuning hook) within 1e-6 of it."""
+    ops = S.ops
+    n = 3
+    assert S.lib.lib().query("san_conv_stream_eligible", n, h, w, cin, cout, cin + 3) == 1
+    xb = g(philox("st.x", (n, cin + 3, h, w)))
+    wt = g(philox("st.w", (cout, cin, 3, 3))) * 0.1
+    bs = g(philox("st.b", (cout,))) if bias else None
+    sc, sh = g(philox("st.sc", (n, cin + 3), lo=0.5, hi=1.5)), g(philox("st.sh", (n, cin + 3)))
+    xa = ops.Act(xb, 2, cin, sc, sh, 0.2)
+    yb = torch.full((n, cout + 2, h, w), 7.0, device=DEV)
+    part = ops.conv2d(xa, wt, bs, ops.Act(yb, 1, cout), stats=True)
+    torch.cuda.synchronize()
+    want = _conv_ref64(xb[:, 2:2 + cin], sc[:, 2:2 + cin], sh[:, 2:2 + cin], 0.2, wt, bs)
+    got = yb[:, 1:1 + cout]
+    err = ((got.double() - want).norm() / want.norm()).item()
+    assert err < 3e-6, err
+    assert torch.all(yb[:, 0] == 7.0) and torch.all(yb[:, -1] == 7.0), "wrote outside its channel view"
+    cnt, mean, m2 = part[..., 0].double(), part[..., 1].double(), part[..., 2].double()
+    tot = cnt.sum(-1)
+    mu = (cnt * mean).sum(-1) / tot
+    var = (m2 + cnt * (mean - mu[..., None]) ** 2).sum(-1) / tot
+    assert torch.all(tot == h * w)
+    assert (mu - got.double().mean((2, 3))).abs().max().item() < 1e-6
+    assert ((var - got.double().var((2, 3), unbiased=False)).abs() / got.double().var((2, 3), unbiased=False)).max().item() < 1e-5
+    # the same layer on the one-tile-per-workgroup kernel
+    S.lib.lib().call("san_conv_stream_set_tuning", 0)
+    try:
+        y2 = torch.full((n, cout + 2, h, w), 7.0, device=DEV)
+        ops.conv2d(xa, wt, bs, ops.Act(y2, 1, cout), stats=True)
+        torch.cuda.synchronize()
+    finally:
+        S.lib.lib().call("san_conv_stream_set_tuning", 1)
+    assert ((got.double() - y2[:, 1:1 + cout].double()).norm() / want.norm()).item() < 1e-6
+
+
+def test_stream_data_gradient_with_amax_scale(S):
+    """The stream kernel as the data gradient of a 3x3 convolution: dy of magnitude 1e-7 scaled by its recorded power of two
+    (two fp16 parts), no input affine; <= 3e-6 of float64 (measured 3.8e-7)."""
+    ops = S.ops
+    n, cin, cout, h, w = 2, 36, 18, 160, 160
+    wt = g(philox("sd.w", (cout, cin, 3, 3))) * 0.1
+    gy = g(philox("sd.g", (n, cout, h, w))) * 1e-7
+    ga = ops.full(gy)
+    if ops.F16_BWD[0]:
+        ga.amax = ops.amax_record(gy.abs().max())
+    dx = torch.full((n, cin, h, w), float("nan"), device=DEV)
+    ops.conv2d_dgrad(ga, wt, ops.full(dx))
+    torch.cuda.synchronize()
+    want = torch.nn.functional.conv_transpose2d(gy.double(), wt.double(), padding=1)
+    assert ((dx.double() - want).norm() / want.norm()).item() < 3e-6
+
+
+def test_stream_convolution_repeated_launches_are_deterministic(S):
+    """200 launches of the persistent kernel on the same data: bit-identical outputs and statistics (and no hang: an early build
+    with register spills stalled intermittently at three workgroups per CU)."""
+    ops = S.ops
+    n, cin, cout, h, w = 8, 18, 18, 320, 320
+    xb, wt = g(philox("sr.x", (n, cin, h, w))), g(philox("sr.w", (cout, cin, 3, 3))) * 0.1
+    sc, sh = g(philox("sr.sc", (n, cin), lo=0.5, hi=1.5)), g(philox("sr.sh", (n, cin)))
+    xa = ops.Act(xb, 0, cin, sc, sh, 0.2)
+    y0 = torch.empty((n, cout, h, w), device=DEV)
+    p0 = ops.conv2d(xa, wt, None, ops.full(y0), stats=True).clone()
+    y1 = torch.empty_like(y0)
+    for _ in range(200):
+        p1 = ops.conv2d(xa, wt, None, ops.full(y1), stats=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
