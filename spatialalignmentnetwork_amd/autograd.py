@@ -148,12 +148,13 @@ class _SmoothPoolFn(Function):
     @staticmethod
     def forward(ctx, x, kern):
         ctx.save_for_backward(kern)
+        ctx.in_hw = (int(x.shape[2]), int(x.shape[3]))      # odd sizes: avg_pool2d drops the last row / column
         return ops.smooth_pool(_c(x), kern)
 
     @staticmethod
     def backward(ctx, g):
         (kern,) = ctx.saved_tensors
-        return ops.smooth_pool_bwd(_c(g), kern), None
+        return ops.smooth_pool_bwd(_c(g), kern, in_hw=ctx.in_hw), None
 
 
 def smooth_pool(x: torch.Tensor, kern: torch.Tensor) -> torch.Tensor:
@@ -243,14 +244,31 @@ class _VarNetFn(Function):
         return (None, None, None, g_ref if want_ref else None, None) + (None,) * ctx.nparams
 
 
+# Bumped whenever ANY module registers a parameter or a submodule (torch's global registration hooks): the memoised parameter
+# lists below are rebuilt then, so a replaced Parameter or a swapped submodule is noticed without walking the module tree on
+# every forward.
+_PARAM_EPOCH = [0]
+
+
+def _bump_param_epoch(*_a, **_k):
+    _PARAM_EPOCH[0] += 1
+
+
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_param_epoch)
+torch.nn.modules.module.register_module_module_registration_hook(_bump_param_epoch)
+
+
 def _trainable(mod):
     """The module's parameters that require gradients (memoised: walking 300-odd parameters per forward was 2 ms of host
-    time per training step; the key notices requires_grad_() / parameter replacement through the list's identity set)."""
+    time per training step).  The parameter list is rebuilt when a parameter / submodule was registered anywhere since
+    (_PARAM_EPOCH), the selection when a requires_grad flag changed."""
     hit = mod.__dict__.get("_san_trainable")
     plist = mod.__dict__.get("_san_plist")
-    if plist is None:
-        plist = list(mod.parameters())
+    if plist is None or plist[0] != _PARAM_EPOCH[0]:
+        plist = (_PARAM_EPOCH[0], list(mod.parameters()))
         object.__setattr__(mod, "_san_plist", plist)
+        hit = None
+    plist = plist[1]
     flags = tuple(p.requires_grad for p in plist)
     if hit is None or hit[0] != flags:
         hit = (flags, tuple(p for p in plist if p.requires_grad))

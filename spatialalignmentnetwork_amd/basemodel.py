@@ -53,6 +53,13 @@ class Config(object):
                 setattr(self, k, v)
 
 
+class _LegacyConfig(Config):
+    """``basemodel.Config`` as the reference's torch-pickled checkpoints name it (allow-listed for the safe loader)."""
+
+
+_LegacyConfig.__module__, _LegacyConfig.__name__, _LegacyConfig.__qualname__ = "basemodel", "Config", "Config"
+
+
 def ckpt_save(ckpt: dict, folder: str) -> None:
     """basemodel.py:43-55."""
     assert isinstance(ckpt, dict)
@@ -72,15 +79,16 @@ def _torch_load(path: str):
     unpickler (weights_only=True); a pickled ``Config`` object is allow-listed for it.  Anything else the safe loader
     rejects is NOT retried with the full unpickler (which executes code from the file) unless the caller opts in with
     SAN_TRUST_CHECKPOINTS=1 -- and then with a warning that names the first error."""
-    import pickle
     import warnings
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except pickle.UnpicklingError as first:
+    except Exception as first:                  # (pickle.UnpicklingError for a refused global; other loader errors take the same road)
         try:
-            with torch.serialization.safe_globals([Config]):
+            # the reference pickles its Config under the global 'basemodel.Config' (basemodel.py:57): a subclass that carries
+            # that module / name is allow-listed next to this package's own, so the safe loader builds it
+            with torch.serialization.safe_globals([Config, _LegacyConfig]):
                 return torch.load(path, map_location="cpu", weights_only=True)
-        except pickle.UnpicklingError:
+        except Exception:
             pass
         if os.environ.get("SAN_TRUST_CHECKPOINTS", "0") != "1":
             raise RuntimeError(f"{path}: the safe loader refused this checkpoint ({first}); set SAN_TRUST_CHECKPOINTS=1 to "

@@ -226,7 +226,9 @@ int san_lncc_loss_bwd(const float* i, const float* j, float* gi, float* gj, floa
 int san_smooth_pool_bwd(const float* gy, const float* kern, float* gx, int accumulate, int planes, int h, int w, int ksize,
                         void* stream) {
     SAN_CHECK_ARG(gy && kern && gx, "null pointer");
-    SAN_CHECK_ARG(planes > 0 && h >= 2 && w >= 2 && (h % 2 == 0) && (w % 2 == 0), "h, w must be even");
+    // (h, w) = the INPUT's size; odd sizes are fine: avg_pool2d drops the last row / column, whose smoothed values get no
+    // gradient while the input pixels there still feed their neighbours' smoothed values
+    SAN_CHECK_ARG(planes > 0 && h >= 2 && w >= 2, "h, w must be at least 2");
     if (ksize != 13) {
         san_set_error("smoothing kernel size %d unsupported (only 13 = sigma 3)", ksize);
         return SAN_E_UNSUPPORTED;

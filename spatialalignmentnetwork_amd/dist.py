@@ -60,8 +60,19 @@ def init(backend: str, device=None, allow_fallback: bool = False):
     return dist
 
 
+def backend() -> str:
+    """The backend in use: what init() recorded, else what a process group initialised directly through torch.distributed
+    (the reference's workflow) reports."""
+    if BACKEND is not None:
+        return BACKEND
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return str(dist.get_backend())
+    return None
+
+
 def _scalar_device(device):
-    return device if BACKEND == "nccl" else "cpu"
+    return device if backend() == "nccl" else "cpu"
 
 
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -104,7 +115,7 @@ def broadcast0(t: torch.Tensor, dist) -> None:
     src = t
     if t.dtype == torch.bool:
         src = t.to(torch.uint8)
-    if src.is_cuda and BACKEND == "gloo":
+    if src.is_cuda and backend() == "gloo":
         host = src.cpu()
         dist.broadcast(host, src=0)
         src = host.to(t.device)
@@ -118,8 +129,8 @@ def broadcast0(t: torch.Tensor, dist) -> None:
 
 class GradBucket:
     """One flat fp32 gradient buffer for a set of parameters; every ``p.grad`` is a view into it, so
-    the data-parallel exchange is a single in-place all-reduce with no packing copies.  (Bucketing
-    per cascade to overlap the exchange with the rest of the backward pass is the next step.)"""
+    the data-parallel exchange needs no packing copies: the whole buffer in one in-place all-reduce, or -- ``range_of`` --
+    contiguous slices of it (one per cascade, in reverse order, as their gradients become final: GradExchange.launch)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
@@ -138,16 +149,30 @@ class GradBucket:
         from . import _lib
         _lib.rec(self.flat.zero_)
 
-    def allreduce_sum(self, dist) -> None:
-        """Sum the gradients over all ranks in place (the optimiser kernel applies the 1/world factor)."""
+    def range_of(self, params):
+        """[lo, hi) of the flat buffer that holds the gradients of ``params`` (they must be consecutive in this bucket's
+        order, as the parameters of one submodule are); None if none of them is in the bucket."""
+        ids = {id(p) for p in params}
+        idx = [i for i, p in enumerate(self.params) if id(p) in ids]
+        if not idx:
+            return None
+        if idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError("the parameters are not consecutive in the bucket")
+        last = idx[-1]
+        return self.offsets[idx[0]], self.offsets[last] + ((self.params[last].numel() + 3) & ~3)
+
+    def allreduce_sum(self, dist, rng=None) -> None:
+        """Sum the gradients over all ranks in place (the optimiser kernel applies the 1/world factor); rng = (lo, hi):
+        that slice of the flat buffer only."""
         if dist is None:
             return
-        if self.flat.is_cuda and BACKEND == "gloo":      # RCCL unavailable: stage through the host
-            host = self.flat.cpu()
+        flat = self.flat if rng is None else self.flat[rng[0]:rng[1]]
+        if flat.is_cuda and backend() == "gloo":      # RCCL unavailable: stage through the host
+            host = flat.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            self.flat.copy_(host)
+            flat.copy_(host)
         else:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
     def allreduce_mean(self, dist) -> None:
         """Average the gradients over all ranks (sum, then divide by the world size)."""
@@ -160,10 +185,11 @@ class GradBucket:
 class GradExchange:
     """The data-parallel gradient exchange of one training step, off the main stream.
 
-    ``launch(bucket, after)`` starts the summing all-reduce of a flat gradient buffer on a communication stream as soon
-    as its producers are done (the main stream up to the call + the streams in ``after``, i.e. the weight-gradient side
-    stream); ``wait()`` joins everything back into the main stream in front of the optimiser.  net_R's 119.8 MB go out
-    right after ``VarNet.backward`` returns and hide behind the alignment network's backward; net_T's 2.9 MB follow.
+    ``launch(bucket, after, rng)`` starts the summing all-reduce of a flat gradient buffer -- or of the slice ``rng`` of it --
+    on a communication stream as soon as its producers are done (the main stream up to the call + the streams in ``after``,
+    i.e. the weight-gradient side stream); ``wait()`` joins everything back into the main stream in front of the optimiser.
+    net_R's 119.8 MB go out cascade by cascade in reverse order (~9.8 MB each) from inside ``VarNet.backward``
+    and hide behind the remaining cascades' backward; the sensitivity net's slice and net_T's 2.9 MB follow.
     RCCL collectives are stream-ordered, so both calls are capturable into a hipGraph.  With gloo (CPU tests, debugging)
     the buffer is staged through the host synchronously -- same call sites, no overlap."""
 
@@ -172,6 +198,7 @@ class GradExchange:
     def __init__(self, dist, timed: bool = False):
         self.dist = dist
         self.works = []
+        self.launched = []              # the slices (None = a whole buffer) in launch order
         self.timed = timed
         self.events = []
         self.comm = None
@@ -182,18 +209,19 @@ class GradExchange:
             GradExchange._streams[key] = torch.cuda.Stream(device=device)
         return GradExchange._streams[key]
 
-    def launch(self, bucket: "GradBucket", after=()) -> None:
+    def launch(self, bucket: "GradBucket", after=(), rng=None) -> None:
         if self.dist is None:
             return
-        flat = bucket.flat
+        flat = bucket.flat if rng is None else bucket.flat[rng[0]:rng[1]]
+        self.launched.append(rng)
         from . import _lib
-        if not flat.is_cuda or BACKEND == "gloo":
+        if not flat.is_cuda or backend() == "gloo":
             if flat.is_cuda:
                 cur = torch.cuda.current_stream()
                 for s in after:
                     if s is not None:
                         _lib.rec(cur.wait_stream, s)
-            _lib.rec(bucket.allreduce_sum, self.dist)
+            _lib.rec(bucket.allreduce_sum, self.dist, rng)
             return
         cur = torch.cuda.current_stream()
         comm = self.comm = self._comm(flat.device)

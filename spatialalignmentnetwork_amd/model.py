@@ -38,6 +38,9 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
 # on, so that the reference's own training loop (train.py:212-217: ``net.set_input(*batch); net.update()``) runs at the
 # recorded step's speed.  SAN_AUTO_RECORD=0 or cfg.auto_record = False: always eager.
 AUTO_RECORD = [os.environ.get("SAN_AUTO_RECORD", "1") != "0"]
+# Data-parallel gradient exchange of net_R: "cascade" (default) = one all-reduce per cascade in reverse order, launched from
+# inside VarNet.backward as each cascade's gradients become final; "single" = the whole flat buffer afterwards.
+GRAD_BUCKETS = [os.environ.get("SAN_GRAD_BUCKETS", "cascade")]
 AUTO_AFTER = 2
 
 
@@ -168,9 +171,25 @@ class CSModel(BaseModel):
 
     def _backward(self, train_T: bool) -> None:
         g_rec = ops.ssim_loss_bwd(self.img_full_rss, self.img_rec, float(self.cfg.weight_sim))
-        g_warped = self.net_R.backward(g_rec, want_ref_grad=train_T)
         exch = getattr(self, "_exchange", None)
-        if exch is not None:
+        per_cascade = exch is not None and GRAD_BUCKETS[0] == "cascade"
+        if per_cascade:
+            bucket = self.optim_R.bucket()
+            ranges = self._cascade_ranges(bucket)
+
+            def hook(which):
+                # cascade `which` (or the sensitivity net) has its gradients: its deferred weight-gradient reductions are
+                # flushed on the side stream and its slice of the flat buffer goes out on the communication stream
+                if ranges.get(which) is not None:
+                    ops.wgrad_flush()
+                    exch.launch(bucket, after=(ops._WG["stream"],), rng=ranges[which])
+
+            self.net_R._grad_hook = hook
+        try:
+            g_warped = self.net_R.backward(g_rec, want_ref_grad=train_T)
+        finally:
+            self.net_R._grad_hook = None
+        if exch is not None and not per_cascade:
             # net_R's gradients are final (its deferred weight-gradient reductions are flushed here): their all-reduce
             # starts now, on the communication stream, and hides behind the alignment network's backward
             ops.wgrad_flush()
@@ -373,7 +392,7 @@ class CSModel(BaseModel):
             self.set_input(img_full, img_aux)
             self.update()
 
-        split = dist is not None and sdist.BACKEND != "nccl"
+        split = dist is not None and sdist.backend() != "nccl"
         if not split:
             try:
                 return CapturedStep([_capture(_whole)], None, "single-graph" + (" (RCCL all-reduce captured)" if dist is not None else ""))
@@ -560,6 +579,18 @@ class CSModel(BaseModel):
         _KEEP_CACHE.clear()
         self._replicas_synced = True
 
+    def _cascade_ranges(self, bucket):
+        """{cascade index | "sens": (lo, hi) of net_R's flat gradient buffer}; together they cover the whole buffer."""
+        ranges = {j: bucket.range_of(list(c.parameters())) for j, c in enumerate(self.net_R.cascades)}
+        ranges["sens"] = bucket.range_of(list(self.net_R.sens_net.parameters()))
+        covered = sorted(r for r in ranges.values() if r is not None)
+        pos = 0
+        for lo, hi in covered:
+            assert lo == pos, "net_R's parameters are not partitioned by (sens_net, cascades)"
+            pos = hi
+        assert pos == bucket.total, (pos, bucket.total)
+        return ranges
+
     def _grad_buckets(self):
         """Flat per-network buffers (p.data / p.grad are views, see dist.ParamBucket)."""
         return {"R": self.optim_R.bucket(), "T": self.optim_T.bucket()}
@@ -611,13 +642,33 @@ class RecordedStep:
     its weight images (the optimiser's own bump is host code and not part of the recording).  Forward-only recordings
     contain the batched weight-packing launches and run them only when the weights changed since their last replay."""
 
+    # Optional run-ahead throttle (SAN_REPLAY_CHUNK > 0; default off): every CHUNK calls the replay records a blocking event
+    # (hipEventBlockingSync) and, before going on, sleeps on the one recorded LAG chunks earlier, so that at most LAG * CHUNK calls
+    # are ever queued.  Built to test whether the ~1.8 busy host cores per rank of a replayed step (host_cpu_ms ~ 84 per 46 ms
+    # step) are the runtime spinning on a full launch queue: they are NOT -- 128..1024 x 2..3 calls in flight leave
+    # host_cpu_ms at 80-88 and the step time unchanged (scratch/attempts/r4_host_depth.txt); the second busy thread is the
+    # runtime's own.  Kept as a hook for boxes with fewer cores than 2 per rank.
+    CHUNK = int(os.environ.get("SAN_REPLAY_CHUNK", "0"))
+    LAG = int(os.environ.get("SAN_REPLAY_LAG", "3"))
+
     def __init__(self, calls, keep, training: bool = True):
         self.calls, self.keep, self.training = calls, keep, training
         self.mode = f"recorded step: {len(calls)} calls"
         self._packed_epoch = None
+        self._ring, self._k = [], 0
+
+    def _throttle(self) -> None:
+        if not self._ring:
+            self._ring = [torch.cuda.Event(blocking=True) for _ in range(self.LAG + 1)]
+        ring, k = self._ring, self._k
+        ring[k % len(ring)].record()
+        if k >= self.LAG:
+            ring[(k - self.LAG) % len(ring)].synchronize()      # the host sleeps until the GPU is within LAG chunks
+        self._k = k + 1
 
     def replay(self) -> None:
         skip_packs = (not self.training) and self._packed_epoch == ops.WEIGHT_EPOCH[0]
+        chunk, left = self.CHUNK, self.CHUNK
         for fn, args, kind in self.calls:
             if kind:
                 if kind == 2 and skip_packs:
@@ -626,6 +677,11 @@ class RecordedStep:
                 if rc:
                     raise RuntimeError(f"recorded step: {getattr(fn, '__name__', fn)} failed ({'argument error' if rc < 0 else 'hipError_t'} "
                                        f"{rc}): {_lib.lib().last_error()}")
+                if chunk:
+                    left -= 1
+                    if left == 0:
+                        left = chunk
+                        self._throttle()
             else:
                 fn(*args)
         if self.training:

@@ -1273,7 +1273,9 @@ class _EventRing:
         return ring[self.i]
 
 
-_EVENTS = _EventRing()
+_EVENTS = _EventRing()          # main-stream hand-off marks ('e0': waited on by the side stream right away)
+_BUSY_EVENTS = _EventRing()     # side-stream completion marks: _WG['busy'] may hold one across many later hand-offs, so they come from
+                                # their own ring and can never be re-recorded as a main-stream mark
 
 
 def _on_side_stream(dy: Act, x: Act, fn) -> None:
@@ -1293,7 +1295,7 @@ def _on_side_stream(dy: Act, x: Act, fn) -> None:
         fn()
     finally:
         _STREAM_OVERRIDE[0] = None
-    ev = torch.cuda.Event() if (torch.cuda.is_current_stream_capturing() or _lib.REC is not None) else _EVENTS.next()
+    ev = torch.cuda.Event() if (torch.cuda.is_current_stream_capturing() or _lib.REC is not None) else _BUSY_EVENTS.next()
     _lib.rec(ev.record, side)
     dptr = dy.buf.data_ptr()
     _WG["busy"][dptr] = ev
@@ -1588,15 +1590,18 @@ def lncc_loss_bwd(i: torch.Tensor, j: torch.Tensor, want_i: bool = True, want_j:
     return gi, gj
 
 
-def smooth_pool_bwd(gy: torch.Tensor, kern: torch.Tensor, gx: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Adjoint of smooth_pool: gx [N,1,2h,2w] (accumulated into when given)."""
+def smooth_pool_bwd(gy: torch.Tensor, kern: torch.Tensor, gx: Optional[torch.Tensor] = None, in_hw=None) -> torch.Tensor:
+    """Adjoint of smooth_pool: gx [N,1,H,W] (accumulated into when given).  in_hw = the forward input's (H, W) -- needed for
+    odd sizes, where avg_pool2d dropped the last row / column (default: 2 x the gradient's size)."""
     _chk(gy, name="gy")
     _chk(kern, name="kern")
     n, c, oh, ow = gy.shape
     acc = gx is not None
+    h, w = (int(gx.shape[2]), int(gx.shape[3])) if gx is not None else (in_hw if in_hw is not None else (2 * oh, 2 * ow))
+    assert h // 2 == oh and w // 2 == ow, (h, w, oh, ow)
     if gx is None:
-        gx = torch.empty((n, c, 2 * oh, 2 * ow), device=gy.device, dtype=torch.float32)
-    lib().call("san_smooth_pool_bwd", _p(gy), _p(kern), _p(_chk(gx, name="gx")), int(acc), n * c, 2 * oh, 2 * ow,
+        gx = torch.empty((n, c, h, w), device=gy.device, dtype=torch.float32)
+    lib().call("san_smooth_pool_bwd", _p(gy), _p(kern), _p(_chk(gx, name="gx")), int(acc), n * c, h, w,
                int(kern.shape[-1]), _stream())
     return gx
 

@@ -695,14 +695,19 @@ class VarNet(nn.Module):
         g_sens = torch.empty_like(x_last)
         ops._lib.rec(g_sens.zero_)
         g_ref1 = None
-        for cascade in reversed(self.cascades):
+        hook = getattr(self, "_grad_hook", None)         # data-parallel training: called as each part's gradients become final
+        for j in reversed(range(len(self.cascades))):
             # (the first cascade visited creates dL/d ref, the others add to it inside their activation-backward kernel)
-            g_x, g_ref = cascade.run_bwd_img(g_x, g_sens, want_ref_grad and self.use_ref, g_ref1)
+            g_x, g_ref = self.cascades[j].run_bwd_img(g_x, g_sens, want_ref_grad and self.use_ref, g_ref1)
             if g_ref is not None:
                 g_ref1 = g_ref
+            if hook is not None:
+                hook(j)                                  # cascade j's weight and dc_weight gradients are complete
         # x_0 = ifft2(k0) and m_0 depend on the sensitivity maps only through m_0 = sum_c conj(S_c) x_0, which
         # run_bwd_img of cascade 0 has already accounted for; k0 itself needs no gradient
         self.sens_net.backward(g_sens)
+        if hook is not None:
+            hook("sens")
         if g_ref1 is None:
             return None
         return ops.rss_bwd(ref, ref1, g_ref1)            # through ref = rss(ref)

@@ -235,3 +235,51 @@ def test_broadcast0_world2():
     for r in range(2):
         t, b, nc = out[r]
         assert torch.equal(t, want_t) and torch.equal(b, torch.tensor([True, True, False])) and torch.equal(nc, want_nc)
+
+
+def _cascade_bucket_worker(rank, world, port, out):
+    """Per-cascade reverse-order gradient exchange against the single-buffer form, on the real VarNet
+    parameter layout: the slices partition the flat buffer, go out in the order (cascade T-1 .. 0, sens) and leave the
+    same bits behind as one all-reduce of the whole buffer."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = sdist.init("gloo")
+    import types
+    from spatialalignmentnetwork_amd.model import CSModel
+    from spatialalignmentnetwork_amd.varnet import VarNet
+    torch.manual_seed(0)
+    net_R = VarNet(num_cascades=3, sens_chans=2, sens_pools=1, chans=4, pools=1, use_ref=True)
+    bucket = sdist.ParamBucket(net_R.parameters())
+    ranges = CSModel._cascade_ranges(types.SimpleNamespace(net_R=net_R), bucket)
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = torch.randn(bucket.total, generator=g)
+    # (a) per cascade, in the order VarNet.backward visits them
+    bucket.flat.copy_(grads)
+    exch = sdist.GradExchange(d)
+    for which in [2, 1, 0, "sens"]:
+        exch.launch(bucket, rng=ranges[which])
+    exch.wait()
+    per_cascade = bucket.flat.clone()
+    # (b) the whole buffer at once
+    bucket.flat.copy_(grads)
+    exch1 = sdist.GradExchange(d)
+    exch1.launch(bucket)
+    exch1.wait()
+    out[rank] = (per_cascade, bucket.flat.clone(), list(exch.launched), ranges, bucket.total)
+    d.destroy_process_group()
+
+
+def test_per_cascade_buckets_match_the_single_buffer_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_cascade_bucket_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for r in range(world):
+        per_cascade, single, launched, ranges, total = out[r]
+        assert torch.equal(per_cascade, single)
+        assert launched == [ranges[2], ranges[1], ranges[0], ranges["sens"]]
+        spans = sorted(launched)
+        assert spans[0][0] == 0 and spans[-1][1] == total and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        # the sensitivity net comes first in parameter order, the cascades follow in order
+        assert ranges["sens"][0] == 0 and ranges[0][0] == ranges["sens"][1] and ranges[2][1] == total
+    assert torch.equal(out[0][0], out[1][0])
