@@ -291,7 +291,28 @@ def make_metrics():
         out[f"{tag}.mae"] = np.float64(R_met.mae(gt, pred))
         out[f"{tag}.nmse"] = np.float64(R_met.nmse(gt, pred))
         out[f"{tag}.mi"] = np.float64(R_met.mi(gt, pred))
+        # metrics.py:40-43 calls skimage.metrics.structural_similarity(g[0], p[0], data_range=1) per slice and averages.  skimage
+        # is absent here; its ALGORITHM (Wang et al.: 7 x 7 scipy.ndimage.uniform_filter with reflecting borders, K1 = 0.01,
+        # K2 = 0.03, sample covariance, the 3-pixel border cropped, float64 mean) is restated below with the same scipy filter
+        # it is built on, so metric_SSIM is pinned to skimage's arithmetic rather than to this repository's own ssimloss
+        out[f"{tag}.ssim_skimage_algorithm"] = np.float64(np.mean([_ssim_skimage_algorithm(g_[0], p_[0], 1.0)
+                                                                   for g_, p_ in zip(gt.numpy(), pred.numpy())]))
     save("metrics.npz", **out)
+
+
+def _ssim_skimage_algorithm(im1, im2, data_range):
+    from scipy.ndimage import uniform_filter
+    win, K1, K2 = 7, 0.01, 0.03
+    im1, im2 = im1.astype(np.float64), im2.astype(np.float64)
+    NP = win ** 2
+    cov_norm = NP / (NP - 1)                       # use_sample_covariance=True
+    ux, uy = uniform_filter(im1, size=win), uniform_filter(im2, size=win)
+    uxx, uyy, uxy = uniform_filter(im1 * im1, size=win), uniform_filter(im2 * im2, size=win), uniform_filter(im1 * im2, size=win)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+    pad = (win - 1) // 2
+    return S[pad:-pad, pad:-pad].mean(dtype=np.float64)
 
 
 def make_ckpt():
@@ -691,6 +712,39 @@ def make_autograd():
     save("autograd_ops.npz", **out)
 
 
+def make_eval_n8():
+    """The bench batch in EVAL mode: N = 8 slices of 320 x 320, 12 cascades, chans 18 -- the reference's fp32
+    forward and its fp64 arbiter.  Kept small: two whole slices (0 and 5) of the reconstruction, and for every slice its sum,
+    L2 norm and 64 probed pixels, for both precisions; the warped image and the offsets as per-slice L2 norms."""
+    n, c, h, w = 8, 1, 320, 320
+    with torch.no_grad():
+        net_T, net_R, img_full, img_aux, pruned, res = run_pair(n, c, h, w, 0.25, 12, 18, 8, 4, seed=1234, training=False)
+        rec32 = res["img_rec"].detach()
+        net_T64, net_R64 = net_T.double(), net_R.double()
+        f64, a64 = img_full.to(torch.complex128), img_aux.to(torch.complex128)
+        k_samp = R_sig.fft2(f64) * (1 - pruned.double())
+        samp = R_sig.ifft2(k_samp)
+        off64, grid64 = net_T64(moving=a64.abs(), fixed=samp.abs())
+        warped64 = torch.nn.functional.grid_sample(a64.abs(), grid64, align_corners=False)     # (cross.py:33-34 casts to fp32)
+        rec64 = net_R64(masked_kspace=k_samp, mask=torch.logical_not(pruned), ref=warped64, num_low_frequencies=int(w * 0.25 * 0.32))
+    idx = probe_idx("eval_n8.probe", h * w, 64)
+    out = {"pruned": pruned.numpy(), "probe_idx": idx}
+    for tag, rec in (("f32", rec32.double()), ("f64", rec64)):
+        flat = rec.reshape(n, -1)
+        out[f"rec_{tag}.sum"] = flat.sum(1).numpy()
+        out[f"rec_{tag}.l2"] = flat.norm(dim=1).numpy()
+        out[f"rec_{tag}.probe"] = flat[:, torch.from_numpy(idx).long()].numpy()
+        for sl in (0, 5):
+            out[f"rec_{tag}.slice{sl}"] = rec[sl, 0].float().numpy()
+    out["warped_f32.l2"] = res["img_warped"].detach().double().reshape(n, -1).norm(dim=1).numpy()
+    out["warped_f64.l2"] = warped64.reshape(n, -1).norm(dim=1).numpy()
+    out["offset_f32.l2"] = res["img_offset"].detach().double().reshape(n, -1).norm(dim=1).numpy()
+    out["ref_f32_vs_f64_rel"] = np.float64(((rec32.double() - rec64).norm() / rec64.norm()).item())
+    out["ref_f32_vs_f64_rel_per_slice"] = ((rec32.double() - rec64).reshape(n, -1).norm(dim=1) / rec64.reshape(n, -1).norm(dim=1)).numpy()
+    print("eval N = 8: reference fp32 vs fp64 rel-L2:", out["ref_f32_vs_f64_rel"], out["ref_f32_vs_f64_rel_per_slice"])
+    save("eval_n8_320.npz", **out)
+
+
 def run_pair_full(n, c, h, w, sparsity, num_cascades, seed, training):
     """run_pair at the full network width (chans 18, sens_chans 8, 4 pooling levels)."""
     return run_pair(n, c, h, w, sparsity, num_cascades, 18, 8, 4, seed=seed, training=training)
@@ -698,7 +752,7 @@ def run_pair_full(n, c, h, w, sparsity, num_cascades, seed, training):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ops", "small", "full", "augment", "metrics", "ckpt", "layers", "pad", "scalars", "train_full",
-                             "multicoil", "autograd", "train_n8"]
+                             "multicoil", "autograd", "train_n8", "eval_n8"]
     with torch.no_grad():
         if "ops" in which:
             make_ops()
@@ -727,3 +781,5 @@ if __name__ == "__main__":
         make_autograd()
     if "train_n8" in which:
         make_train_n8()
+    if "eval_n8" in which:
+        make_eval_n8()

@@ -540,8 +540,10 @@ def test_multicoil_two_cascade_train_step_golden(S):
     for tag, mod in (("R", net.net_R), ("T", net.net_T)):
         wn, name, pe = _digest_errors(S, [(nm, p.grad) for nm, p in mod.named_parameters()], gold, f"train2.grad.{tag}.")
         print(f"multi-coil net_{tag}: worst per-tensor norm error {wn:.2e} ({name}), probe-estimated relative L2 {pe:.2e}")
-        # measured 1.5e-3 / 1.1e-3 (net_R), 2.6e-3 / 3.4e-3 (net_T: train-mode BatchNorm on one slice); bars ~4x
-        assert wn < 1e-2 and pe < 1.2e-2, (tag, wn, name, pe)
+        # measured 1.5e-3 / 1.1e-3 (net_R), 2.6e-3 / 3.4e-3 (net_T: train-mode BatchNorm on one slice); bars = 3x measured
+        # 
+        bar_wn, bar_pe = (4.5e-3, 3.5e-3) if tag == "R" else (8e-3, 1.0e-2)
+        assert wn < bar_wn and pe < bar_pe, (tag, wn, name, pe)
 
 
 # ------------------------------------------------------------------ data parallel (two ranks on one GPU)

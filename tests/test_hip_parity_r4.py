@@ -249,3 +249,115 @@ def test_stream_convolution_repeated_launches_are_deterministic(S):
         p1 = ops.conv2d(xa, wt, None, ops.full(y1), stats=True)
     torch.cuda.synchronize()
     assert torch.equal(y0, y1) and torch.equal(p0, p1)
+
+
+# ------------------------------------------------------------------------------------------- bench batch, eval mode
+def test_eval_bench_batch_n8_golden(S):
+    """the bench batch in EVAL mode -- N = 8 slices of 320 x 320, 12 cascades, chans 18 -- against the
+    reference's fp32 forward with its fp64 run as arbiter (tests/golden/eval_n8_320.npz, made by make_golden.py eval_n8).  Per
+    slice: within max(1e-4, 2 x the reference's own fp32-fp64 distance of that slice) of BOTH references (the reference itself
+    is 1.9e-4 from its fp64 on slice 2, 2.9-5.2e-5 elsewhere); whole slices 0 and 5, 64 probed pixels, sum and L2 of every slice."""
+    from conftest import load_golden, as_t
+    from spatialalignmentnetwork_amd import cross, varnet, signal_utils, ssimloss
+    gold = load_golden("eval_n8_320.npz")
+    n, c, h, w = 8, 1, 320, 320
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=1234)
+    pruned = as_t(gold["pruned"])
+    net_T = cross.SpatialTransformer(1)
+    net_R = varnet.VarNet(num_cascades=12, sens_chans=8, sens_pools=4, chans=18, pools=4, use_ref=True)
+    _fill(S, net_T, 1235)
+    _fill(S, net_R, 1236)
+    net_T.to(DEV).eval()
+    net_R.to(DEV).eval()
+    with torch.no_grad():
+        keep = (~pruned).float().to(DEV)
+        k_samp = S.ops.fft2c(g(img_full), colmask_out=keep)
+        samp = signal_utils.ifft2(k_samp)
+        aux_abs = S.ops.cabs(g(img_aux))
+        offset, grid = net_T(aux_abs, S.ops.cabs(samp))
+        warped = net_T.warp(aux_abs, grid)
+        rec = net_R(k_samp, (~pruned).to(DEV), warped, int(w * 0.25 * 0.32))
+    torch.cuda.synchronize()
+    rec = rec.cpu().double().reshape(n, -1)
+    idx = torch.from_numpy(gold["probe_idx"]).long()
+    floor = torch.from_numpy(gold["ref_f32_vs_f64_rel_per_slice"])
+    worst = 0.0
+    for tag in ("f32", "f64"):
+        l2 = torch.from_numpy(gold[f"rec_{tag}.l2"])
+        # whole slices
+        for sl in (0, 5):
+            want = torch.from_numpy(gold[f"rec_{tag}.slice{sl}"]).double().reshape(-1)
+            e = ((rec[sl] - want).norm() / want.norm()).item()
+            worst = max(worst, e)
+            assert e < max(1e-4, 2 * floor[sl].item()), (tag, sl, e)
+        # every slice: probes (relative to the slice's RMS), sum and L2
+        rms = l2 / (h * w) ** 0.5
+        probe = torch.from_numpy(gold[f"rec_{tag}.probe"])
+        bar = torch.clamp(2 * floor, min=1e-4)
+        perr = ((rec[:, idx] - probe).abs().max(1).values / rms)
+        assert torch.all(perr < 40 * bar), (tag, perr)            # a single pixel against the slice RMS: measured <= 6e-4
+        assert torch.all(((rec.norm(dim=1) - l2).abs() / l2) < bar), tag
+        assert torch.all(((rec.sum(1) - torch.from_numpy(gold[f"rec_{tag}.sum"])).abs() / (l2 * (h * w) ** 0.5)) < bar), tag
+    wl2 = torch.from_numpy(gold["warped_f32.l2"])
+    assert torch.all(((warped.cpu().double().reshape(n, -1).norm(dim=1) - wl2).abs() / wl2) < 3e-5)
+    print(f"eval N = 8: worst whole-slice rel-L2 vs the references {worst:.2e}")
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_metric_ssim_matches_the_skimage_algorithm(S, tag):
+    """metrics.py:40-43 averages skimage.metrics.structural_similarity(g[0], p[0], data_range=1) over the batch.  The fixture
+    value is skimage's algorithm restated on scipy.ndimage.uniform_filter (make_golden.py::_ssim_skimage_algorithm; skimage is
+    not in the image): metric_SSIM (= 1 - ssimloss on the device) must agree to 2e-5 (measured 3e-7)."""
+    from conftest import load_golden
+    from spatialalignmentnetwork_amd import metrics as M
+    gold = load_golden("metrics.npz")
+    gt, pred = torch.from_numpy(gold[f"{tag}.gt"]), torch.from_numpy(gold[f"{tag}.pred"])
+    want = float(gold[f"{tag}.ssim_skimage_algorithm"])
+    got = M.ssim(g(gt), g(pred))
+    assert abs(got - want) < 2e-5, (got, want)
+
+
+# ------------------------------------------------------------------------------------------- gradients on the SHIPPED kernels
+@pytest.mark.parametrize("tag,shape", [("32", (2, 1, 32, 32)), ("48x80c3", (2, 3, 48, 80))])
+def test_full_rec_step_gradients_elementwise_on_shipped_kernels(S, tag, shape):
+    """EVERY parameter gradient of a 'Rec' step, element-wise, against the reference's own gradients
+    (tests/golden/e2e_small_*.npz) with the SHIPPED kernel mix (fp16-part matrix-core convolutions, data and weight gradients,
+    weight gradients on the side stream) -- not the fp32 kernels the round-1 test switches to.  Bar per tensor: max-abs error
+    <= 3e-4 of the tensor's largest reference gradient; measured 1.4e-5 / 5.7e-5 (32 x 32: net_R / net_T) and 2.4e-5 / 5.2e-5
+    (48 x 80, 3 coils) -- no tensor needs to be skipped: the kink-dominated BatchNorm tensors that made round 1 switch kernels
+    (8e-4 on the fp32 path) land at 1e-5 here."""
+    from conftest import load_golden, as_t
+    gold = load_golden(f"e2e_small_{tag}.npz")
+    n, c, h, w = shape
+    cfg = S.base.Config(sparsity=0.25, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                        weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=2, chans=4,
+                        sens_chans=2, pools=2, sens_pools=2)
+    net = S.model.CSModel(cfg)
+    net.net_mask.pruned = S.synth.equispaced_pruned(w, 0.25, 0)
+    _fill(S, net.net_T, 41)
+    _fill(S, net.net_R, 42)
+    net.to(DEV).train()
+    assert S.ops.USE_BF16X3[0] and S.ops.current_precision() == "bf16x3"
+    img_full, img_aux = S.synth.phantom_pair(n, c, h, w, seed=40)
+    net.set_input(g(img_full), g(img_aux))
+    net.loss_all = 0
+    net.forwardT()
+    net.forwardR()
+    for o in (net.optim_R, net.optim_T):
+        o.zero_grad()
+    net.backward(train_T=True)
+    torch.cuda.synchronize()
+    for pre, mod in (("grad.R.", net.net_R), ("grad.T.", net.net_T)):
+        worst, worst_name = 0.0, ""
+        for name, prm in mod.named_parameters():
+            want = as_t(gold[pre + name])
+            scale = want.abs().max().item()
+            got = prm.grad.cpu() if prm.grad is not None else torch.zeros_like(want)
+            if scale < 1e-7:
+                assert got.abs().max().item() < 1e-5, name
+                continue
+            err = (got - want).abs().max().item() / scale
+            if err > worst:
+                worst, worst_name = err, name
+        print(f"{tag} {pre} shipped kernels: worst element-wise relative gradient error {worst:.2e} ({worst_name})")
+        assert worst < 3e-4, (pre, worst, worst_name)
