@@ -583,7 +583,7 @@ def main(argv=None):
             # HBM bytes per launch, algorithmic bytes and MFMA-busy fractions from the committed PMC passes of THIS workload
             # (separate rocprofv3 --pmc runs, corrected as the file states); bench.py itself cannot run the profiler
             pmc, pmc_file = {}, None
-            for cand in ("r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+            for cand in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
                     pmc_file = cand

@@ -28,8 +28,8 @@ f16 = 512 * MiB / (f_list[2] * 1024) if len(f_list) >= 4 else 2.0
 f8 = 512 * MiB / (max(rs["FETCH_SIZE_list"]) * 1024) if rs.get("FETCH_SIZE_list") else f16
 wf4 = 511.998 * MiB / (w_list[0] * 1024) if len(w_list) >= 4 else 1.0
 wf = 512 * MiB / (w_list[2] * 1024) if len(w_list) >= 4 else 1.0
-width = {"conv_mfma_3x3": f4, "conv_mfma_1x1": f4, "conv_bf16x3": f4, "conv_bf16x3_1x1": f4}
-wwidth = {"conv_mfma_3x3": wf4, "conv_mfma_1x1": wf4, "conv_bf16x3": wf4, "conv_bf16x3_1x1": wf4}
+width = {"conv_mfma_3x3": f4, "conv_mfma_1x1": f4, "conv_bf16x3": f4, "conv_bf16x3_1x1": f4, "conv_stream": f4}
+wwidth = {"conv_mfma_3x3": wf4, "conv_mfma_1x1": wf4, "conv_bf16x3": wf4, "conv_bf16x3_1x1": wf4}      # (the stream form stores 16 B per lane)
 kern = {}
 for k, v in raw.items():
     if k.startswith("cal_"):
@@ -48,7 +48,19 @@ for k, v in raw.items():
         e["mfma_counters_avg_per_launch"] = {c: v[c]["avg"] for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES",
                                                                       "GRBM_GUI_ACTIVE") if c in v}
     kern[k] = e
-alias = {"conv3x3": "conv_mfma_3x3", "conv3x3_bf16x3": "conv_bf16x3", "wgrad3x3_bf16x3": "wgrad_bf16x3", "wgrad3x3": "wgrad_vec_3x3"}
+# the bench's "conv3x3_bf16x3" family = the one-tile kernel + (round 4) the persistent stream kernel: launch-weighted merge
+if "conv_stream" in kern and "conv_bf16x3" in kern and "hbm_bytes_per_launch" in kern["conv_stream"]:
+    a_, b_ = kern["conv_bf16x3"], kern["conv_stream"]
+    la, lb = a_["launches"], b_["launches"]
+    m = {"launches": la + lb, "note": "one-tile kernel (conv_bf16x3) + persistent stream kernel (conv_stream), launch-weighted"}
+    for key in ("fetch_bytes_per_launch", "write_bytes_per_launch", "hbm_bytes_per_launch"):
+        m[key] = int((a_[key] * la + b_[key] * lb) / (la + lb))
+    if a_.get("mfma_busy") is not None and b_.get("mfma_busy") is not None:
+        ga, gb = a_["mfma_counters_avg_per_launch"]["GRBM_GUI_ACTIVE"] * la, b_["mfma_counters_avg_per_launch"]["GRBM_GUI_ACTIVE"] * lb
+        m["mfma_busy"] = (a_["mfma_busy"] * ga + b_["mfma_busy"] * gb) / (ga + gb)
+    kern["conv3x3_bf16x3_all"] = m
+alias = {"conv3x3": "conv_mfma_3x3", "conv3x3_bf16x3": "conv3x3_bf16x3_all" if "conv3x3_bf16x3_all" in kern else "conv_bf16x3",
+         "wgrad3x3_bf16x3": "wgrad_bf16x3", "wgrad3x3": "wgrad_vec_3x3"}
 for a, b in alias.items():
     if b in kern:
         kern[a] = dict(kern[b])

@@ -28,6 +28,8 @@ def family(k):
     return ('cal_apply' if 'apply_kernel' in k else 'cal_rss' if 'rss_kernel' in k and 'bwd' not in k else
             'conv_bf16x3_1x1' if 'conv_bf16x3_kernel' in k and (', true, 1, ' in k or ', false, 1, ' in k) else
             'conv_bf16x3' if 'conv_bf16x3_kernel' in k else
+            'conv_stream' if 'conv3x3_stream_kernel' in k else
+            'act_bwd' if ('act_bwd' in k or 'bwd_stats_kernel' in k) else
             'wgrad_bf16x3' if 'wgrad_bf16x3_direct_kernel' in k else
             'wgrad1x1_bf16x3' if 'wgrad1x1_bf16x3_kernel' in k else
             'conv_mfma_3x3' if 'conv_mfma_kernel' in k and ', 3, ' in k else
