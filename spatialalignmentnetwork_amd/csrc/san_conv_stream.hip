@@ -265,10 +265,13 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
     const int wl_rem = REM > 0 ? (nn < REM ? MBF * 1024 + (kg * REM + nn) * 16 : MBF * 1024 + REM * 64) : 0;
 
     f4 acc[MB][4];
+    float biasv[MB];                                    // this lane's channel of every block: fetched once, not once per tile
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MB; ++m) {
+        biasv[m] = (a.bias && 16 * m + nn < a.cout) ? a.bias[16 * m + nn] : 0.f;
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
+    }
 
     if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the resident weight image (and, once, the first prefetch)
     for (;;) {
@@ -377,12 +380,9 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
             }
             if (a.bias) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m) {
-                    const int co = 16 * m + nn;
-                    const float bv = co < a.cout ? a.bias[co] : 0.f;
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[m][b] += f4{bv, bv, bv, bv};
-                }
+                    for (int b = 0; b < 4; ++b) acc[m][b] += f4{biasv[m], biasv[m], biasv[m], biasv[m]};
             }
             if (a.part && !(a.abl & 8)) {
                 const int tiles = ntile * 4;

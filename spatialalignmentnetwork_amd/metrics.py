@@ -52,3 +52,18 @@ def all_metrics(gt, pred) -> dict:
     m = (s[:, 0].sum() / gt.numel()).item()
     return {"MSE": m, "MAE": (s[:, 1].sum() / gt.numel()).item(),
             "PSNR": 10.0 * math.log10(1.0 / m) if m > 0 else float("inf"), "MI": s[:, 3].mean().item()}
+
+
+def test_metrics(gt, pred, warped) -> dict:
+    """Every scalar CSModel.test() reports (model.py:275-279) from ONE host synchronisation: the sums of (gt, pred), the
+    mutual information of (gt, warped) and the SSIM loss of (gt, pred) are computed on the device and cross the bus together."""
+    assert gt.shape == pred.shape == warped.shape and gt.dim() == 4, "wrong shape [batch, channel=1, rows, cols]"
+    a = ops.image_metrics(gt.contiguous(), pred.contiguous(), 64)          # [n*c, 4] float64
+    b = ops.image_metrics(gt.contiguous(), warped.contiguous(), 64)
+    ssl = ops.ssim_loss(gt.contiguous(), pred.contiguous())
+    host = torch.cat([a.reshape(-1), b.reshape(-1), ssl.double().reshape(1)]).cpu()      # the one synchronisation
+    k = a.numel()
+    a, b, ssl = host[:k].reshape(-1, 4), host[k:2 * k].reshape(-1, 4), host[2 * k].item()
+    m = (a[:, 0].sum() / gt.numel()).item()
+    return {"MSE": m, "MAE": (a[:, 1].sum() / gt.numel()).item(), "PSNR": 10.0 * math.log10(1.0 / m) if m > 0 else float("inf"),
+            "SSIM": 1.0 - ssl, "MI": b[:, 3].mean().item()}

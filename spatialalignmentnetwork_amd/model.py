@@ -604,10 +604,11 @@ class CSModel(BaseModel):
             self.forwardT()
             self.loss_all = 0
             self.forwardR()
-            m = metrics.all_metrics(self.img_full_rss, self.img_rec)      # model.py:275-279, on the GPU
-            self.metric_MI = metrics.mi(self.img_full_rss, self.img_warped_rss)
+            # model.py:275-279, on the GPU, one host synchronisation for all five scalars
+            m = metrics.test_metrics(self.img_full_rss, self.img_rec, self.img_warped_rss)
+            self.metric_MI = m["MI"]
             self.metric_PSNR = m["PSNR"]
-            self.metric_SSIM = metrics.ssim(self.img_full_rss, self.img_rec)
+            self.metric_SSIM = m["SSIM"]
             self.metric_MAE = m["MAE"]
             self.metric_MSE = m["MSE"]
         return -self.metric_PSNR

@@ -361,3 +361,15 @@ def test_full_rec_step_gradients_elementwise_on_shipped_kernels(S, tag, shape):
                 worst, worst_name = err, name
         print(f"{tag} {pre} shipped kernels: worst element-wise relative gradient error {worst:.2e} ({worst_name})")
         assert worst < 3e-4, (pre, worst, worst_name)
+
+
+def test_test_metrics_single_sync_matches_the_separate_calls(S):
+    """metrics.test_metrics (what CSModel.test() uses: ONE host synchronisation for MSE / MAE / PSNR / SSIM / MI) against the
+    per-metric functions (one synchronisation each): identical values."""
+    from spatialalignmentnetwork_amd import metrics as M
+    gt = g(philox("tm.gt", (3, 1, 48, 64), lo=0.0, hi=1.0))
+    pred = (gt + 0.05 * g(philox("tm.d", (3, 1, 48, 64)))).clamp(0, 1)
+    warped = (gt + 0.2 * g(philox("tm.w", (3, 1, 48, 64)))).clamp(0, 1)
+    m = M.test_metrics(gt, pred, warped)
+    assert m["MSE"] == M.mse(gt, pred) and m["MAE"] == M.mae(gt, pred) and m["PSNR"] == M.psnr(gt, pred)
+    assert m["MI"] == M.mi(gt, warped) and abs(m["SSIM"] - M.ssim(gt, pred)) < 1e-7
