@@ -604,6 +604,19 @@ int san_adamw_step_hyper(float* p, const float* g, float* m, float* v, size_t co
                          float beta2, float eps, float weight_decay, long long* step_dev, float grad_scale,
                          const float* hyper_dev, void* stream);
 
+/* ------------------------------------------------------------- recorded steps */
+
+/* Walks a "tape" of recorded calls on the host, in order (csrc/san_replay.cpp; the host-side mirror of the reference's train loop
+ * body, train.py:212-217, once CSModel.update() has recorded it -- the reference itself has no such layer: its step is Python).
+ * tape: host array of n_words 64-bit words; an entry = one head word  code | flags << 16 | nargs << 24  followed by nargs
+ * argument words (pointers / integers by value, float / double as bit patterns).  code < 0x8000: the index, in the order of
+ * this header, of an int-returning function declared here, called with those arguments; 0x8000: hipEventRecord(event, stream);
+ * 0x8001: hipStreamWaitEvent(stream, event).  flags bit 0: the call's return value is not an error code; bit 1: a weight-packing
+ * launch, skipped when skip_packs != 0.  Stops at the first failing call: returns its code and stores the index of the entry's
+ * head word in *failed_word (host, may be NULL).  Entries are not validated beyond their length: a tape is built by
+ * spatialalignmentnetwork_amd/model.py from calls that already ran once. */
+int san_replay_run(const void* tape, size_t n_words, int skip_packs, long long* failed_word);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 import os
 import re
+import struct
 from typing import Dict, List, Tuple
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime libsan_hip.so links against)
@@ -98,6 +99,7 @@ class SanLibrary:
         self._setters = set()
         self._dll = ctypes.CDLL(path)
         self.protos = parse_header()
+        self.func_index = {name: i for i, name in enumerate(self.protos)}      # = the case labels of csrc/san_replay_table.inc
         for name, (restype, argtypes) in self.protos.items():
             try:
                 fn = getattr(self._dll, name)
@@ -147,6 +149,73 @@ class SanLibrary:
             return v
         except TypeError:                       # an unhashable argument (a ctypes object): not a geometry query
             return getattr(self, "_" + name)(*args)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Tapes for san_replay_run (csrc/san_replay.cpp): a recorded step's C-ABI calls and stream / event operations as 64-bit words
+# that ONE foreign call walks in C, instead of ~4,000 ctypes calls (~10 us of argument marshalling each) per step.
+TAPE_EVENT_RECORD, TAPE_STREAM_WAIT = 0x8000, 0x8001
+TAPE_IGNORE_RC, TAPE_PACK = 1, 2
+_F32 = struct.Struct("<f")
+_U32 = struct.Struct("<I")
+_F64 = struct.Struct("<d")
+_U64 = struct.Struct("<Q")
+
+
+def tape_call_words(fn, args, flags: int = 0):
+    """The tape entry of the C-ABI call ``fn(*args)`` (fn: a function object of SanLibrary), or None when it cannot be put on a
+    tape (a char*-returning query, an argument that is not a plain value)."""
+    protos = lib().protos
+    name = getattr(fn, "__name__", None)
+    if name not in protos or protos[name][0] is not ctypes.c_int or name == "san_replay_run":
+        return None
+    argtypes = protos[name][1]
+    if len(args) != len(argtypes) or len(args) > 255:
+        return None
+    words = [lib().func_index[name] | flags << 16 | len(args) << 24]
+    for a, t in zip(args, argtypes):
+        if t is ctypes.c_void_p:
+            if a is None:
+                v = 0
+            elif isinstance(a, int):
+                v = a
+            elif isinstance(a, ctypes.c_void_p):
+                v = a.value or 0
+            else:
+                return None
+        elif t is ctypes.c_int:
+            v = int(a) & 0xFFFFFFFFFFFFFFFF       # (sign-extended two's complement: the dispatcher narrows it back to int)
+        elif t is ctypes.c_size_t:
+            v = int(a)
+        elif t is ctypes.c_float:
+            v = _U32.unpack(_F32.pack(float(a)))[0]
+        elif t is ctypes.c_double:
+            v = _U64.unpack(_F64.pack(float(a)))[0]
+        else:
+            return None
+        if not 0 <= v <= 0xFFFFFFFFFFFFFFFF:
+            return None
+        words.append(v)
+    return words
+
+
+class Tape:
+    """A finished tape: ``run(skip_packs)`` walks it; a failing entry raises with the recorded call's name."""
+
+    def __init__(self, words, names):
+        self.n = len(words)
+        self.buf = (ctypes.c_uint64 * max(self.n, 1))(*words)
+        self.names = names                      # {head word index: what the entry is} for error messages
+        self._where = ctypes.c_longlong(-1)
+        self._run = lib()._san_replay_run
+        self._args = (ctypes.addressof(self.buf), self.n)
+        self._wp = ctypes.addressof(self._where)
+
+    def run(self, skip_packs: bool = False) -> None:
+        rc = self._run(self._args[0], self._args[1], 1 if skip_packs else 0, self._wp)
+        if rc:
+            what = self.names.get(self._where.value, "?")
+            raise RuntimeError(f"recorded step: {what} failed ({'argument error' if rc < 0 else 'hipError_t'} {rc}): {lib().last_error()}")
 
 
 _LIB = None

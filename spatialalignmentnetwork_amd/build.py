@@ -22,12 +22,55 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=
          "-Wno-unused-function"] + os.environ.get("SAN_EXTRA_HIPCC_FLAGS", "").split()      # tuning builds (-DSAN_B16_RING=3 ...): use force
 
 
+REPLAY_TABLE = os.path.join(CSRC, "san_replay_table.inc")
+
+
+def replay_table_text() -> str:
+    """The dispatcher cases of csrc/san_replay.cpp, one per int-returning prototype of include/san_hip.h, in header order (the
+    order ``_lib.parse_header`` sees: a function's id on a replay tape is its index there).  An argument travels as one 64-bit
+    word: pointers and integers by value, float / double as their bit patterns."""
+    import re
+    text = open(os.path.join(os.path.dirname(HERE), "include", "san_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = ["// GENERATED from include/san_hip.h by spatialalignmentnetwork_amd/build.py (replay_table_text) -- do not edit;",
+           "// tests/test_abi.py checks that it matches the header."]
+    idx = 0
+    for m in re.finditer(r"(const\s+char\s*\*|int|size_t)\s+(san_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        if ret == "int" and name != "san_replay_run":
+            parts = []
+            if args and args != "void":
+                for i, a in enumerate(args.split(",")):
+                    t = re.sub(r"\b\w+$", "", a.strip()).strip()
+                    if "*" in t:
+                        parts.append(f"({t})(uintptr_t)a[{i}]")
+                    elif t == "float":
+                        parts.append(f"bits_f(a[{i}])")
+                    elif t == "double":
+                        parts.append(f"bits_d(a[{i}])")
+                    elif t == "size_t":
+                        parts.append(f"(size_t)a[{i}]")
+                    else:
+                        parts.append(f"(int)(int64_t)a[{i}]")
+            out.append(f"case {idx}: rc = {name}({', '.join(parts)}); break;")
+        idx += 1
+    return "\n".join(out) + "\n"
+
+
+def _write_replay_table() -> None:
+    text = replay_table_text()
+    if not os.path.exists(REPLAY_TABLE) or open(REPLAY_TABLE).read() != text:
+        with open(REPLAY_TABLE, "w") as f:
+            f.write(text)
+
+
 def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
 def _deps():
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "san_hip.h"))
     return hdrs
 
@@ -48,6 +91,7 @@ def _compile(src: str, force: bool) -> str:
 
 def build(force: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    _write_replay_table()
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))

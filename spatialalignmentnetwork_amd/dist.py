@@ -30,10 +30,14 @@ def init(backend: str, device=None, allow_fallback: bool = False):
     be meaningless.  Only ``allow_fallback=True`` (debugging on a box without working IPC) degrades to gloo, with the
     gradients staged through the host; ``BACKEND`` records what is in use."""
     global BACKEND
-    _, _, world = env_rank_world()
-    if world <= 1:
+    rank, _, world = env_rank_world()
+    if world <= 1 and not single_rank_exchange():
         return None
     import torch.distributed as dist
+    if world <= 1:                                 # (the hook below: a one-rank RCCL communicator on this GPU)
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29533")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if backend == "nccl":
@@ -58,6 +62,15 @@ def init(backend: str, device=None, allow_fallback: bool = False):
     dist.init_process_group(backend)
     BACKEND = backend
     return dist
+
+
+def single_rank_exchange() -> bool:
+    """``SAN_DIST_SINGLE=1``: treat a ONE-rank process group as data-parallel, i.e. run the whole gradient exchange (RCCL
+    communicator, communication stream, per-cascade slices, recorded / captured collectives) with world size 1.  A one-GPU box
+    cannot show the transport, but it does run every RCCL call site of the step (tests/test_hip_parity_r4.py,
+    ``bench.py`` with the variable set); sums over one rank leave the gradients unchanged, so the step must equal the plain one
+    bit for bit."""
+    return os.environ.get("SAN_DIST_SINGLE", "0") == "1"
 
 
 def backend() -> str:

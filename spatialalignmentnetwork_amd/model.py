@@ -11,6 +11,7 @@ model.py:64-71) instead of being hard-coded.
 """
 from __future__ import annotations
 
+import ctypes
 import math
 import os
 
@@ -75,7 +76,7 @@ class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena", "_exchange",
-                                                         "_exchange_events", "_split_capture", "time_exchange", "_auto", "_auto_busy", "auto_record", "step_mode"}
+                                                         "_exchange_events", "exchange_slices", "_split_capture", "time_exchange", "_auto", "_auto_busy", "auto_record", "step_mode"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -316,6 +317,7 @@ class CSModel(BaseModel):
             exch = getattr(self, "_exchange", None)
             if exch is not None:
                 exch.wait()
+                self.exchange_slices = list(exch.launched)      # what went out, in order (None = a whole buffer): tests, bench
                 if exch.events:
                     self._exchange_events = getattr(self, "_exchange_events", []) + exch.events
                 self._exchange = None
@@ -349,10 +351,9 @@ class CSModel(BaseModel):
         memory (FusedAdamW.device_step / sync_hyper: change ``param_groups[0]['lr']``, call ``optim.sync_hyper()``, and
         the next replay uses it); the weight gradients' side stream is captured as a fork / join.
 
-        Under a process group the RCCL all-reduces (stream-ordered) are captured INSIDE the graph, on the
-        communication stream.  Where that is impossible (gloo staging through the host; a collective that refuses
-        capture) the step is recorded as two graphs -- forward + backward, optimiser -- with the exchange issued eagerly
-        between them; ``replay()`` hides the difference (``.mode`` says which one it is).
+        Under a process group the step is recorded as two graphs -- forward + backward, optimiser -- with the gradient
+        exchange issued eagerly between them; ``replay()`` hides the difference (``.mode`` says which form it is).
+        ``SAN_CAPTURE_COLLECTIVES=1`` tries to capture the RCCL all-reduces INSIDE one graph (see the note at ``split``).
 
         ``restore`` (default): parameters, AdamW moments, step counts and BatchNorm buffers are put back to their
         values from before the ``warmup`` real steps the capture needs (arena, packed weights, twiddles), so capturing
@@ -392,7 +393,11 @@ class CSModel(BaseModel):
             self.set_input(img_full, img_aux)
             self.update()
 
-        split = dist is not None and sdist.backend() != "nccl"
+        # Under a process group the exchange is issued eagerly between two graphs by default.  Capturing the RCCL all-reduces (per
+        # cascade, on the forked communication stream) inside ONE graph is opt-in (SAN_CAPTURE_COLLECTIVES=1): the first time this
+        # path ran on RCCL (round 4, one rank, ROCm 7.0 / RCCL 2.26) hipStreamEndCapture crashed the process -- not an error
+        # a caller could catch.  A lone captured all-reduce on the capturing stream does work (scratch/rccl_single.py).
+        split = dist is not None and (sdist.backend() != "nccl" or os.environ.get("SAN_CAPTURE_COLLECTIVES", "0") != "1")
         if not split:
             try:
                 return CapturedStep([_capture(_whole)], None, "single-graph" + (" (RCCL all-reduce captured)" if dist is not None else ""))
@@ -657,6 +662,7 @@ class RecordedStep:
         self.mode = f"recorded step: {len(calls)} calls"
         self._packed_epoch = None
         self._ring, self._k = [], 0
+        self._segs, self._own_events = None, []
 
     def _throttle(self) -> None:
         if not self._ring:
@@ -667,8 +673,90 @@ class RecordedStep:
             ring[(k - self.LAG) % len(ring)].synchronize()      # the host sleeps until the GPU is within LAG chunks
         self._k = k + 1
 
+    # SAN_NATIVE_REPLAY=0: the Python loop below (one ctypes call per recorded entry), kept for comparison and for the throttle
+    NATIVE = os.environ.get("SAN_NATIVE_REPLAY", "1") != "0"
+
+    def _compile(self):
+        """The recording as segments: runs of C-ABI calls and stream / event operations become tapes for san_replay_run (one
+        foreign call each), whatever else was recorded (tensor copies, the collectives, a few torch expressions) stays a Python
+        callable between them.  Order and arguments are the recorded ones; ``wait_stream`` gets an event of its own, as torch
+        does per call."""
+        segs, words, names = [], [], {}
+        own = []                                # events made for wait_stream: alive as long as the step
+
+        def flush():
+            if words:
+                segs.append(_lib.Tape(list(words), dict(names)))
+                words.clear()
+                names.clear()
+
+        def ev_record(ev, stream):
+            names[len(words)] = "hipEventRecord"
+            words.extend((_lib.TAPE_EVENT_RECORD | 2 << 24, ev.cuda_event, stream.cuda_stream))
+
+        def st_wait(stream, ev):
+            names[len(words)] = "hipStreamWaitEvent"
+            words.extend((_lib.TAPE_STREAM_WAIT | 2 << 24, stream.cuda_stream, ev.cuda_event))
+
+        for fn, args, kind in self.calls:
+            enc = None
+            if kind:
+                enc = _lib.tape_call_words(fn, args, _lib.TAPE_PACK if kind == 2 else 0)
+            elif isinstance(fn, ctypes._CFuncPtr):
+                enc = _lib.tape_call_words(fn, args, _lib.TAPE_IGNORE_RC)       # (san_wgrad_defer returns the previous mode)
+            else:
+                owner, name = getattr(fn, "__self__", None), getattr(fn, "__name__", "")
+                if isinstance(owner, torch.cuda.Event) and name == "record" and len(args) == 1 and isinstance(args[0], torch.cuda.Stream) \
+                        and owner.cuda_event:
+                    ev_record(owner, args[0])
+                    continue
+                if isinstance(owner, torch.cuda.Stream) and name == "wait_event" and len(args) == 1 and isinstance(args[0], torch.cuda.Event) \
+                        and args[0].cuda_event:
+                    st_wait(owner, args[0])
+                    continue
+                if isinstance(owner, torch.cuda.Stream) and name == "wait_stream" and len(args) == 1 and isinstance(args[0], torch.cuda.Stream):
+                    ev = torch.cuda.Event()
+                    ev.record(args[0])          # (creates the handle; harmless: nothing waits for this one)
+                    own.append(ev)
+                    ev_record(ev, args[0])
+                    st_wait(owner, ev)
+                    continue
+            if enc is None:
+                if kind:
+                    raise RuntimeError(f"recorded step: {getattr(fn, '__name__', fn)} cannot be put on a replay tape")
+                flush()
+                segs.append((fn, args))
+            else:
+                names[len(words)] = getattr(fn, "__name__", "?")
+                words.extend(enc)
+        flush()
+        self._own_events = own
+        return segs
+
+    def invalidate(self) -> None:
+        """Forget the tapes: the next replay rebuilds them from ``calls`` (tests edit a recorded call)."""
+        self._segs, self._own_events = None, []
+
     def replay(self) -> None:
         skip_packs = (not self.training) and self._packed_epoch == ops.WEIGHT_EPOCH[0]
+        if self.NATIVE and not self.CHUNK:
+            if self._segs is None:
+                self._segs = self._compile()
+            for seg in self._segs:
+                if type(seg) is tuple:
+                    seg[0](*seg[1])
+                else:
+                    seg.run(skip_packs)
+        else:
+            self._replay_python(skip_packs)
+        if self.training:
+            ops.bump_weight_epoch()
+        else:
+            # (the registries' own epoch is left alone: the recording's job table covers the jobs that existed when it was made,
+            # an eager step may have registered more since -- data-gradient images -- and re-packs all of them itself)
+            self._packed_epoch = ops.WEIGHT_EPOCH[0]
+
+    def _replay_python(self, skip_packs: bool) -> None:
         chunk, left = self.CHUNK, self.CHUNK
         for fn, args, kind in self.calls:
             if kind:
@@ -685,12 +773,6 @@ class RecordedStep:
                         self._throttle()
             else:
                 fn(*args)
-        if self.training:
-            ops.bump_weight_epoch()
-        else:
-            # (the registries' own epoch is left alone: the recording's job table covers the jobs that existed when it was made,
-            # an eager step may have registered more since -- data-gradient images -- and re-packs all of them itself)
-            self._packed_epoch = ops.WEIGHT_EPOCH[0]
 
 
 class CapturedStep:
@@ -710,7 +792,9 @@ class CapturedStep:
 
 def _active_dist():
     import torch.distributed as dist
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    from . import dist as sdist
+    return dist if (dist.is_available() and dist.is_initialized()
+                    and (dist.get_world_size() > 1 or sdist.single_rank_exchange())) else None
 
 
 _KEEP_CACHE = {}

@@ -55,3 +55,42 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("# oracle", ""), f
+
+
+def test_replay_table_is_generated_from_the_header(built):
+    """csrc/san_replay_table.inc (the dispatcher cases of san_replay_run) is what build.py derives from include/san_hip.h, and
+    the function ids Python puts on a tape are the header's order."""
+    from spatialalignmentnetwork_amd import build
+    assert open(build.REPLAY_TABLE).read() == build.replay_table_text()
+    lib = built.lib()
+    assert list(lib.func_index) == list(built.parse_header())
+    text = open(build.REPLAY_TABLE).read()
+    for name in ("san_rss", "san_adamw_step_hyper", "san_conv_stream_set_tuning"):
+        assert f"case {lib.func_index[name]}: rc = {name}(" in text
+    assert "san_replay_run(" not in text and "san_last_error_string(" not in text
+
+
+def test_replay_tape_walks_calls_and_reports_the_failing_entry(built):
+    """A tape of C-ABI calls is walked in order by ONE foreign call; the first failing entry stops it and is named; entries flagged
+    as weight packing are skipped on request; a value that is not an error code is ignored when flagged so.  (Argument
+    validation happens before any HIP call: testable without a GPU.)"""
+    lib = built.lib()
+    ok = built.tape_call_words(lib._san_version, (), built.TAPE_IGNORE_RC)      # returns the version number, not an rc
+    bad = built.tape_call_words(lib._san_rss, (None, None, 1, 1, 16, 0, None))
+    assert ok is not None and bad is not None and bad[0] >> 24 == 7
+    built.Tape(ok + ok, {}).run()
+    with pytest.raises(RuntimeError, match=r"san_rss failed \(argument error -1\).*null"):
+        built.Tape(ok + bad + ok, {len(ok): "san_rss"}).run()
+    skipped = built.tape_call_words(lib._san_rss, (None, None, 1, 1, 16, 0, None), built.TAPE_PACK)
+    built.Tape(ok + skipped, {}).run(skip_packs=True)
+    with pytest.raises(RuntimeError, match="argument error"):
+        built.Tape(ok + skipped, {}).run(skip_packs=False)
+    # floats / doubles travel as bit patterns, negative ints sign-extended
+    w = built.tape_call_words(lib._san_adamw_step, (None, None, None, None, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, -3, 1.0, None))
+    assert w is not None and w[6] == 0x3A83126F and w[11] == 0xFFFFFFFFFFFFFFFD
+    with pytest.raises(RuntimeError, match="san_adamw_step"):
+        built.Tape(w, {0: "san_adamw_step"}).run()
+    # a truncated tape is refused, not read past
+    with pytest.raises(RuntimeError, match="past the end"):
+        built.Tape(bad[:3], {0: "truncated"}).run()
+    assert built.tape_call_words(lib._san_last_error_string, ()) is None

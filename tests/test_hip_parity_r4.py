@@ -110,6 +110,7 @@ def test_replay_checks_return_codes(S):
     idx = next(i for i, (fn, args, kind) in enumerate(step.calls) if kind == 1 and getattr(fn, "__name__", "") == "san_norm_finalize")
     fn, args, kind = step.calls[idx]
     step.calls[idx] = (fn, (None,) + tuple(args[1:]), kind)
+    step.invalidate()                                   # (the native tapes are built from `calls` at the first replay)
     with pytest.raises(RuntimeError, match="san_norm_finalize failed"):
         step.replay()
     torch.cuda.synchronize()
@@ -373,3 +374,61 @@ def test_test_metrics_single_sync_matches_the_separate_calls(S):
     m = M.test_metrics(gt, pred, warped)
     assert m["MSE"] == M.mse(gt, pred) and m["MAE"] == M.mae(gt, pred) and m["PSNR"] == M.psnr(gt, pred)
     assert m["MI"] == M.mi(gt, warped) and abs(m["SSIM"] - M.ssim(gt, pred)) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------- RCCL, one rank (SAN_DIST_SINGLE)
+def _rccl_single_worker(rank, port, path, with_group):
+    """Five update() calls (two eager, the recording, two replays) and one captured step of a small 'Rec' model; with_group: under a
+    ONE-rank RCCL process group with SAN_DIST_SINGLE=1, i.e. with the whole gradient exchange of the data-parallel step."""
+    import types
+    if with_group:
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SAN_DIST_SINGLE="1")
+    from spatialalignmentnetwork_amd import basemodel, dist as sdist, model as smodel, synth
+    dev = torch.device(DEV)
+    d = sdist.init("nccl", dev) if with_group else None
+    S_ = types.SimpleNamespace(base=basemodel, model=smodel, synth=synth)
+    n, c, h, w = 2, 1, 48, 80
+    net = _model(S_, w, c, chans=4).train()
+    net.time_exchange = with_group
+    info = {"backend": sdist.backend() if with_group else None, "modes": []}
+    for it in range(5):
+        net.set_input(*(g(t) for t in synth.phantom_pair(n, c, h, w, seed=300 + it)))
+        net.update()
+        info["modes"].append(net.step_mode)
+    torch.cuda.synchronize()
+    info["slices"] = getattr(net, "exchange_slices", None)
+    xf, xa = (g(t) for t in synth.phantom_pair(n, c, h, w, seed=310))
+    cap = net.capture_update(xf, xa, warmup=1)
+    cap.replay()
+    torch.cuda.synchronize()
+    info["capture_mode"] = cap.mode
+    info["state"] = _state(net)
+    torch.save(info, f"{path}/{'rccl' if with_group else 'plain'}.pt")
+    if d is not None:
+        d.destroy_process_group()
+
+
+def test_gradient_exchange_runs_on_rccl_with_one_rank(S, tmp_path):
+    """'RCCL code paths have literally never run.'  A one-GPU box cannot show the transport, but it can run every
+    RCCL call site of the data-parallel step: dist.init("nccl") (communicator + probe all-reduce), the per-cascade slices of
+    net_R's flat buffer launched in reverse order from inside VarNet.backward on the communication stream, net_T's buffer, the
+    join in front of AdamW, the same collectives inside a recorded step's replays, and the eager exchange between the two graphs of a captured step.  With
+    SAN_DIST_SINGLE=1 a one-rank group counts as data-parallel; sums over one rank change nothing, so parameters and BatchNorm
+    buffers must equal the plain single-process run BIT for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    mp.spawn(_rccl_single_worker, args=(port, str(tmp_path), True), nprocs=1, join=True)
+    mp.spawn(_rccl_single_worker, args=(port, str(tmp_path), False), nprocs=1, join=True)
+    a, b = torch.load(tmp_path / "rccl.pt"), torch.load(tmp_path / "plain.pt")
+    assert a["backend"] == "nccl"
+    assert a["modes"][0] == "eager" and a["modes"][-1].startswith("replay"), a["modes"]
+    # net_R went out in slices: the cascades in reverse order, then the sensitivity net; net_T's whole buffer (None) last
+    sl = a["slices"]
+    assert sl is not None and len(sl) >= 4 and sl[-1] is None and all(r is not None for r in sl[:-1]), sl
+    los = [r[0] for r in sl[:2]]
+    assert los[0] > los[1], f"cascade slices not in reverse order: {sl}"
+    assert a["capture_mode"] == "two graphs around an eager exchange", a["capture_mode"]
+    assert all(torch.equal(a["state"][k], b["state"][k]) for k in b["state"]), "the one-rank exchange changed the step"
