@@ -55,6 +55,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _host_cores():
+    """Cores this process may use: affinity mask and cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+# A replayed step keeps ~1.8 host cores busy per rank with HIP's direct dispatch: the launching thread spins inside the runtime
+# while the launch queue is full (the tape itself takes 3 ms per step) and a runtime thread handles completions.  With
+# AMD_DIRECT_DISPATCH=0 the runtime queues commands to its own thread instead: 0.17 cores per rank, the step 7 % slower
+# (measured, profiles/r04_host_env.txt).  On a node with fewer than two cores per rank the former starves the GPUs, so the
+# setting is chosen here, before the HIP runtime loads; an explicit AMD_DIRECT_DISPATCH in the environment wins.
+_LOCAL_WORLD = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+if _LOCAL_WORLD > 1 and "AMD_DIRECT_DISPATCH" not in os.environ and _host_cores() // _LOCAL_WORLD < 2:
+    os.environ["AMD_DIRECT_DISPATCH"] = "0"
+DISPATCH = "runtime thread (AMD_DIRECT_DISPATCH=0)" if os.environ.get("AMD_DIRECT_DISPATCH") == "0" else "direct"
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -566,7 +589,7 @@ def main(argv=None):
                        "parallelism": f"dp{world} (independent slice shards; one RCCL all-reduce of the flat gradient "
                                       f"buffers per step)" if args.mode == "train" else
                                       f"dp{world} (independent slice shards, no data-path collective)",
-                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks, "hip_graph": bool(args.graph),
+                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks, "dispatch": DISPATCH, "hip_graph": bool(args.graph),
                        "step_mode": step_mode, "hip_graph_mode": getattr(graph, "mode", None),
                        "cores_per_rank": len(my_cores) if my_cores else None},
             # the host's share of a step (time until step() returns = everything is enqueued; max over ranks): a value close
