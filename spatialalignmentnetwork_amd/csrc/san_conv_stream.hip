@@ -263,6 +263,11 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
     for (int b = 0; b < 4; ++b) boff[b] = ((2 * wave + (b >> 1)) * kHP + 16 * (b & 1) + nn) * kPS;
     const int wl_full = lane * 16;
     const int wl_rem = REM > 0 ? (nn < REM ? MBF * 1024 + (kg * REM + nn) * 16 : MBF * 1024 + REM * 64) : 0;
+    // The partial block's products (x hi, w hi) and (x hi, w lo) share ONE MFMA: columns 0 .. REM-1 of its weight operand are the
+    // channels' hi parts, columns REM .. 2 REM-1 their lo parts (read from the part-1 region: + RS), the rest the zero slot; the
+    // epilogue adds column c + REM into column c.  2 instead of 3 MFMAs per K-step and pixel block for those channels.
+    const int wl_mix = REM > 0 ? (nn < REM ? wl_rem : (nn < 2 * REM ? RS + MBF * 1024 + (kg * REM + nn - REM) * 16 : MBF * 1024 + REM * 64)) : 0;
+    static_assert(2 * REM <= 16, "hi and lo columns of the partial block must fit one MFMA");
 
     f4 acc[MB][4];
     float biasv[MB];                                    // this lane's channel of every block: fetched once, not once per tile
@@ -333,7 +338,9 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
         }
         if (more && !(a.abl & 1)) prefetch(nn_, nty, ntx, nchunk);
 
-        // ---- 7 K-steps on the staged image; operands of step s + 1 are requested before the MFMAs of step s
+        // ---- 7 K-steps on the staged image; operands of step s + 1 are requested before the MFMAs of step s.  Weight operands
+        // of a step: [m][0] = hi parts, [m][1] = lo parts of the full blocks; the partial block has [MBF][0] = hi and [MBF][1] =
+        // the mixed hi | lo operand (wl_mix)
         if (!(a.abl & 4)) {
             Frag wa[2][MB][2], xa[2][4][2];
             auto load_w = [&](int s, Frag (&wq)[MB][2]) {
@@ -341,7 +348,8 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
-                        wq[m][p].u = *reinterpret_cast<const uint4*>(lds_w + (s * 2 + p) * RS + (m < MBF ? m * 1024 + wl_full : wl_rem));
+                        wq[m][p].u = *reinterpret_cast<const uint4*>(lds_w + (m < MBF ? (s * 2 + p) * RS + m * 1024 + wl_full
+                                                                                        : s * 2 * RS + (p == 0 ? wl_rem : wl_mix)));
             };
             auto load_x = [&](int s, Frag (&xq)[4][2]) {
                 const int to = tapoff[s];
@@ -358,20 +366,41 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
                     load_w(s + 1, wa[(s + 1) & 1]);
                     load_x(s + 1, xa[(s + 1) & 1]);
                 }
+                // (x hi, w hi | mixed), (x lo, w hi), (x hi, w lo of the full blocks)
 #pragma unroll
-                for (int pw = 0; pw < 2; ++pw)
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int px = 0; px < 2 - pw; ++px)
+                    for (int b = 0; b < 4; ++b)
+                        acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][0].h, wa[s & 1][m][m < MBF ? 0 : 1].h, acc[m][b], 0, 0, 0);
 #pragma unroll
-                        for (int m = 0; m < MB; ++m)
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-                            for (int b = 0; b < 4; ++b)
-                                acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][px].h, wa[s & 1][m][pw].h, acc[m][b], 0, 0, 0);
+                    for (int b = 0; b < 4; ++b)
+                        acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][1].h, wa[s & 1][m][0].h, acc[m][b], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MBF; ++m)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][0].h, wa[s & 1][m][1].h, acc[m][b], 0, 0, 0);
             }
         }
 
         // ---- last chunk of the tile: epilogue.  acc[m][b][r] = channel 16 m + nn at tile pixel 64 wave + 16 b + 4 kg + r
         if (chunk == a.chunks - 1) {
+            if constexpr (REM > 0) {                    // column c + REM (x hi . w lo) into column c: a row shift by REM lanes
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    // (scalars, each shift behind an opaque barrier: on the vector elements hipcc 7.0 shifted element 0 four times)
+                    float e[4] = {acc[MBF][b][0], acc[MBF][b][1], acc[MBF][b][2], acc[MBF][b][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        asm volatile("" : "+v"(e[r]));
+                        const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, e[r]), 0x100 + REM, 0xf, 0xf, false));
+                        e[r] += t;
+                    }
+                    acc[MBF][b] = f4{e[0], e[1], e[2], e[3]};
+                }
+            }
             if (a.amax) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
