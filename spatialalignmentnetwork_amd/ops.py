@@ -212,7 +212,7 @@ class Arena:
             t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
             self._bufs[key] = t
             _ARENA_PTRS.add(t.data_ptr())
-        elif not _no_wait and _WG["busy"]:
+        elif not _no_wait and (_WG["busy"] or _WG["pending_ptrs"]):
             _wait_if_busy(t)                    # a side-stream weight gradient may still be reading it (wgrad_overlap)
         return t
 
@@ -749,6 +749,7 @@ class AmaxPool:
             # gradients may still be reading the records about to be zeroed -- join them first
             side = _WG["stream"]
             if side is not None:
+                _flush_pending()
                 torch.cuda.current_stream().wait_stream(side)
             self.reset(device)
         self.idx += 1
@@ -1136,7 +1137,15 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
 #   * allocator-owned operands get record_stream();
 #   * leaving the context joins the side stream back into the main one (before the all-reduce / optimiser).
 # ---------------------------------------------------------------------------
-_WG = {"stream": None, "main": None, "pool": {}, "busy": {}, "rr": {}, "defer": False, "defer_k": 0, "defer_dw": set()}
+_WG = {"stream": None, "main": None, "pool": {}, "busy": {}, "rr": {}, "defer": False, "defer_k": 0, "defer_dw": set(),
+       "pending": [], "pending_ptrs": set(), "seq": 0, "waited": 0}
+# Hand-offs between the two streams cost the GPU: an event record on the main stream is a ~2 us bubble in front of the next
+# kernel, a wait ~1-3 us (scratch/event_bubble.py); one pair per weight gradient, ~330 per step, plus the reverse waits of the
+# rotating dy copies, were 2 ms of a 46 ms step (measured by leaving them out: gpurun_out/r4b_unsafe.txt).  So weight gradients
+# are handed over in BATCHES of up to WGRAD_BATCH launches behind ONE event, and a reverse wait is skipped when the main stream
+# already waited for a later batch (the side stream runs in order).  A queued launch keeps its operands alive; an arena buffer
+# that a queued launch will read is never handed out again before the queue is flushed.
+WGRAD_BATCH = [int(os.environ.get("SAN_WGRAD_BATCH", "4"))]     # 1: 45.95, 2: 45.54, 4: 45.38, 8: 46.38, 16: 48.5 ms per step (later launches overlap less)
 WGRAD_OVERLAP = [os.environ.get("SAN_NO_WGRAD_OVERLAP", "0") != "1"]
 # Deferred weight-gradient reductions (san_wgrad_defer): inside wgrad_overlap the side-stream weight gradients queue the
 # fixed-order reduction of their partial tiles, and one launch reduces up to 48 layers (each with its own scratch copy).
@@ -1145,7 +1154,8 @@ _DEFER_BATCH = 48
 
 
 def wgrad_flush() -> None:
-    """Launch the queued weight-gradient reductions (on the side stream)."""
+    """Hand over the queued weight gradients and launch the queued reductions (on the side stream)."""
+    _flush_pending()
     if _WG["defer"] and _WG["defer_k"]:
         lib().call("san_wgrad_defer_flush", _WG["stream"].cuda_stream)
     _WG["defer_k"] = 0
@@ -1185,6 +1195,7 @@ class wgrad_overlap:
     def __exit__(self, *exc):
         side = _WG["stream"]
         if side is not None:
+            _flush_pending()
             if _WG["defer"]:
                 wgrad_flush()
                 lib().query("san_wgrad_defer", 0)
@@ -1194,6 +1205,7 @@ class wgrad_overlap:
         _WG["main"] = None
         _WG["busy"].clear()
         _WG["rr"].clear()
+        _WG["seq"] = _WG["waited"] = 0
         return False
 
 
@@ -1225,9 +1237,13 @@ class backward_scope:
 
 
 def _wait_if_busy(t: torch.Tensor) -> None:
-    ev = _WG["busy"].pop(t.data_ptr(), None)
-    if ev is not None:
-        _lib.rec(torch.cuda.current_stream().wait_event, ev)
+    ptr = t.data_ptr()
+    if ptr in _WG["pending_ptrs"]:              # a queued weight gradient will read it: hand the queue over first
+        _flush_pending()
+    ent = _WG["busy"].pop(ptr, None)
+    if ent is not None and ent[0] > _WG["waited"]:      # (a wait for a later batch covers every earlier one: the side stream is in order)
+        _WG["waited"] = ent[0]
+        _lib.rec(torch.cuda.current_stream().wait_event, ent[1])
 
 
 def wgrad_dy_buffer(name: str, shape, device, arena: Arena = GLOBAL_ARENA) -> torch.Tensor:
@@ -1246,8 +1262,12 @@ def wgrad_dy_buffer(name: str, shape, device, arena: Arena = GLOBAL_ARENA) -> to
     first = None
     for k in range(4):
         t = arena.get(name if k == 0 else f"{name}#{k}", shape, device, _no_wait=True)
-        ev = _WG["busy"].get(t.data_ptr())
-        if ev is None or ev.query():
+        if t.data_ptr() in _WG["pending_ptrs"]:
+            if first is None:
+                first = t
+            continue
+        ent = _WG["busy"].get(t.data_ptr())
+        if ent is None or ent[0] <= _WG["waited"] or ent[1].query():
             _WG["busy"].pop(t.data_ptr(), None)
             return t
         if first is None:
@@ -1283,26 +1303,46 @@ def _on_side_stream(dy: Act, x: Act, fn) -> None:
     if side is None:
         fn()
         return
+    _WG["pending"].append((dy, x, fn))
+    _WG["pending_ptrs"].add(dy.buf.data_ptr())
+    _WG["pending_ptrs"].add(x.buf.data_ptr())
+    if len(_WG["pending"]) >= WGRAD_BATCH[0]:
+        _flush_pending()
+
+
+def _flush_pending() -> None:
+    """Hand the queued weight gradients to the side stream: one event on the main stream (their operands' producers are queued
+    on main up to here), the launches in the order they were asked for, one completion mark for all their operands."""
+    pend = _WG["pending"]
+    side = _WG["stream"]
+    if not pend or side is None:
+        return
+    _WG["pending"] = []
+    _WG["pending_ptrs"] = set()
     main = _WG["main"]
     if torch.cuda.is_current_stream_capturing():
         side.wait_stream(main)                  # (capture: fresh events, the graph keeps them as edges)
     else:
         e0 = torch.cuda.Event() if _lib.REC is not None else _EVENTS.next()      # (a recorded step owns its events)
-        _lib.rec(e0.record, main)               # the operands' producers are queued on main up to here
+        _lib.rec(e0.record, main)
         _lib.rec(side.wait_event, e0)
     _STREAM_OVERRIDE[0] = side                  # (launches take the side stream's handle; torch's current stream stays put)
     try:
-        fn()
+        for _, _, fn in pend:
+            fn()
     finally:
         _STREAM_OVERRIDE[0] = None
     ev = torch.cuda.Event() if (torch.cuda.is_current_stream_capturing() or _lib.REC is not None) else _BUSY_EVENTS.next()
     _lib.rec(ev.record, side)
-    dptr = dy.buf.data_ptr()
-    _WG["busy"][dptr] = ev
-    if dptr not in _ARENA_PTRS:                 # allocator-owned operands: keep their memory until the side stream is done
-        dy.buf.record_stream(side)
-    if x.buf.data_ptr() not in _ARENA_PTRS:
-        x.buf.record_stream(side)
+    _WG["seq"] += 1
+    ent = (_WG["seq"], ev)
+    for dy, x, _ in pend:
+        dptr = dy.buf.data_ptr()
+        _WG["busy"][dptr] = ent
+        if dptr not in _ARENA_PTRS:             # allocator-owned operands: keep their memory until the side stream is done
+            dy.buf.record_stream(side)
+        if x.buf.data_ptr() not in _ARENA_PTRS:
+            x.buf.record_stream(side)
 
 
 def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
