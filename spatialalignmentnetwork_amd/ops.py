@@ -1132,7 +1132,7 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
 # work that produced its operands, and the main stream goes straight on to the data gradient and the HBM-bound
 # activation-backward kernels, which share the CUs with the matrix-bound weight gradient.  Hazards:
 #   * dy buffers are arena temporaries the main stream rewrites a layer later -> wgrad_dy_buffer() hands out up to
-#     four rotating copies and makes the main stream wait only when all of them still have a reader in flight;
+#     DY_COPIES rotating copies and makes the main stream wait only when all of them still have a reader in flight;
 #     Arena.get() applies the same wait to any other buffer with a pending side-stream reader;
 #   * allocator-owned operands get record_stream();
 #   * leaving the context joins the side stream back into the main one (before the all-reduce / optimiser).
@@ -1145,6 +1145,7 @@ _WG = {"stream": None, "main": None, "pool": {}, "busy": {}, "rr": {}, "defer": 
 # are handed over in BATCHES of up to WGRAD_BATCH launches behind ONE event, and a reverse wait is skipped when the main stream
 # already waited for a later batch (the side stream runs in order).  A queued launch keeps its operands alive; an arena buffer
 # that a queued launch will read is never handed out again before the queue is flushed.
+DY_COPIES = [int(os.environ.get("SAN_DY_COPIES", "8"))]      # rotating copies of a dy buffer that a weight gradient reads (4: the main stream stalled 50-135 us behind every bottleneck-level split-K join; 4 / 6 / 8 / 16: 46.38 / 45.90 / 45.80 / 45.92 ms per step)
 WGRAD_BATCH = [int(os.environ.get("SAN_WGRAD_BATCH", "4"))]     # 1: 45.95, 2: 45.54, 4: 45.38, 8: 46.38, 16: 48.5 ms per step (later launches overlap less)
 WGRAD_OVERLAP = [os.environ.get("SAN_NO_WGRAD_OVERLAP", "0") != "1"]
 # Deferred weight-gradient reductions (san_wgrad_defer): inside wgrad_overlap the side-stream weight gradients queue the
@@ -1248,19 +1249,19 @@ def _wait_if_busy(t: torch.Tensor) -> None:
 
 def wgrad_dy_buffer(name: str, shape, device, arena: Arena = GLOBAL_ARENA) -> torch.Tensor:
     """An arena temporary that a weight gradient will read: the plain arena buffer outside wgrad_overlap, otherwise
-    one of up to four rotating copies without a side-stream reader in flight (else the oldest, after waiting)."""
+    one of up to DY_COPIES rotating copies without a side-stream reader in flight (else the oldest, after waiting)."""
     if _WG["stream"] is None:
         return arena.get(name, shape, device)
     if torch.cuda.is_current_stream_capturing() or _lib.REC is not None:
         # hipGraph capture / step recording: no event queries (the choice must not depend on timing); take the copies
         # round-robin and wait (a stream dependency, not a host wait) for the reader that used this copy four requests ago
         k = _WG["rr"].get(name, 0)
-        _WG["rr"][name] = (k + 1) & 3
+        _WG["rr"][name] = (k + 1) % DY_COPIES[0]
         t = arena.get(name if k == 0 else f"{name}#{k}", shape, device, _no_wait=True)
         _wait_if_busy(t)
         return t
     first = None
-    for k in range(4):
+    for k in range(DY_COPIES[0]):
         t = arena.get(name if k == 0 else f"{name}#{k}", shape, device, _no_wait=True)
         if t.data_ptr() in _WG["pending_ptrs"]:
             if first is None:
