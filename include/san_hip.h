@@ -284,6 +284,14 @@ int san_norm_finalize(const float* part, int n, int c, int tiles, int mode, floa
                       float* scale, float* shift, int sc_ctot, int sc_coff,
                       float* aux_a, float* aux_b, void* stream);
 
+/* BATCH finalisation and BatchNorm2d's running statistics in ONE launch (san_norm_finalize mode BATCH followed by
+ * san_bn_update_running: 26 extra launches per training step of the alignment network before):
+ * running = (1-m) running + m batch, the unbiased batch variance times var_factor, *num_batches_tracked += 1 (may be NULL).
+ * unet.py:125 (torch.nn.BatchNorm2d training forward). */
+int san_norm_finalize_bn(const float* part, int n, int c, int tiles, float eps, const float* gamma, const float* beta,
+                         float* scale, float* shift, int sc_ctot, int sc_coff, float* aux_a, float* aux_b, float* rmean,
+                         float* rvar, long long* num_batches_tracked, float momentum, float var_factor, void* stream);
+
 /* (count, mean, M2) partials of an existing tensor view, san_plane_stat_tiles(hw)
  * chunks per plane: part [n, c, tiles, 3].  Used for tensors no conv produced
  * (ref image, sens_reduce output). */

@@ -16,7 +16,8 @@ __global__ void __launch_bounds__(256)
 norm_finalize_kernel(const float* __restrict__ part, int n, int c, int tiles, int mode, float eps,
                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale,
                      float* __restrict__ shift, int sc_ctot, int sc_coff, float* __restrict__ aux_a,
-                     float* __restrict__ aux_b) {
+                     float* __restrict__ aux_b, float* __restrict__ rmean, float* __restrict__ rvar,
+                     long long* __restrict__ nbt, float momentum, float var_factor) {
     __shared__ double red[3][4];
     const int ch = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -104,6 +105,12 @@ norm_finalize_kernel(const float* __restrict__ part, int n, int c, int tiles, in
         }
         if (aux_a) aux_a[ch] = (float)mean;
         if (aux_b) aux_b[ch] = (float)var_u;
+        // BatchNorm2d's running statistics in the same launch (san_norm_finalize_bn): the arithmetic of bn_update_running_kernel
+        if (rmean) {
+            rmean[ch] = rmean[ch] * (1.f - momentum) + momentum * (float)mean;
+            rvar[ch] = rvar[ch] * (1.f - momentum) + momentum * ((float)var_u * var_factor);
+            if (ch == 0 && nbt) *nbt += 1;
+        }
     }
 }
 
@@ -350,7 +357,21 @@ int san_norm_finalize(const float* part, int n, int c, int tiles, int mode, floa
     SAN_CHECK_ARG(check_view(sc_ctot, sc_coff, c), "bad scale/shift view");
     dim3 grid(c, mode == SAN_NORM_BATCH ? 1 : n);
     hipLaunchKernelGGL(norm_finalize_kernel, grid, dim3(256), 0, (hipStream_t)stream, part, n, c, tiles, mode, eps,
-                       gamma, beta, scale, shift, sc_ctot, sc_coff, aux_a, aux_b);
+                       gamma, beta, scale, shift, sc_ctot, sc_coff, aux_a, aux_b, (float*)nullptr, (float*)nullptr,
+                       (long long*)nullptr, 0.f, 1.f);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_norm_finalize_bn(const float* part, int n, int c, int tiles, float eps, const float* gamma, const float* beta,
+                         float* scale, float* shift, int sc_ctot, int sc_coff, float* aux_a, float* aux_b, float* rmean,
+                         float* rvar, long long* num_batches_tracked, float momentum, float var_factor, void* stream) {
+    SAN_CHECK_ARG(part && scale && shift && rmean && rvar, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && tiles > 0, "bad dims");
+    SAN_CHECK_ARG(check_view(sc_ctot, sc_coff, c), "bad scale/shift view");
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3(c, 1), dim3(256), 0, (hipStream_t)stream, part, n, c, tiles, SAN_NORM_BATCH,
+                       eps, gamma, beta, scale, shift, sc_ctot, sc_coff, aux_a, aux_b, rmean, rvar, num_batches_tracked,
+                       momentum, var_factor);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

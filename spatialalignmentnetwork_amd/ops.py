@@ -1529,6 +1529,17 @@ def bn_bwd_coef(g: Act, y: Act, gamma: torch.Tensor, beta: torch.Tensor, dgamma:
     return coef
 
 
+def norm_finalize_bn(part: torch.Tensor, eps: float, scale: torch.Tensor, shift: torch.Tensor, coff: int, bn, bmean: torch.Tensor,
+                     bvar: torch.Tensor, momentum: float, var_factor: float) -> None:
+    """Training-mode BatchNorm2d after a convolution that emitted statistics: the lazy affine, the batch mean / unbiased variance
+    (the backward's) and the running statistics + num_batches_tracked, one launch (unet.py:125)."""
+    n, c, tiles, _ = part.shape
+    lib().call("san_norm_finalize_bn", _p(part), n, c, tiles, float(eps), _p(bn.weight), _p(bn.bias), _p(scale), _p(shift),
+               int(scale.shape[1]), coff, _p(bmean), _p(bvar), _p(_chk(bn.running_mean, name="running_mean")),
+               _p(_chk(bn.running_var, name="running_var")), _p(_chk(bn.num_batches_tracked, torch.int64, "num_batches_tracked")),
+               float(momentum), float(var_factor), _stream())
+
+
 def bn_update_running(bn, bmean: torch.Tensor, bvar: torch.Tensor, momentum: float, var_factor: float) -> None:
     """BatchNorm2d running statistics and num_batches_tracked in one launch (unet.py:125)."""
     c = bn.running_mean.shape[0]

@@ -124,9 +124,8 @@ class UNet(torch.nn.Module):
             c = conv.weight.shape[0]
             bmean = ARENA.get(f"{tag}.bmean", (c,), x.buf.device)
             bvar = ARENA.get(f"{tag}.bvar", (c,), x.buf.device)
-            ops.norm_finalize(part, ops.NORM_BATCH, BN_EPS, out.scale, out.shift, out.coff, gamma=bn.weight,
-                              beta=bn.bias, aux_a=bmean, aux_b=bvar)
-            _update_running_stats(bn, bmean, bvar, x.n * x.h * x.w, count_scale)
+            m, factor = _running_factors(bn, x.n * x.h * x.w, count_scale)
+            ops.norm_finalize_bn(part, BN_EPS, out.scale, out.shift, out.coff, bn, bmean, bvar, m, factor)
         else:
             ops.conv2d(x, conv.weight, conv.bias, out, stats=False)
             ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS,
@@ -356,15 +355,13 @@ def _arena_act(name, n, c, h, w, dev) -> Act:
                ARENA.get(name + ".sh", (n, c), dev), SLOPE)
 
 
-def _update_running_stats(bn: torch.nn.BatchNorm2d, bmean: torch.Tensor, bvar_unbiased: torch.Tensor, count: int,
-                          count_scale: int) -> None:
-    """running = (1-m)*running + m*batch (m = 0.1), unbiased batch variance.
-    ``count_scale`` = 4 for the Up blocks, whose statistics are taken at low
-    resolution: the reference sees every value 4 times, which changes only the
-    n/(n-1) factor of the unbiased variance."""
+def _running_factors(bn: torch.nn.BatchNorm2d, count: int, count_scale: int):
+    """(momentum m, variance factor) of running = (1-m)*running + m*batch (m = 0.1) with the unbiased batch variance.
+    ``count_scale`` = 4 for the Up blocks, whose statistics are taken at low resolution: the reference sees every value 4
+    times, which changes only the n/(n-1) factor of the unbiased variance."""
     m = bn.momentum if bn.momentum is not None else 0.1
     factor = 1.0
     if count_scale != 1 and count > 1:
         big = count * count_scale
         factor = ((count - 1) / count) * (big / (big - 1))
-    ops.bn_update_running(bn, bmean, bvar_unbiased, m, factor)
+    return m, factor
