@@ -31,7 +31,7 @@ Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max ran
                    The split-operand kernels execute 3 fp16 products per fp32 MAC (two fp16 parts per operand; 6 on
                    three bf16 parts with SAN_NO_F16X2=1): `executed_tflops` and `frac_of_bf16x3_ceiling` (ceiling =
                    2500 / products TFLOP/s fp32-equivalent; fp16 and bf16 dense MFMA peaks are equal) are extras.
-                   The LAST timed step is a second recording of the same step that carries an event pair around every 5th
+                   The LAST timed step is a second recording of the same step that carries an event pair around every 10th
                    launch of a conv family and around EVERY cascade-boundary launch (run alone: the two streams are joined
                    around it); the other timed steps run without brackets.  Eager mode: every 29th launch of every step.
   roofline_*     : the same for the fused FFT + data-consistency kernels (HBM; forward and backward boundary: `frac` = one
@@ -401,10 +401,10 @@ def main(argv=None):
         step_mode = "CSModel.update(): " + str(getattr(net, "step_mode", "eager"))
         if str(getattr(net, "step_mode", "")).startswith("replay") and not args.no_kernel_timer:
             try:
-                # a second recording of the same step WITH the roofline event brackets (every 5th launch of a conv family,
+                # a second recording of the same step WITH the roofline event brackets (every 10th launch of a conv family,
                 # EVERY cascade-boundary launch, each run alone): it is the LAST of the timed steps, so the HIP-event
                 # figures come from inside the timed region while the other steps run without the brackets' stream joins
-                timer = ops.KernelTimer(stride=5, strides={"fft_dc": 1, "fft_dc_bwd": 1})
+                timer = ops.KernelTimer(stride=10, strides={"fft_dc": 1, "fft_dc_bwd": 1})
                 marked = net.record_update(img_full, img_aux, warmup=1, restore=False, timer=timer)
                 graph = marked
                 torch.cuda.synchronize()
