@@ -346,6 +346,11 @@ def main(argv=None):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}")
     if args.launch_test:
         return launch_test(args)
+    # The contract is ONE line on stdout.  Libraries write there too (RCCL prints its version banner to the C-level stdout, and
+    # flushes it at exit, i.e. AFTER the JSON line): keep the real stdout aside for the line and send everything else to stderr.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -649,7 +654,7 @@ def main(argv=None):
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)
-        print(json.dumps(out))
+        print(json.dumps(out), file=line_out, flush=True)      # (flushed before the process group is torn down)
     if dist is not None:
         dist.destroy_process_group()
 

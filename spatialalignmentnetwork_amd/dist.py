@@ -34,6 +34,8 @@ def init(backend: str, device=None, allow_fallback: bool = False):
     if world <= 1 and not single_rank_exchange():
         return None
     import torch.distributed as dist
+    if backend == "nccl" and device is not None:
+        prebind_streams(device)
     if world <= 1:                                 # (the hook below: a one-rank RCCL communicator on this GPU)
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
@@ -62,6 +64,28 @@ def init(backend: str, device=None, allow_fallback: bool = False):
     dist.init_process_group(backend)
     BACKEND = backend
     return dist
+
+
+def prebind_streams(device) -> None:
+    """Create the step's own streams (weight gradients, gradient exchange) and run one kernel on each BEFORE RCCL comes up.  HIP
+    binds a stream to one of its few hardware queues at first use; with the process group initialised first (what bench.py and
+    train.py do) RCCL's streams took them and the weight-gradient stream ended up sharing a queue with the main stream -- no
+    overlap left: 49.9 instead of 45.5 ms per step with the exchange not even running (round 4, scratch/rccl1_where2.py).
+    ``init()`` calls it; a program that calls ``torch.distributed.init_process_group`` itself should call it first."""
+    from . import ops
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    dev = torch.device("cuda", idx)
+    side = ops._WG["pool"].get(idx)
+    if side is None:
+        side = ops._WG["pool"][idx] = torch.cuda.Stream(device=dev)
+    comm = GradExchange._streams.get(str(dev))
+    if comm is None:
+        comm = GradExchange._streams[str(dev)] = torch.cuda.Stream(device=dev)
+    for st in (torch.cuda.current_stream(dev), side, comm):
+        with torch.cuda.stream(st):
+            torch.zeros(64, device=dev).add_(1.0)
+    torch.cuda.synchronize(dev)
 
 
 def single_rank_exchange() -> bool:
