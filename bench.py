@@ -71,10 +71,10 @@ def _host_cores():
 # A replayed step keeps ~1.8 host cores busy per rank with HIP's direct dispatch: the launching thread spins inside the runtime
 # while the launch queue is full (the tape itself takes 3 ms per step) and a runtime thread handles completions.  With
 # AMD_DIRECT_DISPATCH=0 the runtime queues commands to its own thread instead: 0.17 cores per rank, the step 7 % slower
-# (measured, profiles/r04_host_env.txt).  On a node with fewer than two cores per rank the former starves the GPUs, so the
+# (measured, profiles/r04_host_env.txt).  On a node with fewer than three cores per rank the former leaves nothing for RCCL's own threads and starves the GPUs, so the
 # setting is chosen here, before the HIP runtime loads; an explicit AMD_DIRECT_DISPATCH in the environment wins.
 _LOCAL_WORLD = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-if _LOCAL_WORLD > 1 and "AMD_DIRECT_DISPATCH" not in os.environ and _host_cores() // _LOCAL_WORLD < 2:
+if _LOCAL_WORLD > 1 and "AMD_DIRECT_DISPATCH" not in os.environ and _host_cores() // _LOCAL_WORLD < 3:
     os.environ["AMD_DIRECT_DISPATCH"] = "0"
 DISPATCH = "runtime thread (AMD_DIRECT_DISPATCH=0)" if os.environ.get("AMD_DIRECT_DISPATCH") == "0" else "direct"
 
