@@ -1196,6 +1196,9 @@ class wgrad_overlap:
     def __exit__(self, *exc):
         side = _WG["stream"]
         if side is not None:
+            if exc and exc[0] is not None:      # the step failed: its queued weight gradients are dropped, not launched
+                _WG["pending"] = []
+                _WG["pending_ptrs"] = set()
             _flush_pending()
             if _WG["defer"]:
                 wgrad_flush()
