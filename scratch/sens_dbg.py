@@ -25,8 +25,8 @@ def grads(net):
 if os.environ.get("PREAMBLE", "1") == "1":
     # what tests/test_hip_parity_r3.py::test_amax_pool_resets_on_an_unindexed_device leaves behind
     ops.AMAX.reset(torch.device("cuda"))
-    rec_ = ops.AMAX.next(torch.device("cuda")); rec_.fill_(0x7F000000); ops.AMAX.reset(torch.device("cuda"))
-    rec_ = ops.AMAX.next(DEV); rec_.fill_(0x7F000000); ops.AMAX.reset("cuda")
+    rec_ = ops.AMAX.next(torch.device("cuda")); rec_ is not None and rec_.fill_(0x7F000000); ops.AMAX.reset(torch.device("cuda"))
+    rec_ = ops.AMAX.next(DEV); rec_ is not None and rec_.fill_(0x7F000000); ops.AMAX.reset("cuda")
     f0, a0 = synth.phantom_pair(2, 1, 32, 32, seed=40)
     for dev in (torch.device("cuda"), torch.device(DEV)):
         cfg0 = basemodel.Config(sparsity=0.25, lr=1e-4, shape=32, coils=1, reg="Rec", mask="equispaced", weight_smooth=1000.0, weight_gan=0.0,
