@@ -35,7 +35,7 @@ void san_wgrad_set_parts(int parts);             // san_wgrad_bf16.hip
 // san_conv_stream.hip: the persistent form for the high-resolution few-channel layers (fp16-format weights)
 int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
                         const void* w_packed, int nblkp, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
-                        const void* amax, int n, int h, int w, void* stream);
+                        const void* amax, int n, int h, int w, void* stream, int nprt);
 
 // Tuning switches, both measured and left off (scratch/README.md, round 2): HALFX = the K-loop's activation operand reads run
 // half a K-step ahead (two of a wave's four pixel blocks per set: 32 operand registers fewer) -- neutral, the register peak is
@@ -1319,10 +1319,12 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     SAN_CHECK_ARG(a.fmt != 2 || g_conv_np == 1, "fp8-format weights are for the one-part mode only (san_set_conv_precision(1))");
     a.amax = a.fmt == 1 ? static_cast<const uint32_t*>(amax) : nullptr;
     a.f8_tail = a.fmt == 2 ? reinterpret_cast<const float*>(static_cast<const uint16_t*>(w_packed) + p.packed_elems) : nullptr;
-    if (ks == 3 && a.fmt == 1 && g_conv_np == 3 && !shuffle && g_b16_mb < 0 && g_b16_wd < 0 &&
+    // the persistent form: two fp16 parts (fp32-equivalent mode) or one bf16 part (cout 18 / 36: the network's layers)
+    const bool stream_f16 = a.fmt == 1 && g_conv_np == 3, stream_bf1 = a.fmt == 0 && g_conv_np == 1 && (cout == 18 || cout == 36);
+    if (ks == 3 && (stream_f16 || stream_bf1) && !shuffle && g_b16_mb < 0 && g_b16_wd < 0 &&
         san_conv_stream_eligible(n, h, w, cin, cout, x_ctot))
         return san_conv_stream_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, p.nblkp, bias, y, y_ctot, y_coff, cout,
-                                   part_stats, a.amax, n, h, w, stream);
+                                   part_stats, a.amax, n, h, w, stream, stream_f16 ? 2 : 1);
     a.dbg = g_b16_dbg;
     a.shuffle = shuffle;
     a.bias = bias;

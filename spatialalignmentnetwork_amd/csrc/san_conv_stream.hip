@@ -38,9 +38,12 @@ typedef float fl2 __attribute__((ext_vector_type(2)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((ext_vector_type(8))) _Float16 h8;
 typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
 union Frag {
     uint4 u;
     h8 h;
+    bf8 v;
 };
 
 struct SArgs {
@@ -75,6 +78,10 @@ __device__ __forceinline__ uint32_t cvt_pk_h(float f0, float f1) {
     const fl2 v = {f0, f1};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hf2));
 }
+__device__ __forceinline__ uint32_t cvt_pk_bf(float f0, float f1) {
+    const fl2 v = {f0, f1};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+}
 // a = a1 + a2 with a1 = fp16(a), a2 = fp16(a - a1) (san_conv_bf16.hip: split2h_pair)
 __device__ __forceinline__ void split2h_pair(float f0, float f1, uint32_t& p1, uint32_t& p2) {
     p1 = cvt_pk_h(f0, f1);
@@ -101,12 +108,14 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 // MBF full blocks of 16 output channels + (REM > 0) one partial block of REM channels; OCC = resident waves per SIMD the
 // register allocation aims at
-template <int MBF, int REM, int OCC>
+// NPRT = 2: two fp16 parts per operand, three products per MAC (the fp32-equivalent mode); NPRT = 1: ONE bf16 part, one product
+// (san_set_conv_precision(1): BASELINE configs[1] as written; the packed image's leading bf16 part, activations rounded to bf16)
+template <int MBF, int REM, int OCC, int NPRT = 2>
 __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) {
     constexpr int MB = MBF + (REM > 0 ? 1 : 0);
     constexpr int RS = MBF * 1024 + (REM > 0 ? REM * 64 + 16 : 0);      // LDS bytes of one (step, part) weight region
     constexpr int RSL = RS / 16;                                        // ... in 16-byte slots
-    constexpr int NSLOT = kSteps * 2 * RSL;                             // slots of one chunk's weight image
+    constexpr int NSLOT = kSteps * NPRT * RSL;                          // slots of one chunk's weight image
     constexpr int NWI = (NSLOT + 63) / 64;                              // DMA instructions per chunk
     constexpr int NWK = (NWI + kT / 64 - 1) / (kT / 64);                // ... per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -201,7 +210,7 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
         wok[k] = q < NSLOT;
         const int qq = min(q, NSLOT - 1);
         const int r = qq / RSL, j = qq - r * RSL;
-        const int step = r >> 1, part = r & 1;
+        const int step = r / NPRT, part = r - step * NPRT;
         int m, l;
         if (j < MBF * 64) {
             m = j >> 6;
@@ -266,7 +275,7 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
     // The partial block's products (x hi, w hi) and (x hi, w lo) share ONE MFMA: columns 0 .. REM-1 of its weight operand are the
     // channels' hi parts, columns REM .. 2 REM-1 their lo parts (read from the part-1 region: + RS), the rest the zero slot; the
     // epilogue adds column c + REM into column c.  2 instead of 3 MFMAs per K-step and pixel block for those channels.
-    const int wl_mix = REM > 0 ? (nn < REM ? wl_rem : (nn < 2 * REM ? RS + MBF * 1024 + (kg * REM + nn - REM) * 16 : MBF * 1024 + REM * 64)) : 0;
+    const int wl_mix = (REM > 0 && NPRT == 2) ? (nn < REM ? wl_rem : (nn < 2 * REM ? RS + MBF * 1024 + (kg * REM + nn - REM) * 16 : MBF * 1024 + REM * 64)) : 0;
     static_assert(2 * REM <= 16, "hi and lo columns of the partial block must fit one MFMA");
 
     f4 acc[MB][4];
@@ -301,14 +310,17 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
                         const float a1 = __builtin_fmaf(raw[i + 1], i < 4 ? sc0[i + 1] : sc1[i - 3], i < 4 ? sh0[i + 1] : sh1[i - 3]);
                         const float v0 = __builtin_amdgcn_fmed3f(a0, a0 * a.in_slope, lrelu_c);
                         const float v1 = __builtin_amdgcn_fmed3f(a1, a1 * a.in_slope, lrelu_c);
-                        split2h_pair(v0, v1, q1[i >> 1], q2[i >> 1]);
+                        if constexpr (NPRT == 2)
+                            split2h_pair(v0, v1, q1[i >> 1], q2[i >> 1]);
+                        else
+                            q1[i >> 1] = cvt_pk_bf(v0, v1);
                     }
                 }
                 *reinterpret_cast<uint4*>(dst) = make_uint4(q1[0], q1[1], q1[2], q1[3]);
-                *reinterpret_cast<uint4*>(dst + kPartB) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
+                if constexpr (NPRT == 2) *reinterpret_cast<uint4*>(dst + kPartB) = make_uint4(q2[0], q2[1], q2[2], q2[3]);
             } else {
                 *reinterpret_cast<uint4*>(dst) = make_uint4(0u, 0u, 0u, 0u);
-                *reinterpret_cast<uint4*>(dst + kPartB) = make_uint4(0u, 0u, 0u, 0u);
+                if constexpr (NPRT == 2) *reinterpret_cast<uint4*>(dst + kPartB) = make_uint4(0u, 0u, 0u, 0u);
             }
         };
         if (!(a.abl & 2)) {
@@ -342,21 +354,21 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
         // of a step: [m][0] = hi parts, [m][1] = lo parts of the full blocks; the partial block has [MBF][0] = hi and [MBF][1] =
         // the mixed hi | lo operand (wl_mix)
         if (!(a.abl & 4)) {
-            Frag wa[2][MB][2], xa[2][4][2];
-            auto load_w = [&](int s, Frag (&wq)[MB][2]) {
+            Frag wa[2][MB][NPRT], xa[2][4][NPRT];
+            auto load_w = [&](int s, Frag (&wq)[MB][NPRT]) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p)
-                        wq[m][p].u = *reinterpret_cast<const uint4*>(lds_w + (m < MBF ? (s * 2 + p) * RS + m * 1024 + wl_full
-                                                                                        : s * 2 * RS + (p == 0 ? wl_rem : wl_mix)));
+                    for (int p = 0; p < NPRT; ++p)
+                        wq[m][p].u = *reinterpret_cast<const uint4*>(lds_w + (m < MBF ? (s * NPRT + p) * RS + m * 1024 + wl_full
+                                                                                        : s * NPRT * RS + (p == 0 ? wl_rem : wl_mix)));
             };
-            auto load_x = [&](int s, Frag (&xq)[4][2]) {
+            auto load_x = [&](int s, Frag (&xq)[4][NPRT]) {
                 const int to = tapoff[s];
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
+                    for (int p = 0; p < NPRT; ++p) xq[b][p].u = *reinterpret_cast<const uint4*>(lds_a + p * kPartB + boff[b] + to);
             };
             load_w(0, wa[0]);
             load_x(0, xa[0]);
@@ -366,28 +378,36 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
                     load_w(s + 1, wa[(s + 1) & 1]);
                     load_x(s + 1, xa[(s + 1) & 1]);
                 }
-                // (x hi, w hi | mixed), (x lo, w hi), (x hi, w lo of the full blocks)
+                if constexpr (NPRT == 1) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+                    for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][0].h, wa[s & 1][m][m < MBF ? 0 : 1].h, acc[m][b], 0, 0, 0);
+                        for (int b = 0; b < 4; ++b)
+                            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[s & 1][b][0].v, wa[s & 1][m][0].v, acc[m][b], 0, 0, 0);
+                } else {
+                    // (x hi, w hi | mixed), (x lo, w hi), (x hi, w lo of the full blocks)
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+                    for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][1].h, wa[s & 1][m][0].h, acc[m][b], 0, 0, 0);
+                        for (int b = 0; b < 4; ++b)
+                            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][0].h, wa[s & 1][m][m < MBF ? 0 : NPRT - 1].h, acc[m][b], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < MBF; ++m)
+                    for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][0].h, wa[s & 1][m][1].h, acc[m][b], 0, 0, 0);
+                        for (int b = 0; b < 4; ++b)
+                            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][NPRT - 1].h, wa[s & 1][m][0].h, acc[m][b], 0, 0, 0);
+#pragma unroll
+                    for (int m = 0; m < MBF; ++m)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xa[s & 1][b][0].h, wa[s & 1][m][NPRT - 1].h, acc[m][b], 0, 0, 0);
+                }
             }
         }
 
         // ---- last chunk of the tile: epilogue.  acc[m][b][r] = channel 16 m + nn at tile pixel 64 wave + 16 b + 4 kg + r
         if (chunk == a.chunks - 1) {
-            if constexpr (REM > 0) {                    // column c + REM (x hi . w lo) into column c: a row shift by REM lanes
+            if constexpr (REM > 0 && NPRT == 2) {       // column c + REM (x hi . w lo) into column c: a row shift by REM lanes
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     // (scalars, each shift behind an opaque barrier: on the vector elements hipcc 7.0 shifted element 0 four times)
@@ -476,19 +496,19 @@ struct StreamEnv {
     }
 } g_stream_env;
 
-size_t stream_lds_bytes(int cin, int cout) {
+size_t stream_lds_bytes(int cin, int cout, int nprt = 2) {
     const int chunks = san_cdiv(cin, kCKC);
     const int mbf = cout / 16, rem = cout % 16;
     const size_t rs = (size_t)mbf * 1024 + (rem ? rem * 64 + 16 : 0);
-    return 2 * (size_t)kPartB + (size_t)chunks * 192 + (size_t)kSteps * 2 * rs;        // operand image, affine table, one chunk of weights
+    return 2 * (size_t)kPartB + (size_t)chunks * 192 + (size_t)kSteps * nprt * rs;     // operand image, affine table, one chunk of weights
 }
 
-template <int MBF, int REM, int OCC>
+template <int MBF, int REM, int OCC, int NPRT = 2>
 int launch_stream(const SArgs& a, hipStream_t s) {
-    const size_t lds = stream_lds_bytes(a.cin, a.cout);
+    const size_t lds = stream_lds_bytes(a.cin, a.cout, NPRT);
     static size_t configured = 0;
     if (lds > configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel<MBF, REM, OCC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel<MBF, REM, OCC, NPRT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the stream convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -501,7 +521,7 @@ int launch_stream(const SArgs& a, hipStream_t s) {
     int grid = 256 * per_cu;
     const int need = ((a.total + 7) / 8) * 8;           // (a multiple of 8: the tile ranges are per XCD)
     if (grid > need) grid = need;
-    hipLaunchKernelGGL((conv3x3_stream_kernel<MBF, REM, OCC>), dim3(grid), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv3x3_stream_kernel<MBF, REM, OCC, NPRT>), dim3(grid), dim3(kT), lds, s, a);
     return SAN_OK;
 }
 
@@ -529,7 +549,7 @@ int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot)
 
 int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
                         const void* w_packed, int nblkp, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
-                        const void* amax, int n, int h, int w, void* stream) {
+                        const void* amax, int n, int h, int w, void* stream, int nprt) {
     SArgs a{};
     a.x = x;
     a.in_scale = in_scale;
@@ -567,13 +587,21 @@ int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const f
     SAN_CHECK_ARG((reinterpret_cast<uintptr_t>(y) & 15) == 0, "stream convolution: output must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    switch (cout) {
-        case 16: rc = launch_stream<1, 0, 2>(a, s); break;
-        case 18: rc = launch_stream<1, 2, 2>(a, s); break;
-        case 32: rc = launch_stream<2, 0, 2>(a, s); break;
-        case 36: rc = launch_stream<2, 4, 2>(a, s); break;
-        case 48: rc = launch_stream<3, 0, 2>(a, s); break;
-        default: san_set_error("stream convolution: unsupported cout %d", cout); return SAN_E_UNSUPPORTED;
+    if (nprt == 1) {                                    // one bf16 part (the layers of the network only)
+        switch (cout) {
+            case 18: rc = launch_stream<1, 2, 2, 1>(a, s); break;
+            case 36: rc = launch_stream<2, 4, 2, 1>(a, s); break;
+            default: san_set_error("stream convolution: unsupported cout %d for the one-part form", cout); return SAN_E_UNSUPPORTED;
+        }
+    } else {
+        switch (cout) {
+            case 16: rc = launch_stream<1, 0, 2>(a, s); break;
+            case 18: rc = launch_stream<1, 2, 2>(a, s); break;
+            case 32: rc = launch_stream<2, 0, 2>(a, s); break;
+            case 36: rc = launch_stream<2, 4, 2>(a, s); break;
+            case 48: rc = launch_stream<3, 0, 2>(a, s); break;
+            default: san_set_error("stream convolution: unsupported cout %d", cout); return SAN_E_UNSUPPORTED;
+        }
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();

@@ -252,6 +252,47 @@ def test_stream_convolution_repeated_launches_are_deterministic(S):
     assert torch.equal(y0, y1) and torch.equal(p0, p1)
 
 
+
+@pytest.mark.parametrize("cin,cout", [(18, 18), (36, 18), (18, 36), (72, 36)])
+def test_stream_convolution_one_bf16_part(S, cin, cout):
+    """The persistent kernel's one-part form (san_set_conv_precision 'bf16': BASELINE configs[1] as written): activations and
+    weights rounded to bf16, one product per MAC, fp32 accumulation -- against float64 on the SAME rounded operands (<= 2e-6:
+    only the accumulation order differs) and against the one-tile kernel in the same mode; forward with lazy affine +
+    statistics, and the data gradient."""
+    ops = S.ops
+    n, h, w = 2, 160, 160
+    xb = g(philox("s1.x", (n, cin, h, w)))
+    wt = g(philox("s1.w", (cout, cin, 3, 3))) * 0.1
+    sc, sh = g(philox("s1.sc", (n, cin), lo=0.5, hi=1.5)), g(philox("s1.sh", (n, cin)))
+    xa = ops.Act(xb, 0, cin, sc, sh, 0.2)
+    with ops.conv_precision("bf16"):
+        assert S.lib.lib().query("san_conv_stream_eligible", n, h, w, cin, cout, cin) == 1
+        y = torch.full((n, cout, h, w), float("nan"), device=DEV)
+        part = ops.conv2d(xa, wt, None, ops.full(y), stats=True)
+        torch.cuda.synchronize()
+        S.lib.lib().call("san_conv_stream_set_tuning", 0)
+        try:
+            y2 = torch.full((n, cout, h, w), float("nan"), device=DEV)
+            ops.conv2d(xa, wt, None, ops.full(y2), stats=True)
+            torch.cuda.synchronize()
+        finally:
+            S.lib.lib().call("san_conv_stream_set_tuning", 1)
+        gy = g(philox("s1.g", (n, cout, h, w))) * 1e-6
+        dx = torch.full((n, cin, h, w), float("nan"), device=DEV)
+        ops.conv2d_dgrad(ops.full(gy), wt, ops.full(dx))
+        torch.cuda.synchronize()
+    a = xb.double() * sc.double()[:, :, None, None] + sh.double()[:, :, None, None]
+    a = torch.where(a >= 0, a, a * 0.2).float().bfloat16().double()
+    want = torch.nn.functional.conv2d(a, wt.bfloat16().double(), padding=1)
+    err = ((y.double() - want).norm() / want.norm()).item()
+    assert err < 2e-6, err
+    assert ((y.double() - y2.double()).norm() / want.norm()).item() < 1e-6
+    cnt, mean = part[..., 0].double(), part[..., 1].double()
+    assert torch.all(cnt.sum(-1) == h * w)
+    assert ((cnt * mean).sum(-1) / cnt.sum(-1) - y.double().mean((2, 3))).abs().max().item() < 1e-6
+    wantg = torch.nn.functional.conv_transpose2d(gy.bfloat16().double(), wt.bfloat16().double(), padding=1)
+    assert ((dx.double() - wantg).norm() / wantg.norm()).item() < 2e-6
+
 # ------------------------------------------------------------------------------------------- bench batch, eval mode
 def test_eval_bench_batch_n8_golden(S):
     """the bench batch in EVAL mode -- N = 8 slices of 320 x 320, 12 cascades, chans 18 -- against the
