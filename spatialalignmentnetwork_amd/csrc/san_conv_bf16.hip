@@ -1112,8 +1112,9 @@ int pick_mb(int cout, int tiles) {
 int pick_mb_f16(int cin, int cout, int tiles) {
     const int nblk = san_cdiv(cout, 16);
     if (nblk <= 2 || cin >= 64) return 2;
-    for (int mb = 4; mb > 2; --mb)
-        if (mb <= nblk && tiles * san_cdiv(nblk, mb) >= 768) return mb;
+    // (round 4, re-measured on the final kernels: four blocks per workgroup lose everywhere -- 36->72 @160^2, the data gradient of
+    // the decoder's 72->36: 97 us at 4, 74 at 2; 32->64 @160^2: 59 vs 50 -- three win only where they cover the layer exactly)
+    if (nblk == 3 && tiles >= 768) return 3;
     return 2;
 }
 
