@@ -1043,10 +1043,14 @@ struct B16Env {
 // the chunks (at least 2, at most ~4 workgroups per CU in the launch) and writing a partial output; splitk_reduce_kernel then adds the partials in a fixed order,
 // applies the bias, stores and takes the statistics.  (An in-kernel last-arriver join was tried first: its device-scope
 // fences write back / invalidate the whole L2 of every XCD and made the layer 1.7x SLOWER.)
-int splitk_parts(int groups, int chunks, int ks, int hw) {
+// out_elems = n * cout * hw: every part writes (and the join reads) that many partial sums, so on a large output a split pays only
+// while each part keeps a long chain of chunks (round 4, re-measured: 144 -> 288 @40^2 59 us split in two, 40 unsplit; 144 -> 144
+// @40^2 38 / 35; 288 -> 144 @40^2 stays split: 54 / 61; the 20^2 layers, under a million outputs, keep up to four parts)
+int splitk_parts(int groups, int chunks, int ks, int hw, long long out_elems) {
     if (ks != 3 || hw > 4096) return 1;
+    const int min_chain = out_elems > 1000000ll ? 4 : 2;
     int S = 1;
-    while (S * 2 <= g_b16_splitk && groups * S * 2 <= g_b16_splitcap && chunks / (S * 2) >= 2) S *= 2;
+    while (S * 2 <= g_b16_splitk && groups * S * 2 <= g_b16_splitcap && chunks / (S * 2) >= min_chain) S *= 2;
     return S;
 }
 
@@ -1354,7 +1358,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.nblkp = p.nblkp;
     a.S = 1;
     if (ws && !shuffle) {
-        const int S = splitk_parts(a.tiles_x * a.tiles_y * n * a.cgs, p.chunks, ks, h * w);
+        const int S = splitk_parts(a.tiles_x * a.tiles_y * n * a.cgs, p.chunks, ks, h * w, (long long)n * cout * h * w);
         if (S > 1 && ws_bytes >= splitk_bytes(S, n, cout, h * w)) {
             a.S = S;
             a.ws = static_cast<float*>(ws);
@@ -1458,7 +1462,7 @@ size_t san_conv_bf16x3_ws_bytes(int n, int h, int w, int cin, int cout, int ks) 
         int mb = f ? pick_mb_f16(cin, cout, tg.tiles_x * tg.tiles_y * n) : pick_mb(cout, tg.tiles_x * tg.tiles_y * n);
         if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
         const int groups = tg.tiles_x * tg.tiles_y * n * san_cdiv(san_cdiv(cout, 16), mb);
-        const int Sf = splitk_parts(groups, p.chunks, ks, h * w);
+        const int Sf = splitk_parts(groups, p.chunks, ks, h * w, (long long)n * cout * h * w);
         if (Sf > S) S = Sf;
     }
     return S > 1 ? splitk_bytes(S, n, cout, h * w) : 0;
