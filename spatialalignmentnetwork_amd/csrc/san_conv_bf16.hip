@@ -1115,10 +1115,13 @@ int pick_mb(int cout, int tiles) {
 // gives >= 768 workgroups (256 CUs x 3), and 2 whenever the reduction is deep enough (cin >= 64) for the matrix part to dominate.
 int pick_mb_f16(int cin, int cout, int tiles) {
     const int nblk = san_cdiv(cout, 16);
+    // three blocks where they cover the layer exactly and two would compute a block that does not exist (cout 36 / 48: 4 blocks
+    // for 3; cout 144: 10 for 9): 72->36 @80^2 23.5 -> 20.5 us, 72->144 @80^2 50 -> 48, 144->144 @40^2 34.8 -> 32.6 (not the tiny
+    // 144->144 @20^2: 20 -> 23)
+    if (nblk == 3 || (nblk == 9 && (tiles >= 32 || cin >= 288))) return 3;
     if (nblk <= 2 || cin >= 64) return 2;
     // (round 4, re-measured on the final kernels: four blocks per workgroup lose everywhere -- 36->72 @160^2, the data gradient of
     // the decoder's 72->36: 97 us at 4, 74 at 2; 32->64 @160^2: 59 vs 50 -- three win only where they cover the layer exactly)
-    if (nblk == 3 && tiles >= 768) return 3;
     return 2;
 }
 
