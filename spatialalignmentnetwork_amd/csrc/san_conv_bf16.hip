@@ -1354,7 +1354,9 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.th = tg.th;
     a.hp = tg.tw + 2;
     a.npx = (tg.tw + 2) * (tg.th + 2);
-    int mb = a.fmt >= 1 && ks == 3 ? pick_mb_f16(cin, cout, a.tiles_x * a.tiles_y * n) : pick_mb(cout, a.tiles_x * a.tiles_y * n);
+    // (the one-part bf16 mode has even less matrix work per chunk than the fp16-part format: the same small-workgroup choice --
+    // 72->144 @80^2 45.7 us with pick_mb's five blocks, 28-34 with two / three; 36->72 @160^2 66.6 -> 41.8)
+    int mb = (a.fmt >= 1 || g_conv_np == 1) && ks == 3 ? pick_mb_f16(cin, cout, a.tiles_x * a.tiles_y * n) : pick_mb(cout, a.tiles_x * a.tiles_y * n);
     if (g_b16_mb >= 2 && g_b16_mb <= 5 && g_b16_mb <= san_cdiv(cout, 16)) mb = g_b16_mb;
     a.cgs = san_cdiv(san_cdiv(cout, 16), mb);
     a.chunks = p.chunks;
