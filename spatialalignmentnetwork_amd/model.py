@@ -378,8 +378,10 @@ class CSModel(BaseModel):
         if snap is not None:
             self._restore_state(snap)
             torch.cuda.synchronize()
+        pack_keep = []
         for reg in (ops.PACKS, ops.PACKS16):   # job tables are uploaded now, not inside the capture
             reg.ensure_table(self.device)
+            pack_keep.append((reg.table, [j["packed"] for j in reg.order]))    # (the captured packing launch writes all of them)
         from . import dist as sdist
 
         def _capture(fn):
@@ -400,7 +402,9 @@ class CSModel(BaseModel):
         split = dist is not None and (sdist.backend() != "nccl" or os.environ.get("SAN_CAPTURE_COLLECTIVES", "0") != "1")
         if not split:
             try:
-                return CapturedStep([_capture(_whole)], None, "single-graph" + (" (RCCL all-reduce captured)" if dist is not None else ""))
+                step = CapturedStep([_capture(_whole)], None, "single-graph" + (" (RCCL all-reduce captured)" if dist is not None else ""))
+                step.keep = pack_keep
+                return step
             except RuntimeError:
                 if dist is None:
                     raise
@@ -420,7 +424,9 @@ class CSModel(BaseModel):
             g1, g2 = _capture(_front), _capture(_back)
         finally:
             self._split_capture = False
-        return CapturedStep([g1, g2], self._exchange_eager, "two graphs around an eager exchange")
+        step = CapturedStep([g1, g2], self._exchange_eager, "two graphs around an eager exchange")
+        step.keep = pack_keep
+        return step
 
     @_no_auto
     def record_update(self, img_full, img_aux=None, warmup: int = 2, restore: bool = True, timer=None):
@@ -488,6 +494,11 @@ class CSModel(BaseModel):
         for reg in (ops.PACKS, ops.PACKS16):   # the pack job tables are uploaded now (a host-to-device copy), not inside the step
             reg.ensure_table(self.device)
             keep.append(reg.table)              # the recorded packing launch reads THIS table: it must outlive a later re-registration
+            # ... and it WRITES every packed image the table names, other live models' included: those buffers stay allocated as
+            # long as this recording lives.  (Before round 4's end only the table was kept: once another model was freed and its
+            # jobs pruned, a replay wrote its packed weights into memory the allocator had handed to somebody else -- the likely
+            # source of the one-in-twenty bit-identity failures in long test processes.)
+            keep.append([j["packed"] for j in reg.order])
 
         class _Watch(TorchDispatchMode):
             """Keeps every tensor the step creates alive (their addresses are in the recording) and notes torch operations

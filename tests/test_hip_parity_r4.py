@@ -473,3 +473,35 @@ def test_gradient_exchange_runs_on_rccl_with_one_rank(S, tmp_path):
     assert los[0] > los[1], f"cascade slices not in reverse order: {sl}"
     assert a["capture_mode"] == "two graphs around an eager exchange", a["capture_mode"]
     assert all(torch.equal(a["state"][k], b["state"][k]) for k in b["state"]), "the one-rank exchange changed the step"
+
+
+def test_recording_keeps_every_packed_image_it_rewrites(S):
+    """A recorded step's weight-packing launch re-packs EVERY job of the table it was recorded with -- other live models' too.  When
+    such a model is freed later and its jobs are pruned, the packed buffers must stay allocated for as long as the recording lives:
+    otherwise a replay writes packed weights into memory the allocator has handed to somebody else."""
+    import gc
+    ops = S.ops
+    n, c, h, w = 1, 1, 32, 32
+    other = _model(S, w, c, chans=4).eval()
+    xf, xa = (g(t) for t in S.synth.phantom_pair(n, c, h, w, seed=5))
+    with torch.no_grad():
+        other.set_input(xf, xa)
+        other.loss_all = 0
+        other.forwardT()
+        other.forwardR()                                    # `other`'s weights are registered with the pack registries
+    net = _model(S, w, c, chans=4).eval()
+    rec = net.record_forward(xf.clone(), xa.clone())
+    ptrs = {j["packed"].data_ptr() for reg in (ops.PACKS, ops.PACKS16) for j in reg.order}
+    assert ptrs, "nothing registered"
+    kept = {t.data_ptr() for item in rec.keep if isinstance(item, list) for t in item if isinstance(t, torch.Tensor)}
+    assert ptrs <= kept, "the recording does not hold every packed image its packing launch writes"
+    del other
+    gc.collect()
+    for reg in (ops.PACKS, ops.PACKS16):
+        reg._prune()                                        # `other`'s jobs are gone from the registries ...
+    live = {j["packed"].data_ptr() for reg in (ops.PACKS, ops.PACKS16) for j in reg.jobs.values()}
+    assert len(live) < len(ptrs)
+    junk = [torch.full((1 << 18,), 7.0, device=DEV) for _ in range(32)]      # ... and the allocator is asked for fresh blocks
+    rec.replay()
+    torch.cuda.synchronize()
+    assert all(bool((t == 7.0).all()) for t in junk), "a replay wrote into memory that no longer belongs to a packed image"
