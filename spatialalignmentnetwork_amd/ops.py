@@ -620,6 +620,13 @@ class _PackRegistry:
         """Re-pack every live job on `device` in one launch."""
         self.ensure_table(device)
         if self.order:
+            if _lib.KEEP is not None:
+                # inside a recording: the recorded launch reads THIS job table and writes THESE packed images at every replay.  A
+                # table rebuilt during the recorded step itself (a registered weight of some other model died just then) used to
+                # be held by the registry only -- after the next rebuild a replay read whatever the allocator had put there
+                # (typically the NEW table, with the OLD job count: some images silently not re-packed, weights one step stale)
+                _lib.KEEP.append(self.table)
+                _lib.KEEP.append([j["packed"] for j in self.order])
             self._batch()
         for j in self.order:
             w = j["wref"]()
