@@ -199,6 +199,43 @@ def _creal(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
 _ARENA_PTRS = set()
 
 
+# Debugging hook (SAN_ARENA_GUARD=1, or ops.ARENA_GUARD[0] = True before the buffers are made): every arena buffer sits between two
+# 4 KiB bands of a byte pattern (SAN_ARENA_GUARD_BYTE, hex: FF makes the bands NaN, so that a kernel that READS past its input and
+# uses the value shows up in the results); arena_guard_report() names the buffers whose bands were written.  A kernel that stores
+# past the end (or in front) of its output does no visible harm while the step's streams run one after the other, and corrupts a
+# neighbour's data once they overlap.
+ARENA_GUARD = [os.environ.get("SAN_ARENA_GUARD", "0") == "1"]
+_GUARD_BYTES, _GUARD_PATTERN = 4096, int(os.environ.get("SAN_ARENA_GUARD_BYTE", "A5"), 16)
+_GUARDS = []
+
+
+def _guarded(key, shape, device, dtype, zero: bool) -> torch.Tensor:
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    nbytes = numel * torch.empty((), dtype=dtype).element_size()
+    raw = torch.full((nbytes + 2 * _GUARD_BYTES,), _GUARD_PATTERN, dtype=torch.uint8, device=device)
+    t = raw[_GUARD_BYTES:_GUARD_BYTES + nbytes].view(dtype).view(tuple(int(d) for d in shape))
+    if zero:
+        t.zero_()
+    _GUARDS.append((key, raw, nbytes))
+    return t
+
+
+def arena_guard_report():
+    """[(buffer name, shape), 'front' | 'back', number of overwritten guard bytes, byte offset of the nearest one from the buffer's
+    start (negative) / end] for every guarded arena buffer whose bands no longer hold the pattern."""
+    out = []
+    torch.cuda.synchronize()
+    for key, raw, nbytes in _GUARDS:
+        for side, band in (("front", raw[:_GUARD_BYTES]), ("back", raw[_GUARD_BYTES + nbytes:])):
+            hit = (band != _GUARD_PATTERN).nonzero()
+            if hit.numel():
+                first = int(hit[0]) if side == "back" else int(hit[-1]) - _GUARD_BYTES
+                out.append((key[:2], side, int(hit.numel()), first))
+    return out
+
+
 class Arena:
     def __init__(self):
         self._bufs: Dict[Tuple, torch.Tensor] = {}
@@ -209,7 +246,10 @@ class Arena:
         key = (name, shape if type(shape) is tuple else tuple(shape), _DEV_KEYS.get(device) or _dev_key(device), dtype)
         t = self._bufs.get(key)
         if t is None:
-            t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
+            if ARENA_GUARD[0]:
+                t = _guarded(key, shape, device, dtype, zero)
+            else:
+                t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
             self._bufs[key] = t
             _ARENA_PTRS.add(t.data_ptr())
         elif not _no_wait and (_WG["busy"] or _WG["pending_ptrs"]):
@@ -223,7 +263,7 @@ class Arena:
         if t is None or t.numel() < nbytes:
             if t is not None:
                 self._retired.append(t)         # a side-stream kernel may still be using it: never hand its memory back
-            t = torch.empty(int(nbytes), device=device, dtype=torch.uint8)
+            t = _guarded(key, (int(nbytes),), device, torch.uint8, False) if ARENA_GUARD[0] else torch.empty(int(nbytes), device=device, dtype=torch.uint8)
             self._bufs[key] = t
         return t
 

@@ -505,3 +505,31 @@ def test_recording_keeps_every_packed_image_it_rewrites(S):
     rec.replay()
     torch.cuda.synchronize()
     assert all(bool((t == 7.0).all()) for t in junk), "a replay wrote into memory that no longer belongs to a packed image"
+
+
+@pytest.mark.parametrize("c,h,w", [(1, 48, 80), (3, 80, 112)])
+def test_no_kernel_writes_outside_its_arena_buffers(S, c, h, w):
+    """Guard bands around every arena buffer (ops.ARENA_GUARD): a full training step -- odd plane sizes at the lower levels, the
+    W % 4 != 0 forms, split-K scratch, rotating dy copies -- leaves all of them intact; a deliberate store past a buffer's end is
+    reported.  (A store outside a buffer is harmless while the step's streams run one after the other and corrupts a neighbour
+    once they overlap: the check the stream-overlap work of round 4 needed.)"""
+    ops = S.ops
+    before = len(ops._GUARDS)
+    ops.ARENA_GUARD[0] = True
+    try:
+        net = _model(S, w, c, chans=4).train()
+        xf, xa = (g(t) for t in S.synth.phantom_pair(1, c, h, w, seed=11))
+        net.auto_record = False
+        for _ in range(2):
+            net.set_input(xf, xa)
+            net.update()
+        assert len(ops._GUARDS) > before + 20, "the step's arena buffers were not guarded"
+        assert ops.arena_guard_report() == []
+        key, raw, nbytes = ops._GUARDS[-1]
+        raw[ops._GUARD_BYTES + nbytes + 3] = 0            # one byte past the buffer's end
+        rep = ops.arena_guard_report()
+        assert len(rep) == 1 and rep[0][1:] == ("back", 1, 3), rep
+        raw[ops._GUARD_BYTES + nbytes + 3] = ops._GUARD_PATTERN
+    finally:
+        ops.ARENA_GUARD[0] = False
+        del ops._GUARDS[before:]
