@@ -730,8 +730,9 @@ __device__ __forceinline__ void dy_store(float* __restrict__ base, int i, bf4 o,
 // InstanceNorm + LeakyReLU backward of a whole (sample, channel) plane in ONE pass: the plane's g and y (<= V float4 per
 // thread each, 512 threads) stay in registers between the two reductions and the write of dy, so g and y are read once
 // instead of twice and there is one launch instead of two.  Planes of up to 512 * 4 * V values (V = 13: 160 x 160).
+// (SAN_NO_PK32: san_common.h -- the kernel this was found on)
 template <int V>
-__global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
+__global__ void __launch_bounds__(512) SAN_NO_PK32 act_bwd_plane_kernel(const float* __restrict__ g, int g_ctot, int g_coff,
                                                             const float* __restrict__ y, int y_ctot, int y_coff,
                                                             const float* __restrict__ sc, const float* __restrict__ sh, float slope,
                                                             float* __restrict__ dy, int d_ctot, int d_coff, int hw, unsigned* amax,
@@ -799,7 +800,7 @@ __global__ void __launch_bounds__(512) act_bwd_plane_kernel(const float* __restr
     san_amax_record<8>(amax, blockIdx.y * gridDim.x + blockIdx.x, mx);
 }
 
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads) SAN_NO_PK32
 bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
                  const float* __restrict__ sc, const float* __restrict__ sh, float slope, int c, int hw, int tiles,
                  float* __restrict__ part, const G2Src g2) {
@@ -856,7 +857,7 @@ bwd_stats_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const floa
     }
 }
 
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads) SAN_NO_PK32
 act_bwd_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
                const float* __restrict__ sc, const float* __restrict__ sh, float slope, const float* __restrict__ part,
                int tiles, int mode, float* __restrict__ dy, int d_ctot, int d_coff, int c, int hw, unsigned* amax,

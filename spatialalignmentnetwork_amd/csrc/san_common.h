@@ -47,6 +47,17 @@ __device__ __forceinline__ float san_dpp_get(float v) {
     return __builtin_bit_cast(float,
                               __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
+// Kernels that may share the compute units with another stream's MFMA kernel are compiled WITHOUT packed-fp32 instructions.
+// Measured on MI355X (scratch/two_stream_probe.py, scratch/attempts/r4_sens_overlap_notes.md): `v_pk_mul_f32 d, a[0:1], v[m1:m2]
+// op_sel:[0,1]` (both halves take m2, the HIGH register of the pair) now and then read the LOW register in the low half for the
+// last 16 lanes of a wave while a convolution kernel of another stream was resident on the same compute units -- 16 elements of
+// a plane off by exactly s * yh * (m1 - m2) in 2 of 3 launches; never when the kernel ran alone, never without the packed form.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SAN_NO_PK32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define SAN_NO_PK32
+#endif
+
 __device__ __forceinline__ float san_wave_total(float v) {
     v += san_dpp_get<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
     v += san_dpp_get<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]

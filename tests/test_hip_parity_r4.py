@@ -533,3 +533,38 @@ def test_no_kernel_writes_outside_its_arena_buffers(S, c, h, w):
     finally:
         ops.ARENA_GUARD[0] = False
         del ops._GUARDS[before:]
+
+
+def test_plane_activation_backward_is_bit_stable_beside_another_streams_convolutions(S):
+    """The one-pass InstanceNorm backward (act_bwd_plane_kernel) on one stream while data-gradient convolutions run on another,
+    with no memory in common: every launch gives the bits of the launch that ran alone.  With packed-fp32 instructions in that
+    kernel 2 of 3 launches differed on MI355X (16 elements of a plane off by s * yh * (m1 - m2): csrc/san_common.h SAN_NO_PK32,
+    scratch/two_stream_probe.py)."""
+    ops, Act = S.ops, S.ops.Act
+    torch.manual_seed(0)
+    aux = torch.cuda.Stream()
+    n, c, h, w = 15, 32, 160, 92
+    gbuf, y = torch.randn(n, c, h, w, device=DEV), torch.randn(n, c, h, w, device=DEV)
+    sc, sh = torch.rand(n, c, device=DEV) + 0.5, torch.randn(n, c, device=DEV) * 0.1
+    out = torch.empty_like(gbuf)
+    ar_v, ar_a = ops.Arena(), ops.Arena()
+    wgt = torch.randn(64, 64, 3, 3, device=DEV) * 0.05
+    dy, dx = torch.randn(1, 64, 160, 92, device=DEV), torch.empty(1, 64, 160, 92, device=DEV)
+
+    def victim():
+        ops.act_bwd(ops.full(gbuf), Act(y, 0, c, sc, sh, 0.2), ops.full(out), instance_norm=True)
+
+    with ops.use_arena(ar_v):
+        victim()
+    torch.cuda.synchronize()
+    want = out.clone()
+    bad = 0
+    for _ in range(60):
+        with ops.use_arena(ar_a):
+            for _ in range(4):
+                ops.conv2d_dgrad(ops.full(dy), wgt, ops.full(dx))
+        with torch.cuda.stream(aux), ops.use_arena(ar_v):
+            victim()
+        torch.cuda.synchronize()
+        bad += int(not torch.equal(out, want))
+    assert bad == 0, f"{bad} of 60 launches differ from the launch that ran alone"
