@@ -32,6 +32,8 @@ REC = None          # list of (callable, args, kind) while recording; kind 0 = P
 KEEP = None         # objects whose addresses were recorded (host scratch of C calls)
 IN_REC = [0]        # > 0 inside rec(): torch operations seen by the recording's dispatch mode are accounted for
 UNTRACKED = [0]     # > 0 inside untracked(): torch operations that need no replay (constants, host-side scalars)
+AUX = [None]        # the stream of the auxiliary region being recorded (ops.aux_region): a torch callable recorded inside it is
+                    # replayed with that stream current (a replay runs with the main stream current)
 
 
 def rec(fn, *args):
@@ -42,8 +44,20 @@ def rec(fn, *args):
     finally:
         IN_REC[0] -= 1
     if REC is not None:
-        REC.append((fn, args, 0))
+        aux = AUX[0]
+        if aux is not None and getattr(fn, "__self__", None).__class__.__name__ not in ("Stream", "Event", "ExternalStream"):
+            REC.append((_under_stream(aux, fn), args, 0))       # (stream / event methods name their streams themselves)
+        else:
+            REC.append((fn, args, 0))
     return out
+
+
+def _under_stream(stream, fn):
+    def run(*args):
+        with torch.cuda.stream(stream):
+            return fn(*args)
+    run.__name__ = getattr(fn, "__name__", "callable") + "@aux"
+    return run
 
 
 class untracked:

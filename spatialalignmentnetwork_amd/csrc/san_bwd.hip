@@ -929,7 +929,7 @@ dc_weight_grad_kernel(const float2* __restrict__ G, const float2* __restrict__ k
 }
 
 // gS[n,c] += sign1 * conj(r[n]) * t1[n,c] + x[n,c] * conj(gm[n]);  r, gm planar [n,2,hw]
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads) SAN_NO_PK32
 sens_grad_acc_kernel(float2* __restrict__ gS, const float* __restrict__ r, const float2* __restrict__ t1,
                      const float2* __restrict__ x, const float* __restrict__ gm, float sign1, int C, int HW) {
     const int n = blockIdx.y;
@@ -953,7 +953,7 @@ sens_grad_acc_kernel(float2* __restrict__ gS, const float* __restrict__ r, const
 
 // image-domain cascade backward (see san_dc_rows): the same sensitivity-map accumulation, and in the same pass the
 // regulariser-input gradient joins the state gradient:  gd[n,c] += gm[n] * S[n,c]   (m = sum_c conj(S_c) x_c).  gS may be null.
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads) SAN_NO_PK32
 sens_grad_prop_kernel(float2* __restrict__ gS, const float* __restrict__ r, const float2* __restrict__ t1,
                       const float2* __restrict__ x, const float* __restrict__ gm, float sign1, float2* __restrict__ gd,
                       const float2* __restrict__ S, int C, int HW) {
@@ -1134,7 +1134,7 @@ act_bwd_coef_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const f
 
 // bilinear warp backward wrt the sampling grid (zeros padding, align_corners = False):
 // g_off[n, 0/1, i, j] = sum_c g[n,c,i,j] * d out / d (x, y)   in normalised units (ix = ((x+1)W-1)/2)
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(kThreads) SAN_NO_PK32
 warp_bwd_grid_kernel(const float* __restrict__ img, const float* __restrict__ grid, const float* __restrict__ g,
                      float* __restrict__ g_off, int C, int H, int W) {
     const int n = blockIdx.y;

@@ -43,6 +43,8 @@ AUTO_RECORD = [os.environ.get("SAN_AUTO_RECORD", "1") != "0"]
 # inside VarNet.backward as each cascade's gradients become final; "single" = the whole flat buffer afterwards.
 GRAD_BUCKETS = [os.environ.get("SAN_GRAD_BUCKETS", "cascade")]
 AUTO_AFTER = 2
+SENS_OVERLAP = [os.environ.get("SAN_SENS_OVERLAP", "1") != "0"]
+_SENS_DBG = int(os.environ.get("SAN_SENS_DBG", "0"))      # 1: forward branch only, 2: backward branch only (debugging)
 
 
 def _no_auto(fn):
@@ -76,7 +78,7 @@ class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena", "_exchange",
-                                                         "_exchange_events", "exchange_slices", "_split_capture", "time_exchange", "_auto", "_auto_busy", "auto_record", "step_mode"}
+                                                         "_exchange_events", "exchange_slices", "_aux_stream", "_split_capture", "time_exchange", "_auto", "_auto_busy", "auto_record", "step_mode"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -135,9 +137,39 @@ class CSModel(BaseModel):
         self.img_mask = vis
 
     # ---------------------------------------------------------------- forwards
+    def _sens_fork(self) -> None:
+        """The sensitivity network (varnet.py:389-420) depends on the sampled k-space only, the alignment network on the two
+        images only: the former is issued on an auxiliary stream with its own arena while the latter runs on the main stream
+        (1.9 of the 4.4 ms in front of the first cascade); VarNet._forward_impl joins.  Backward likewise (VarNet._backward_impl:
+        1.2 ms beside the alignment network's 4.3 ms).  SAN_SENS_OVERLAP=0: in line, as the reference orders them."""
+        R = self.net_R
+        if not SENS_OVERLAP[0] or self.device.type != "cuda" or not hasattr(R, "sens_net") or not hasattr(self, "img_k_sampled"):
+            return
+        aux = self.__dict__.get("_aux_stream")
+        if aux is None:
+            aux = self._aux_stream = torch.cuda.Stream(device=self.device)
+        arena = ops.owner_arena(R.sens_net)
+        main = torch.cuda.current_stream()
+        ops.ensure_packs(self.device)                   # (stale weight images are re-packed on the main stream, before the fork)
+        mk = self.img_k_sampled.detach().contiguous()
+        nlf = int(self.cfg.shape * self.cfg.sparsity * 0.32)
+        _lib.rec(aux.wait_stream, main)
+        with ops.aux_region(aux, arena):
+            sens = R.sens_net(mk, nlf)
+        R._sens_pre = (sens, (mk.data_ptr(), tuple(mk.shape), nlf), aux, arena)
+        if _SENS_DBG == 2:
+            _lib.rec(main.wait_stream, aux)
+
+    def _sens_join(self) -> None:
+        """The main stream waits for the sensitivity network's backward (its gradients are read by the exchange / the optimiser)."""
+        st = self.net_R.__dict__.pop("_sens_bwd_stream", None)
+        if st is not None:
+            _lib.rec(torch.cuda.current_stream().wait_stream, st)
+
     @_own_arena
     def forwardT(self):
         """model.py:142-155."""
+        self._sens_fork()
         aux_abs = ops.cabs(self.img_aux)
         self._aux_abs = aux_abs
         self.img_offset, self.img_grid = self.net_T(moving=aux_abs, fixed=ops.cabs(self.img_sampled))
@@ -168,7 +200,10 @@ class CSModel(BaseModel):
         Replaces ``scalar.scale(loss_all).backward()`` (model.py:203-214); ``loss_all.backward()`` itself works too
         (autograd.py) and gives the same bits."""
         with ops.backward_scope(self.device):   # gradient-maximum records zeroed, weight gradients on the side stream
-            self._backward(train_T)
+            try:
+                self._backward(train_T)
+            finally:
+                self._sens_join()
 
     def _backward(self, train_T: bool) -> None:
         g_rec = ops.ssim_loss_bwd(self.img_full_rss, self.img_rec, float(self.cfg.weight_sim))
@@ -183,18 +218,21 @@ class CSModel(BaseModel):
                 # flushed on the side stream and its slice of the flat buffer goes out on the communication stream
                 if ranges.get(which) is not None:
                     ops.wgrad_flush()
-                    exch.launch(bucket, after=(ops._WG["stream"],), rng=ranges[which])
+                    exch.launch(bucket, after=(ops._WG["stream"], self.net_R.__dict__.get("_sens_bwd_stream")), rng=ranges[which])
 
             self.net_R._grad_hook = hook
+        if SENS_OVERLAP[0] and self.__dict__.get("_aux_stream") is not None and _SENS_DBG != 1:
+            self.net_R._sens_async = self._aux_stream    # (this caller joins it: _sens_join)
         try:
             g_warped = self.net_R.backward(g_rec, want_ref_grad=train_T)
         finally:
             self.net_R._grad_hook = None
+            self.net_R.__dict__.pop("_sens_async", None)
         if exch is not None and not per_cascade:
             # net_R's gradients are final (its deferred weight-gradient reductions are flushed here): their all-reduce
             # starts now, on the communication stream, and hides behind the alignment network's backward
             ops.wgrad_flush()
-            exch.launch(self.optim_R.bucket(), after=(ops._WG["stream"],))
+            exch.launch(self.optim_R.bucket(), after=(ops._WG["stream"], self.net_R.__dict__.get("_sens_bwd_stream")))
         if not train_T:
             return
         off = self.net_T._last_offset_nchw
@@ -245,7 +283,7 @@ class CSModel(BaseModel):
                dist.get_world_size() if dist is not None else 1, self.net_T.training, self.net_R.training,
                tuple(p.requires_grad for o in (self.optim_R, self.optim_T) for p in o._params()),
                tuple(o.bucket().flat_p.data_ptr() for o in (self.optim_R, self.optim_T)), pr.data_ptr(), pr._version,
-               ops.F16_FWD[0], ops.F16_BWD[0], ops.USE_BF16X3[0], ops.WGRAD_OVERLAP[0], ops.WGRAD_DEFER[0],
+               ops.F16_FWD[0], ops.F16_BWD[0], ops.USE_BF16X3[0], ops.WGRAD_OVERLAP[0], ops.WGRAD_DEFER[0], SENS_OVERLAP[0],
                bool(getattr(self, "time_exchange", False)))
         st = getattr(self, "_auto", None)
         if st is None or st["key"] != key:

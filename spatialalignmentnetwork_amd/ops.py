@@ -199,6 +199,9 @@ def _creal(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
 _ARENA_PTRS = set()
 
 
+_POISON = os.environ.get("SAN_ARENA_POISON", "0") == "1"
+
+
 # Debugging hook (SAN_ARENA_GUARD=1, or ops.ARENA_GUARD[0] = True before the buffers are made): every arena buffer sits between two
 # 4 KiB bands of a byte pattern (SAN_ARENA_GUARD_BYTE, hex: FF makes the bands NaN, so that a kernel that READS past its input and
 # uses the value shows up in the results); arena_guard_report() names the buffers whose bands were written.  A kernel that stores
@@ -250,6 +253,10 @@ class Arena:
                 t = _guarded(key, shape, device, dtype, zero)
             else:
                 t = torch.zeros(shape, device=device, dtype=dtype) if zero else torch.empty(shape, device=device, dtype=dtype)
+            if _POISON and _lib.REC is not None:
+                print("arena buffer first created inside a recording:", key[:2], flush=True)
+            elif _POISON and not zero and t.is_floating_point():
+                t.fill_(float("nan"))           # (debugging: a kernel that reads an arena buffer it never wrote shows up as NaN)
             self._bufs[key] = t
             _ARENA_PTRS.add(t.data_ptr())
         elif not _no_wait and (_WG["busy"] or _WG["pending_ptrs"]):
@@ -1258,6 +1265,51 @@ class wgrad_overlap:
         _WG["rr"].clear()
         _WG["seq"] = _WG["waited"] = 0
         return False
+
+
+class aux_region:
+    """``with aux_region(stream, arena):`` -- an independent branch of the step (the sensitivity network beside the alignment
+    network: model.py) issued on ``stream`` with its own arena.  Launches inside take ``stream`` (it is torch's current stream
+    for the block); arena requests go to ``arena``, so nothing is shared with the main branch's temporaries; weight gradients
+    run in line on ``stream`` with their reductions at once (the side stream's hand-offs are ordered against the MAIN stream,
+    and the library's deferred-reduction queue belongs to it).  The caller orders the region against its producers and consumers
+    (``stream.wait_stream(main)`` before, ``main.wait_stream(stream)`` where the results are read)."""
+
+    def __init__(self, stream, arena: Arena):
+        self.stream, self.arena = stream, arena
+
+    def __enter__(self):
+        self.saved = (_WG["stream"], _WG["defer"])
+        if _WG["defer"]:
+            lib().query("san_wgrad_defer", 0)
+        _WG["stream"], _WG["defer"] = None, False
+        self.prev_aux = _lib.AUX[0]
+        _lib.AUX[0] = self.stream
+        self.cm = torch.cuda.stream(self.stream)
+        self.cm.__enter__()
+        self.ua = use_arena(self.arena)
+        self.ua.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ua.__exit__(*exc)
+        self.cm.__exit__(*exc)
+        _lib.AUX[0] = self.prev_aux
+        _WG["stream"], _WG["defer"] = self.saved
+        if _WG["defer"]:
+            lib().query("san_wgrad_defer", 1)
+        return False
+
+
+def ensure_packs(device) -> None:
+    """Re-pack the registered weight images NOW (on the current stream) if an optimiser step made them stale -- instead of at the
+    first convolution that asks, which inside an aux_region would put the batch on the wrong stream."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:  # ('cuda' == the current device: the jobs carry their weights' indexed device)
+        device = torch.device("cuda", torch.cuda.current_device())
+    for reg in (PACKS, PACKS16):
+        if reg.jobs and reg.epoch != WEIGHT_EPOCH[0]:
+            reg._run(device)
 
 
 class backward_scope:

@@ -637,7 +637,17 @@ class VarNet(nn.Module):
         n, c, h, w = masked_kspace.shape
         dev = masked_kspace.device
         self._fwd_id = getattr(self, "_fwd_id", 0) + 1
-        sens = self.sens_net(masked_kspace, num_low_frequencies)
+        pre = self.__dict__.pop("_sens_pre", None)
+        join_sens = None
+        self._sens_fwd_arena = None
+        if pre is not None and pre[1] == (masked_kspace.data_ptr(), tuple(masked_kspace.shape), num_low_frequencies):
+            # CSModel issued the sensitivity network beside the alignment network (model.py: _sens_fork): its maps (and its
+            # tapes, in its own arena) exist already; the main stream joins that stream in front of the first reader
+            sens, aux_stream = pre[0], pre[2]
+            self._sens_fwd_arena = pre[3]
+            join_sens = lambda: ops._lib.rec(torch.cuda.current_stream().wait_stream, aux_stream)      # noqa: E731
+        else:
+            sens = self.sens_net(masked_kspace, num_low_frequencies)
         with ops._lib.untracked():                       # (a constant of the model: the sampling mask as floats)
             mask_f = mask.reshape(-1).to(torch.float32).contiguous()
         assert mask_f.numel() == w, "mask must be a [W] column mask (broadcast like the reference's [1,1,1,W])"
@@ -655,6 +665,8 @@ class VarNet(nn.Module):
             xin = self.cascades[0].model.input_buffer(n, h, w, dev, "cas") if T else None
             x = ARENA.get("cas.x", (n, c, h, w), dev, dtype=torch.complex64)
             ops.fft2c(masked_kspace, inverse=True, out=x)
+            if join_sens is not None:
+                join_sens()
             if T:
                 if self.use_ref:
                     self.cascades[0].model.set_ref(xin, ref1)
@@ -671,6 +683,8 @@ class VarNet(nn.Module):
             if self.use_ref:
                 cascade.model.set_ref(xin, ref1)
             xins.append(xin)
+        if join_sens is not None:
+            join_sens()
         if T:
             ops.sens_reduce(masked_kspace, sens, xins[0].buf)
         for j, cascade in enumerate(self.cascades):
@@ -705,7 +719,19 @@ class VarNet(nn.Module):
                 hook(j)                                  # cascade j's weight and dc_weight gradients are complete
         # x_0 = ifft2(k0) and m_0 depend on the sensitivity maps only through m_0 = sum_c conj(S_c) x_0, which
         # run_bwd_img of cascade 0 has already accounted for; k0 itself needs no gradient
-        self.sens_net.backward(g_sens)
+        arena = getattr(self, "_sens_fwd_arena", None)   # the sensitivity net's forward ran in its own arena (CSModel._sens_fork)
+        aux = self.__dict__.get("_sens_async")           # a stream: CSModel runs this branch beside the alignment net's backward
+        if arena is not None and aux is not None:
+            ops._lib.rec(aux.wait_stream, torch.cuda.current_stream())         # dL/d(sens maps) is complete on the main stream
+            g_sens.record_stream(aux)
+            with ops.aux_region(aux, arena):
+                self.sens_net.backward(g_sens)
+            self._sens_bwd_stream = aux                  # whoever reads the sensitivity net's gradients waits for it
+        elif arena is not None:
+            with ops.use_arena(arena):
+                self.sens_net.backward(g_sens)
+        else:
+            self.sens_net.backward(g_sens)
         if hook is not None:
             hook("sens")
         if g_ref1 is None:
