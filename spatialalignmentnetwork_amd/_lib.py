@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime li
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "san_hip.h")
-LIB_PATH = os.path.join(HERE, "libsan_hip.so")
+LIB_PATH = os.environ.get("SAN_LIB_PATH") or os.path.join(HERE, "libsan_hip.so")     # SAN_LIB_PATH: same-box A/B of two builds
 
 # ---------------------------------------------------------------------------------------------------------------
 # Step recorder.  A training step issues the SAME ~2,000 C-ABI calls with the same arguments every time once the arenas are

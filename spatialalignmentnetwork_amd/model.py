@@ -43,6 +43,7 @@ AUTO_RECORD = [os.environ.get("SAN_AUTO_RECORD", "1") != "0"]
 # inside VarNet.backward as each cascade's gradients become final; "single" = the whole flat buffer afterwards.
 GRAD_BUCKETS = [os.environ.get("SAN_GRAD_BUCKETS", "cascade")]
 AUTO_AFTER = 2
+AUTO_KEEP = 3          # recordings kept besides the current one (each holds its step's tensors: ~6 GB at N = 8, 320^2)
 SENS_OVERLAP = [os.environ.get("SAN_SENS_OVERLAP", "1") != "0"]
 _SENS_DBG = int(os.environ.get("SAN_SENS_DBG", "0"))      # 1: forward branch only, 2: backward branch only (debugging)
 
@@ -78,7 +79,7 @@ class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena", "_exchange",
-                                                         "_exchange_events", "exchange_slices", "_aux_stream", "_split_capture", "time_exchange", "_auto", "_auto_busy", "auto_record", "step_mode"}
+                                                         "_exchange_events", "exchange_slices", "_aux_stream", "_split_capture", "time_exchange", "_auto", "_auto_cache", "_auto_busy", "auto_record", "step_mode"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -252,12 +253,23 @@ class CSModel(BaseModel):
         st = self._auto_state()
         if st is not None:
             if st["step"] is None and st["seen"] >= AUTO_AFTER and not st["failed"]:
+                err = None
                 try:
                     self._auto_make(st)
                 except Exception as e:              # the step cannot be recorded (a stray torch operation, ...): stay eager
-                    st["failed"] = f"{type(e).__name__}: {e}"
+                    err = f"{type(e).__name__}: {e}"
+                dist = _active_dist()
+                if dist is not None:
+                    # every rank replays or every rank stays eager: a replay and an eager step issue the same collectives, but a
+                    # rank that failed half-way must not be left alone with the others' next exchange
+                    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=self.device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                    if int(flag.item()) and err is None:
+                        err = "another rank could not record the step"
+                if err is not None:
+                    st.update(step=None, full=None, aux=None, attrs=None, failed=err)
                     import warnings
-                    warnings.warn(f"CSModel.update(): recording the step failed, staying eager ({st['failed']})")
+                    warnings.warn(f"CSModel.update(): recording the step failed, staying eager ({err})")
             if st["step"] is not None:
                 return self._auto_replay(st)
             st["seen"] += 1
@@ -284,10 +296,22 @@ class CSModel(BaseModel):
                tuple(p.requires_grad for o in (self.optim_R, self.optim_T) for p in o._params()),
                tuple(o.bucket().flat_p.data_ptr() for o in (self.optim_R, self.optim_T)), pr.data_ptr(), pr._version,
                ops.F16_FWD[0], ops.F16_BWD[0], ops.USE_BF16X3[0], ops.WGRAD_OVERLAP[0], ops.WGRAD_DEFER[0], SENS_OVERLAP[0],
-               bool(getattr(self, "time_exchange", False)))
+               bool(getattr(self, "time_exchange", False)),
+               # baked into the recording as host-side arguments: the low-frequency count of the sensitivity estimate, AdamW's
+               # betas / eps (lr, weight decay and the step count live in device memory: sync_hyper)
+               float(self.cfg.sparsity), int(self.cfg.shape),
+               tuple((tuple(g["betas"]), float(g["eps"])) for o in (self.optim_R, self.optim_T) for g in o.param_groups))
         st = getattr(self, "_auto", None)
         if st is None or st["key"] != key:
-            st = self._auto = {"key": key, "seen": 0, "step": None, "full": None, "aux": None, "attrs": None, "failed": None}
+            # a few recordings are kept by key (AUTO_KEEP): the short last batch of an epoch, or a validation pass with other
+            # loss weights, does not throw the full batch's recording away
+            cache = self.__dict__.setdefault("_auto_cache", {})
+            if st is not None and st["step"] is not None:
+                cache[st["key"]] = st
+                while len(cache) > AUTO_KEEP:
+                    cache.pop(next(iter(cache)))
+            st = cache.pop(key, None) or {"key": key, "seen": 0, "step": None, "full": None, "aux": None, "attrs": None, "failed": None}
+            self._auto = st
         return st
 
     def _auto_make(self, st) -> None:
@@ -487,20 +511,24 @@ class CSModel(BaseModel):
             o.device_step = True
             o.bucket()
         snap = self._snapshot_state() if restore else None
-        for _ in range(max(1, warmup)):         # arenas, packed weights, twiddles, flat buffers, constant tables exist afterwards
-            self.set_input(img_full, img_aux)
-            self.update()
-        torch.cuda.synchronize()
 
         def run():
             self.set_input(img_full, img_aux)
             self.update()
 
-        self._exchange_events = []               # (only the recorded step's exchange events are kept)
-        step = self._record(run, "record_update", timer)
-        if snap is not None:
-            self._restore_state(snap)
+        try:
+            for _ in range(max(1, warmup)):     # arenas, packed weights, twiddles, flat buffers, constant tables exist afterwards
+                run()
             torch.cuda.synchronize()
+            self._exchange_events = []           # (only the recorded step's exchange events are kept)
+            step = self._record(run, "record_update", timer)
+        finally:
+            # ALSO when the warm-up or the recording raised (a stray torch operation, out of memory): the caller falls back to
+            # the eager step, which must start from the state before the warm-up -- not one to three optimiser steps later
+            if snap is not None:
+                torch.cuda.synchronize()
+                self._restore_state(snap)
+                torch.cuda.synchronize()
         return step
 
     @_no_auto

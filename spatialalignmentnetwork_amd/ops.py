@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import weakref
+import dataclasses
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -1402,11 +1403,25 @@ _BUSY_EVENTS = _EventRing()     # side-stream completion marks: _WG['busy'] may 
 
 
 def _on_side_stream(dy: Act, x: Act, fn) -> None:
+    """``fn(x, dy)`` launches one weight gradient.  Outside wgrad_overlap it runs at once; inside it is queued with a SNAPSHOT of
+    what it will read at launch time: private copies of the two Act records (a caller may re-point .buf / .coff / .amax of the
+    objects it passed before the queue is handed over) and the convolution precision in force now."""
     side = _WG["stream"]
     if side is None:
-        fn()
+        fn(x, dy)
         return
-    _WG["pending"].append((dy, x, fn))
+    dy, x = dataclasses.replace(dy), dataclasses.replace(x)
+    mode = _CONV_NP[0], _FP8_FWD[0]
+
+    def launch(fn=fn, x=x, dy=dy, mode=mode):
+        saved = _CONV_NP[0], _FP8_FWD[0]
+        _CONV_NP[0], _FP8_FWD[0] = mode
+        try:
+            fn(x, dy)
+        finally:
+            _CONV_NP[0], _FP8_FWD[0] = saved
+
+    _WG["pending"].append((dy, x, launch))
     _WG["pending_ptrs"].add(dy.buf.data_ptr())
     _WG["pending_ptrs"].add(x.buf.data_ptr())
     if len(_WG["pending"]) >= WGRAD_BATCH[0]:
@@ -1451,7 +1466,7 @@ def _flush_pending() -> None:
 def conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
     """dw [cout, cin, ks, ks] (+)= correlation of dy with the lazily activated forward input x (on the side stream
     inside ``wgrad_overlap``)."""
-    _on_side_stream(dy, x, lambda: _conv2d_wgrad(x, dy, dw, accumulate, arena))
+    _on_side_stream(dy, x, lambda x, dy: _conv2d_wgrad(x, dy, dw, accumulate, arena))
 
 
 def _conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
@@ -1477,7 +1492,7 @@ def _conv2d_wgrad(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, a
 
 
 def conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA) -> None:
-    _on_side_stream(dy, x, lambda: _conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena))
+    _on_side_stream(dy, x, lambda x, dy: _conv2d_wgrad_bf16x3(x, dy, dw, accumulate, arena))
 
 
 def _conv2d_wgrad_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
@@ -1510,7 +1525,7 @@ def wgrad1x1_bf16x3_ok(x: Act, dy: Act) -> bool:
 
 def conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,
                            transposed: bool = False) -> None:
-    _on_side_stream(dy, x, lambda: _conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena, transposed))
+    _on_side_stream(dy, x, lambda x, dy: _conv2d_wgrad1x1_bf16x3(x, dy, dw, accumulate, arena, transposed))
 
 
 def _conv2d_wgrad1x1_bf16x3(x: Act, dy: Act, dw: torch.Tensor, accumulate: bool = False, arena: Arena = GLOBAL_ARENA,

@@ -94,3 +94,41 @@ def test_replay_tape_walks_calls_and_reports_the_failing_entry(built):
     with pytest.raises(RuntimeError, match="past the end"):
         built.Tape(bad[:3], {0: "truncated"}).run()
     assert built.tape_call_words(lib._san_last_error_string, ()) is None
+
+
+def _device_disassembly(lib_path, tmp_path):
+    """gfx950 disassembly of every code object in the library's .hip_fatbin section (one clang offload bundle per
+    translation unit, concatenated by the linker)."""
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    fat = str(tmp_path / "fat.bin")
+    subprocess.run([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib_path], check=True)
+    data = open(fat, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    starts = [m.start() for m in re.finditer(magic, data)]
+    assert starts, "no offload bundle in the library"
+    out = []
+    for k, (lo, hi) in enumerate(zip(starts, starts[1:] + [len(data)])):
+        bundle, co = str(tmp_path / f"b{k}.bin"), str(tmp_path / f"b{k}.hsaco")
+        open(bundle, "wb").write(data[lo:hi])
+        ids = subprocess.run([f"{llvm}/clang-offload-bundler", "--list", "--type=o", f"--input={bundle}"], check=True,
+                             capture_output=True, text=True).stdout.split()
+        target = [t for t in ids if "gfx950" in t]
+        assert len(target) == 1, ids
+        subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--targets={target[0]}", f"--input={bundle}",
+                        f"--output={co}"], check=True)
+        out.append(subprocess.run([f"{llvm}/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout)
+    return out
+
+
+def test_library_has_no_packed_fp32_instruction(built, tmp_path):
+    """Round 4 found `v_pk_mul_f32 ... op_sel:[0,1]` reading the wrong register of its source pair while another stream's MFMA
+    kernel shared the compute unit.  The library is built without the packed-fp32 target feature (build.py, NO_PK32): no kernel
+    of any stream can contain such an instruction, whatever shares the chip with it.  Checked on the shipped binary."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    texts = _device_disassembly(built.LIB_PATH, tmp_path)
+    assert len(texts) >= 10                      # one per .hip source
+    pk = [line.strip() for t in texts for line in t.splitlines() if re.search(r"\bv_pk_(mul|add|fma|mov)_(f32|b32)\b", line)]
+    assert not pk, f"{len(pk)} packed-fp32 instructions in libsan_hip.so, e.g. {pk[:3]}"
+    assert sum(t.count("v_mfma_") for t in texts) > 10000        # (the disassembly is the real one)
