@@ -435,6 +435,12 @@ int san_grid_sample_fwd(const float* img, const float* grid, float* out,
  * autograd callers of SpatialTransformer.warp with img.requires_grad do; cross.py:32-34). */
 int san_grid_sample_bwd_img(const float* grid, const float* g, float* gimg,
                             int n, int c, int h, int w, int ho, int wo, void* stream);
+/* The same gradient without float atomics (round 5; what autograd._WarpFn calls): contributions are rounded to 64-bit fixed
+ * point (2^-40 of max |g|) and summed with integer atomics, so the result is independent of the arrival order -- bit-reproducible.
+ * work: san_grid_sample_bwd_img_work_bytes(n, c, h, w) bytes of scratch.  cross.py:32-34 (F.grid_sample's autograd). */
+size_t san_grid_sample_bwd_img_work_bytes(int n, int c, int h, int w);
+int san_grid_sample_bwd_img_det(const float* grid, const float* g, float* gimg, long long* work,
+                                int n, int c, int h, int w, int ho, int wo, void* stream);
 
 /* The same sampler on interleaved complex planes (img, out: [n,c,h,w] float2): real and imaginary
  * parts sampled with one grid, as augment.py:62-63 does with two grid_sample calls. */

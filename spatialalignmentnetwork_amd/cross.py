@@ -76,4 +76,14 @@ class SpatialTransformer(torch.nn.Module):
         """Bilinear, zeros padding, align_corners=False; inputs forced to fp32 (cross.py:32-38).  Differentiable wrt the
         grid (and, with float atomics, the image) through autograd._WarpFn."""
         from . import autograd
-        return autograd.warp(img.float(), grid.float())
+        warped = autograd.warp(img.float(), grid.float())
+        if interp and warped.shape != img.shape:
+            # cross.py:35-37: F.interpolate(warped, size=img.shape[2:]) in its default mode 'nearest' --
+            # source index = min(floor(dst * in / out), in - 1) with the ratio taken in float32, as ATen computes it.
+            # Two index_selects (differentiable); not on CSModel's path (model.py never passes interp=True).
+            for dim, (n_in, n_out) in ((2, (warped.shape[2], img.shape[2])), (3, (warped.shape[3], img.shape[3]))):
+                if n_in != n_out:
+                    scale = torch.tensor(n_in / n_out, dtype=torch.float32)
+                    idx = torch.clamp((torch.arange(n_out, dtype=torch.float32) * scale).floor().long(), max=n_in - 1)
+                    warped = warped.index_select(dim, idx.to(warped.device))
+        return warped

@@ -181,9 +181,92 @@ grid_sample_bwd_img_kernel(const float* __restrict__ grid, const float* __restri
     }
 }
 
+// The same scatter WITHOUT float atomics (round 5): contributions are rounded to 64-bit fixed point (2^-40 of the largest |g|,
+// i.e. finer than an fp32 sum of them could resolve) and added with INTEGER atomics -- integer addition is associative, so the
+// result does not depend on the order the workgroups arrive in; a last pass converts back.  work: n*c*h*w + 1 words (the last
+// one collects the bits of max |g|).
+__global__ void __launch_bounds__(kThreads) gsb_amax_kernel(const float* __restrict__ g, size_t count, unsigned long long* __restrict__ amax) {
+    float mx = 0.f;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) mx = fmaxf(mx, fabsf(g[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax, (unsigned long long)__builtin_bit_cast(unsigned, mx));
+}
+
+__device__ __forceinline__ float gsb_scale(const unsigned long long* amax) {
+    const float mx = __builtin_bit_cast(float, (unsigned)*amax);
+    if (!(mx > 0.f) || !(mx < INFINITY)) return 0.f;
+    int e;
+    frexpf(mx, &e);                                      // mx = m * 2^e, 0.5 <= m < 1
+    return ldexpf(1.f, 40 - e);                          // |g| * scale < 2^40: 2^23 coinciding contributions fit in 63 bits
+}
+
+__global__ void __launch_bounds__(kThreads)
+grid_sample_bwd_img_fixed_kernel(const float* __restrict__ grid, const float* __restrict__ g, unsigned long long* __restrict__ work,
+                                 const unsigned long long* __restrict__ amax, int C, int H, int W, int HO, int WO) {
+    const int n = blockIdx.y;
+    const int HWo = HO * WO;
+    const float scale = gsb_scale(amax);
+    if (scale == 0.f) return;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < HWo; i += gridDim.x * kThreads) {
+        const float2 gg = *reinterpret_cast<const float2*>(grid + ((size_t)n * HWo + i) * 2);
+        const float ix = ((gg.x + 1.f) * (float)W - 1.f) * 0.5f;
+        const float iy = ((gg.y + 1.f) * (float)H - 1.f) * 0.5f;
+        const float fx = floorf(ix), fy = floorf(iy);
+        if (!(fx > -2.f && fx < (float)W + 1.f && fy > -2.f && fy < (float)H + 1.f)) continue;      // (also NaN / far outside)
+        const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+        const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+        const bool xin0 = x0 >= 0 && x0 < W, xin1 = x1 >= 0 && x1 < W;
+        const bool yin0 = y0 >= 0 && y0 < H, yin1 = y1 >= 0 && y1 < H;
+        for (int c = 0; c < C; ++c) {
+            const float go = g[((size_t)n * C + c) * HWo + i] * scale;           // (a power of two: exact)
+            unsigned long long* p = work + ((size_t)n * C + c) * H * W;
+            if (yin0 && xin0) atomicAdd(p + y0 * W + x0, (unsigned long long)__float2ll_rn(go * (wx0 * wy0)));
+            if (yin0 && xin1) atomicAdd(p + y0 * W + x1, (unsigned long long)__float2ll_rn(go * (wx1 * wy0)));
+            if (yin1 && xin0) atomicAdd(p + y1 * W + x0, (unsigned long long)__float2ll_rn(go * (wx0 * wy1)));
+            if (yin1 && xin1) atomicAdd(p + y1 * W + x1, (unsigned long long)__float2ll_rn(go * (wx1 * wy1)));
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kThreads) gsb_convert_kernel(const unsigned long long* __restrict__ work, const unsigned long long* __restrict__ amax,
+                                                               float* __restrict__ gimg, size_t count) {
+    const float scale = gsb_scale(amax);
+    const double inv = scale > 0.f ? 1.0 / (double)scale : 0.0;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads)
+        gimg[i] = (float)((double)(long long)work[i] * inv);
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t san_grid_sample_bwd_img_work_bytes(int n, int c, int h, int w) { return ((size_t)n * c * h * w + 1) * sizeof(long long); }
+
+int san_grid_sample_bwd_img_det(const float* grid, const float* g, float* gimg, long long* work, int n, int c, int h, int w, int ho,
+                                int wo, void* stream) {
+    SAN_CHECK_ARG(grid && g && gimg && work, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && h > 0 && w > 0 && ho > 0 && wo > 0, "bad dims");
+    const size_t count = (size_t)n * c * h * w, gcount = (size_t)n * c * ho * wo;
+    hipError_t e = hipMemsetAsync(work, 0, (count + 1) * sizeof(long long), (hipStream_t)stream);
+    if (e != hipSuccess) {
+        san_set_error("san_grid_sample_bwd_img_det: memset failed: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    unsigned long long* wk = reinterpret_cast<unsigned long long*>(work);
+    int ba = (int)((gcount + kThreads - 1) / kThreads);
+    if (ba > 1024) ba = 1024;
+    hipLaunchKernelGGL(gsb_amax_kernel, dim3(ba), dim3(kThreads), 0, (hipStream_t)stream, g, gcount, wk + count);
+    int bx = san_cdiv(ho * wo, kThreads);
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(grid_sample_bwd_img_fixed_kernel, dim3(bx, n), dim3(kThreads), 0, (hipStream_t)stream, grid, g, wk, wk + count, c, h,
+                       w, ho, wo);
+    int bc = (int)((count + kThreads - 1) / kThreads);
+    if (bc > 2048) bc = 2048;
+    hipLaunchKernelGGL(gsb_convert_kernel, dim3(bc), dim3(kThreads), 0, (hipStream_t)stream, wk, wk + count, gimg, count);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
 
 int san_grid_sample_bwd_img(const float* grid, const float* g, float* gimg, int n, int c, int h, int w, int ho, int wo,
                             void* stream) {

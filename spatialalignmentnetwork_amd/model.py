@@ -44,7 +44,12 @@ AUTO_RECORD = [os.environ.get("SAN_AUTO_RECORD", "1") != "0"]
 GRAD_BUCKETS = [os.environ.get("SAN_GRAD_BUCKETS", "cascade")]
 AUTO_AFTER = 2
 AUTO_KEEP = 3          # recordings kept besides the current one (each holds its step's tensors: ~6 GB at N = 8, 320^2)
-SENS_OVERLAP = [os.environ.get("SAN_SENS_OVERLAP", "1") != "0"]
+# Sensitivity network on an auxiliary stream beside the alignment network (forward and backward).  On by default again in round 5:
+# the misread that made co-resident kernels of two streams disagree needs a packed-fp32 instruction in the victim
+# (scratch/probe/pk32_two_stream_repro.hip), the library has none (build.py NO_PK32, tests/test_abi.py), and
+# tests/test_hip_parity_r5.py holds 50 overlapped steps at N = 8, 320^2 and 10 at 15 x 640 x 368 to the serial step bit for bit.
+SENS_OVERLAP_DEFAULT = os.environ.get("SAN_SENS_OVERLAP", "1") != "0"
+SENS_OVERLAP = [SENS_OVERLAP_DEFAULT]
 _SENS_DBG = int(os.environ.get("SAN_SENS_DBG", "0"))      # 1: forward branch only, 2: backward branch only (debugging)
 
 

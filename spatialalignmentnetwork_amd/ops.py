@@ -1776,12 +1776,14 @@ def smooth_pool_bwd(gy: torch.Tensor, kern: torch.Tensor, gx: Optional[torch.Ten
 
 
 def grid_sample_bwd_img(grid: torch.Tensor, g: torch.Tensor, img_shape) -> torch.Tensor:
-    """d <g, grid_sample(img, grid)> / d img (zeros padding): a scatter with float atomics (san_grid_sample_bwd_img)."""
+    """d <g, grid_sample(img, grid)> / d img (zeros padding): a scatter in 64-bit fixed point with integer atomics
+    (san_grid_sample_bwd_img_det) -- bit-reproducible, unlike the float-atomic form it replaces (round 5)."""
     n, c, h, w = img_shape
     ho, wo = grid.shape[1:3]
     gimg = torch.empty((n, c, h, w), device=g.device, dtype=torch.float32)
-    lib().call("san_grid_sample_bwd_img", _p(_chk(grid, name="grid")), _p(_chk(g, name="g")), _p(gimg), n, c, h, w, ho, wo,
-               _stream())
+    work = torch.empty((lib().query("san_grid_sample_bwd_img_work_bytes", n, c, h, w) // 8,), device=g.device, dtype=torch.int64)
+    lib().call("san_grid_sample_bwd_img_det", _p(_chk(grid, name="grid")), _p(_chk(g, name="g")), _p(gimg), _p(work),
+               n, c, h, w, ho, wo, _stream())
     return gimg
 
 

@@ -1,0 +1,200 @@
+"""Round-5 GPU tests (through the C ABI): the overlapped step against the serial step at the bench's full sizes, a failed
+recording, hand-off batch sizes, ``warp(interp=True)``, the fixed-point image gradient of the sampler."""
+import os
+import warnings
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def S():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from spatialalignmentnetwork_amd import ops, synth, model, basemodel, _lib, autograd, cross
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.ops, ns.synth, ns.model, ns.base, ns.lib, ns.autograd, ns.cross = ops, synth, model, basemodel, _lib, autograd, cross
+    return ns
+
+
+def g(t):
+    return t.to(DEV).contiguous()
+
+
+def _fill(S, m, seed, damp=1.0):
+    m.load_state_dict(S.synth.fill_params([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed=seed, damp=damp))
+
+
+def _model(S, w, c, sparsity=0.25, **kw):
+    cfg = S.base.Config(sparsity=sparsity, lr=1e-4, shape=w, coils=c, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                        weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, **kw)
+    net = S.model.CSModel(cfg)
+    net.net_mask.pruned = S.synth.equispaced_pruned(w, sparsity, 0)
+    _fill(S, net.net_T, 41, damp=0.1)
+    _fill(S, net.net_R, 42, damp=0.1)
+    return net.to(DEV)
+
+
+def _state(net):
+    return {f"{s_}.{k}": v.detach().cpu().clone() for s_ in ("net_R", "net_T") for k, v in getattr(net, s_).state_dict().items()}
+
+
+# ---------------------------------------------------------------------- overlap on / off at the sizes the bench and config 4 run
+@pytest.mark.parametrize("tag,n,c,h,w,sparsity,steps", [("bench_n8_320", 8, 1, 320, 320, 0.25, 50),
+                                                        ("config4_15x640x368", 1, 15, 640, 368, 0.125, 10)])
+def test_overlapped_steps_equal_serial_steps_at_full_size(S, tag, n, c, h, w, sparsity, steps):
+    """the default step runs three streams (weight gradients on the side stream, the sensitivity network
+    beside the alignment network); with every overlap switched off the same kernels run one after the other.  ``steps``
+    optimisation steps of the 12-cascade model (new data every step; eager, eager, then replays of the auto-recorded step) must
+    leave BIT-identical parameters, BatchNorm buffers, reconstructions and losses in both forms.  The library carries no
+    packed-fp32 instruction any more (tests/test_abi.py), which is what made two co-resident kernels disagree in round 4."""
+    batches = [tuple(g(t) for t in S.synth.phantom_pair(n, c, h, w, seed=700 + i)) for i in range(4)]
+
+    def loop(overlap):
+        S.ops.WGRAD_OVERLAP[0] = overlap
+        S.model.SENS_OVERLAP[0] = overlap
+        try:
+            net = _model(S, w, c, sparsity=sparsity, num_cascades=12).train()
+            sims, modes = [], []
+            for it in range(steps):
+                net.set_input(*batches[it % len(batches)])
+                net.update()
+                sims.append(net.loss_sim.detach().clone())
+                modes.append(net.step_mode)
+            torch.cuda.synchronize()
+            return _state(net), torch.stack(sims).cpu(), net.img_rec.detach().cpu().clone(), modes
+        finally:
+            S.ops.WGRAD_OVERLAP[0] = True
+            S.model.SENS_OVERLAP[0] = S.model.SENS_OVERLAP_DEFAULT
+
+    st_s, sims_s, rec_s, modes_s = loop(False)
+    torch.cuda.empty_cache()
+    st_o, sims_o, rec_o, modes_o = loop(True)
+    assert modes_o[0] == "eager" and modes_o[-1].startswith("replay"), modes_o
+    assert torch.isfinite(sims_o).all() and torch.isfinite(sims_s).all(), (sims_s, sims_o)
+    assert torch.equal(sims_s, sims_o), (tag, (sims_s - sims_o).abs().max().item())
+    bad = [k for k in st_s if not torch.equal(st_s[k], st_o[k])]
+    assert not bad, (tag, len(bad), bad[:5])
+    assert torch.equal(rec_s, rec_o)
+
+
+# --------------------------------------------------------------------------------------- a recording that fails
+def test_failed_recording_leaves_the_model_where_the_eager_loop_would_be(S):
+    """``update()`` tries to record the third step.  When the recording raises (here: after the warm-up step and the recorded step
+    have both run and changed the weights), the model must be put back before the call falls back to the eager step -- otherwise
+    the same batch gets three optimiser steps.  Four steps with a failing recorder == four eager steps, bit for bit."""
+    n, c, h, w = 2, 3, 48, 80
+    batches = [tuple(g(t) for t in S.synth.phantom_pair(n, c, h, w, seed=300 + i)) for i in range(4)]
+
+    def loop(break_recorder):
+        net = _model(S, w, c, num_cascades=2, chans=6, sens_chans=4, pools=2, sens_pools=2).train()
+        if break_recorder:
+            real = net._record
+
+            def failing(run, what, timer):
+                real(run, what, timer)              # the step runs under the recorder (and trains) ...
+                raise RuntimeError("stray operation (test)")      # ... and then the recording is refused
+
+            net._record = failing
+            net.memo_init.add("_record")
+        else:
+            net.auto_record = False
+        modes = []
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            for b in batches:
+                net.set_input(*b)
+                net.update()
+                modes.append(net.step_mode)
+        torch.cuda.synchronize()
+        return _state(net), modes, [str(x.message) for x in wlist], net.optim_R.steps_taken()
+
+    want, _, _, steps_e = loop(False)
+    got, modes, msgs, steps_f = loop(True)
+    assert all(m == "eager" for m in modes), modes
+    assert any("staying eager" in m for m in msgs), msgs
+    assert steps_e == steps_f == len(batches)
+    bad = [k for k in want if not torch.equal(want[k], got[k])]
+    assert not bad, bad[:5]
+
+
+# ------------------------------------------------------------------------------------------------ hand-off batches
+def test_weight_gradient_handoff_batch_size_changes_nothing(S):
+    """Queued weight gradients snapshot their operands (ops._on_side_stream): batches of 1, 4 and 16 launches behind one event give
+    the same bits."""
+    n, c, h, w = 2, 3, 48, 80
+    batch = tuple(g(t) for t in S.synth.phantom_pair(n, c, h, w, seed=77))
+
+    def run(k):
+        old = S.ops.WGRAD_BATCH[0]
+        S.ops.WGRAD_BATCH[0] = k
+        try:
+            net = _model(S, w, c, num_cascades=2, chans=6, sens_chans=4, pools=2, sens_pools=2).train()
+            net.auto_record = False
+            for _ in range(2):
+                net.set_input(*batch)
+                net.update()
+            torch.cuda.synchronize()
+            return _state(net)
+        finally:
+            S.ops.WGRAD_BATCH[0] = old
+
+    a, b, c_ = run(1), run(4), run(16)
+    assert not [k for k in a if not torch.equal(a[k], b[k])]
+    assert not [k for k in a if not torch.equal(a[k], c_[k])]
+
+
+# ------------------------------------------------------------------------------------------------------------- warp(interp=True)
+@pytest.mark.parametrize("hg,wg", [(24, 40), (48, 80), (96, 50)])
+def test_warp_interp_resizes_like_the_reference(S, hg, wg):
+    """cross.py:32-38: ``grid_sample`` on a grid of another size, then ``F.interpolate(size=img.shape[2:])`` (nearest) when
+    ``interp`` is set.  Against the same two ATen calls on the CPU."""
+    n, c, h, w = 2, 3, 48, 80
+    gen = torch.Generator().manual_seed(5)
+    img = torch.randn(n, c, h, w, generator=gen)
+    grid = torch.rand(n, hg, wg, 2, generator=gen) * 2.2 - 1.1
+    st = S.cross.SpatialTransformer(channels=c).to(DEV)
+    got = st.warp(g(img), g(grid), interp=True)
+    want = F.grid_sample(img, grid, align_corners=False)
+    if want.shape != img.shape:
+        want = F.interpolate(want, size=img.shape[2:])
+    assert got.shape == img.shape
+    # (the sampler itself is held to 1e-5 against ATen in test_warp_and_losses_golden: weights formed in another order)
+    assert (got.cpu() - want).abs().max().item() < 1e-5 * max(1.0, want.abs().max().item())
+    plain = st.warp(g(img), g(grid))                    # without interp: the grid's size, as in the reference
+    assert tuple(plain.shape) == (n, c, hg, wg)
+
+
+# ---------------------------------------------------------------------------------------------- sampler gradient wrt the image
+def test_grid_sample_image_gradient_is_bit_reproducible_and_matches_autograd(S):
+    """d/d img of the bilinear sampler: 64-bit fixed-point integer atomics instead of float atomics -- 20 launches give identical
+    bits (the float form differed from launch to launch), and the values equal ATen's autograd to fp32 rounding."""
+    n, c, h, w, ho, wo = 3, 2, 96, 80, 64, 112
+    gen = torch.Generator().manual_seed(9)
+    img = torch.randn(n, c, h, w, generator=gen)
+    grid = torch.rand(n, ho, wo, 2, generator=gen) * 2.4 - 1.2
+    gout = torch.randn(n, c, ho, wo, generator=gen) * 3.0
+    imr = img.clone().requires_grad_(True)
+    F.grid_sample(imr, grid, align_corners=False).backward(gout)
+    want = imr.grad
+    first = S.ops.grid_sample_bwd_img(g(grid), g(gout), (n, c, h, w))
+    for _ in range(20):
+        again = S.ops.grid_sample_bwd_img(g(grid), g(gout), (n, c, h, w))
+        assert torch.equal(first, again)
+    err = (first.cpu() - want).abs().max().item()
+    assert err < 2e-6 * want.abs().max().item(), err
+    zero = S.ops.grid_sample_bwd_img(g(grid), torch.zeros_like(g(gout)), (n, c, h, w))
+    assert float(zero.abs().max()) == 0.0
+    # through the module-level autograd function, as a caller of SpatialTransformer.warp would get it
+    im2 = g(img).requires_grad_(True)
+    S.autograd.warp(im2, g(grid)).backward(g(gout))
+    assert torch.equal(im2.grad, first)
