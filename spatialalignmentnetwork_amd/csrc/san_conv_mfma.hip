@@ -580,6 +580,277 @@ int launch_mfma(const float* x, const float* wp, float* y, const MArgs& a, hipSt
     return SAN_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Direct fp32 convolution for layers with a handful of channels on ONE side (round 5): the cascade's first convolution
+// (4 -> 18, 3x3), its output convolution (18 -> 2, 1x1) and their data gradients (2 -> 18 1x1, 18 -> 4 3x3).  These move 13 + 59 MB
+// per launch at N = 8 (12 us of HBM time) and need 648 FMAs per pixel (7 us of the vector pipe), but took 45 / 18 / 47 / 44 us on
+// the outer-product kernel above (its per-(channel, tap) MFMA blocks are tiny there, the launch is latency-bound).  Here:
+// tile 64 x 16 pixels, thread = 4 consecutive pixels of one row x ALL CW output channels of its group (4 CW accumulators);
+// the halo tile of CK input channels (lazy affine + LeakyReLU applied once, while staging) and the group's whole weight set
+// sit in LDS; per (channel, row) a thread reads its 6 (3x3) or 4 (1x1) inputs with one or two wide LDS reads, the CW weights of
+// a tap are broadcast reads (same address in every lane).  Pure v_fma_f32: exact fp32 chains like the kernel above.
+// Same packed weights ([group][cin][tap][4][CQP], forward or data-gradient packing), same epilogue contract (bias, per-wave
+// (count, mean, M2) statistics tiles, per-(n, c) output affine, channel views) -- san_conv2d_fwd routes here by shape alone.
+constexpr int kDTW = 64, kDTH = 16, kDPX = 4;
+
+__host__ __device__ inline bool direct_ok(int cin, int cout, int ks) {
+    if (ks != 1 && ks != 3) return false;
+    return cin <= 4 || (cout <= 4 && cin <= 48);
+}
+
+// CK = 4: cin <= 4, ONE staged chunk; the output channels are produced four at a time (CW / 4 passes over the staged tile), each
+// quad's bias / statistics / stores issued as soon as it is complete, so that the stores of one quad drain while the next is
+// computed (with all CW x 4 accumulators finished at once, every resident workgroup stored at the same moment and the launch
+// took compute + store time).  Measured at N = 8, 320^2 (rocprofv3, us): 4 -> 18 3x3 47.5 -> 35.2 (ablation: loads + stores alone 15,
+// the FMAs alone 23 -- a plain v_fma_f32 issues at half the packed / MFMA fp32 rate -- statistics 6), 2 -> 18 1x1 28.0 -> 14.5,
+// 18 -> 4 3x3 37.2 -> ~22, 18 -> 2 1x1 18.2 -> 17.2; 2 -> 8 3x3 on 15 planes of 640 x 368: 60 -> 41.  CK = 6: cout <= 4 (CW = 4), the input channels arrive in chunks of six
+// whose global loads are issued a whole compute phase ahead.
+template <int CK, int KS, int CW>
+__global__ void __launch_bounds__(kThreads)
+conv_direct_kernel(const float* __restrict__ x, const float* __restrict__ wp, float* __restrict__ y, const MArgs a) {
+    static_assert(CK == 4 || CW == 4, "many input channels only with one output quad");
+    constexpr int PAD = KS / 2, TAPS = KS * KS;
+    constexpr int TWH = kDTW + 2 * PAD, THH = kDTH + 2 * PAD;
+    constexpr int PITCH = (TWH + 3) & ~3;                  // 68 (3x3) / 64 (1x1): rows start 16-byte aligned
+    constexpr int TILE = THH * PITCH;
+    constexpr int SL = (THH * TWH + kThreads - 1) / kThreads;
+    constexpr int NX = kDPX + 2 * PAD;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int tx = tid & 15, ty = tid >> 4;                // thread = pixels (4 tx .. 4 tx + 3, ty) of the tile
+    const int H = a.H, W = a.W, cin = a.cin;
+    const size_t HW = (size_t)H * W;
+    const int tiles_x = (W + kDTW - 1) / kDTW, tiles_y = (H + kDTH - 1) / kDTH, ntile = tiles_x * tiles_y;
+    const int groups = a.g.groups, cqp = a.g.cqp;
+    int lin;
+    {
+        const int total = gridDim.x, id = blockIdx.x;      // XCD-contiguous logical order, as in the kernel above
+        const int xcd = id & 7, slot = id >> 3;
+        lin = xcd * (total >> 3) + min(xcd, total & 7) + slot;
+    }
+    const int grp = lin % groups;
+    const int tile = (lin / groups) % ntile;
+    const int n = lin / (groups * ntile);
+    const int tyy = tile / tiles_x, txx = tile - tyy * tiles_x;
+    const int x0 = txx * kDTW, y0 = tyy * kDTH;
+
+    float* lds_x = mf_lds;                                  // [CK][THH][PITCH]
+    float* lds_w = mf_lds + CK * TILE;                      // [cin][TAPS][CW], channel co = 4 cq + j of the group at [co]
+    int goff[SL], loff[SL];
+    bool inb[SL];
+#pragma unroll
+    for (int s = 0; s < SL; ++s) {
+        const int e = tid + s * kThreads;
+        const int r = e / TWH, c = e - r * TWH;
+        const int gy = y0 - PAD + r, gx = x0 - PAD + c;
+        const bool in_tile = e < THH * TWH;
+        inb[s] = in_tile && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        goff[s] = inb[s] ? gy * W + gx : 0;
+        loff[s] = in_tile ? r * PITCH + c : -1;
+    }
+    const float* xn = x + (size_t)(n * a.x_ctot + a.x_coff) * HW;
+    float v[CK][SL];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            const float* xc = xn + (size_t)min(c0 + ch, cin - 1) * HW;
+#pragma unroll
+            for (int s = 0; s < SL; ++s) v[ch][s] = inb[s] ? xc[goff[s]] : 0.f;
+        }
+    };
+    auto stage = [&](int c0) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            const int ci = min(c0 + ch, cin - 1);           // (channels past cin are staged but never read)
+            float sc = 1.f, sh = 0.f;
+            if (a.in_scale) {
+                sc = a.in_scale[n * a.x_ctot + a.x_coff + ci];
+                sh = a.in_shift[n * a.x_ctot + a.x_coff + ci];
+            }
+#pragma unroll
+            for (int s = 0; s < SL; ++s)
+                if (loff[s] >= 0) lds_x[ch * TILE + loff[s]] = inb[s] ? san_act(v[ch][s], sc, sh, a.in_slope) : 0.f;
+        }
+    };
+    fetch(0);
+    {
+        const float* src = wp + (size_t)grp * cin * TAPS * 4 * cqp;
+        const int total = cin * TAPS * CW;
+        for (int i = tid; i < total; i += kThreads) {
+            const int row = i / CW, co = i - row * CW;
+            lds_w[i] = src[(size_t)row * 4 * cqp + (co & 3) * cqp + (co >> 2)];
+        }
+    }
+    const int oy = y0 + ty, ox = x0 + kDPX * tx;
+    bool valid[kDPX];
+#pragma unroll
+    for (int p = 0; p < kDPX; ++p) valid[p] = oy < H && ox + p < W;
+    const int cbase = grp * CW;
+    const bool quad = valid[kDPX - 1] && (W & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    float cnt = 0.f, inv = 0.f;
+    int src_lane = 0;
+    if (a.part) {
+        const unsigned long long vm = __ballot(valid[0]);
+        src_lane = vm ? (int)__ffsll((long long)vm) - 1 : 0;
+#pragma unroll
+        for (int p = 0; p < kDPX; ++p) cnt += valid[p] ? 1.f : 0.f;
+        cnt = san_wave_total(cnt);
+        inv = cnt > 0.f ? 1.f / cnt : 0.f;
+    }
+    float acc[kDPX][4];
+    auto clear = [&]() {
+#pragma unroll
+        for (int p = 0; p < kDPX; ++p)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[p][i] = 0.f;
+    };
+    // the staged chunk c0.. x the weight columns 4 cq .. 4 cq + 3
+    auto compute = [&](int c0, int cq) {
+#pragma unroll
+        for (int ch = 0; ch < CK; ++ch) {
+            if (c0 + ch < cin) {                            // (workgroup-uniform)
+                const float* wrow = lds_w + (size_t)(c0 + ch) * TAPS * CW + 4 * cq;
+#pragma unroll
+                for (int ky = 0; ky < KS; ++ky) {
+                    const float* xr = lds_x + ch * TILE + (ty + ky) * PITCH + kDPX * tx;
+                    float xv[NX];
+                    const f4 q = *reinterpret_cast<const f4*>(xr);
+                    xv[0] = q[0]; xv[1] = q[1]; xv[2] = q[2]; xv[3] = q[3];
+                    if constexpr (KS == 3) {
+                        typedef float f2v __attribute__((ext_vector_type(2)));
+                        const f2v r2 = *reinterpret_cast<const f2v*>(xr + 4);
+                        xv[4] = r2[0]; xv[5] = r2[1];
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const f4 wv = *reinterpret_cast<const f4*>(wrow + (ky * KS + kx) * CW);      // broadcast read
+#pragma unroll
+                        for (int p = 0; p < kDPX; ++p)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) acc[p][i] = fmaf(xv[p + kx], wv[i], acc[p][i]);
+                    }
+                }
+            }
+        }
+    };
+    // bias, per-WAVE (count, mean, M2) statistics (pilot-shifted single pass: the format san_norm_finalize merges), output affine,
+    // stores of output channels cbase + 4 cq ..
+    auto finish = [&](int cq) {
+        float my_mean = 0.f, my_m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = cbase + 4 * cq + i;
+            if (a.bias) {
+                const float bv = co < a.cout ? a.bias[co] : 0.f;
+#pragma unroll
+                for (int p = 0; p < kDPX; ++p) acc[p][i] += bv;
+            }
+            if (a.part) {
+                const float pilot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, acc[0][i]), src_lane));
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int p = 0; p < kDPX; ++p) {
+                    const float e = valid[p] ? acc[p][i] - pilot : 0.f;
+                    s1 += e;
+                    s2 = fmaf(e, e, s2);
+                }
+                const float S1 = san_wave_total(s1), S2 = san_wave_total(s2);
+                if (lane == i) {
+                    my_mean = pilot + S1 * inv;
+                    my_m2 = fmaxf(S2 - S1 * S1 * inv, 0.f);
+                }
+            }
+        }
+        if (a.part && lane < 4 && cbase + 4 * cq + lane < a.cout) {
+            const int tiles = ntile * 4;
+            float* o = a.part + ((size_t)(n * a.cout + cbase + 4 * cq + lane) * tiles + tile * 4 + wave) * 3;
+            o[0] = cnt;
+            o[1] = cnt > 0.f ? my_mean : 0.f;
+            o[2] = cnt > 0.f ? my_m2 : 0.f;
+        }
+        if (valid[0]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int co = cbase + 4 * cq + i;
+                if (co < a.cout) {
+                    float os = 1.f, ob = 0.f;
+                    if (a.out_scale) {
+                        os = a.out_scale[n * a.cout + co];
+                        ob = a.out_shift[n * a.cout + co];
+                    }
+                    float* dst = y + (size_t)(n * a.y_ctot + a.y_coff + co) * HW + (size_t)oy * W + ox;
+                    if (quad) {
+                        *reinterpret_cast<f4*>(dst) = f4{fmaf(acc[0][i], os, ob), fmaf(acc[1][i], os, ob), fmaf(acc[2][i], os, ob), fmaf(acc[3][i], os, ob)};
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < kDPX; ++p)
+                            if (valid[p]) dst[p] = fmaf(acc[p][i], os, ob);
+                    }
+                }
+            }
+        }
+    };
+
+    if constexpr (CK == 4) {
+        stage(0);
+        __syncthreads();
+        for (int cq = 0; cq < CW / 4; ++cq) {
+            if (cbase + 4 * cq >= a.cout) break;            // (padding quads of the last group)
+            clear();
+            compute(0, cq);
+            finish(cq);
+        }
+    } else {
+        clear();
+        for (int c0 = 0; c0 < cin; c0 += CK) {
+            if (c0) __syncthreads();                        // everyone is done with the previous chunk's tile
+            stage(c0);
+            __syncthreads();
+            if (c0 + CK < cin) fetch(c0 + CK);              // in flight while this chunk is computed
+            compute(c0, 0);
+        }
+        finish(0);
+    }
+}
+
+template <int CK, int KS>
+int launch_direct_cw(const float* x, const float* wp, float* y, const MArgs& a, hipStream_t s) {
+    constexpr int PAD = KS / 2;
+    constexpr int TILE = (kDTH + 2 * PAD) * ((kDTW + 2 * PAD + 3) & ~3);
+    const int tiles = san_cdiv(a.W, kDTW) * san_cdiv(a.H, kDTH);
+    dim3 grid(tiles * a.g.groups * a.N, 1, 1);
+    const size_t lds = ((size_t)CK * TILE + (size_t)a.cin * KS * KS * a.g.cw) * sizeof(float);
+    if (lds > 64 * 1024) {
+        san_set_error("direct convolution: %d input channels x %d do not fit the weight table", a.cin, a.g.cw);
+        return SAN_E_UNSUPPORTED;
+    }
+    if constexpr (CK == 4) {
+        switch (a.g.cw) {
+            case 4: hipLaunchKernelGGL((conv_direct_kernel<4, KS, 4>), grid, dim3(kThreads), lds, s, x, wp, y, a); break;
+            case 8: hipLaunchKernelGGL((conv_direct_kernel<4, KS, 8>), grid, dim3(kThreads), lds, s, x, wp, y, a); break;
+            case 16: hipLaunchKernelGGL((conv_direct_kernel<4, KS, 16>), grid, dim3(kThreads), lds, s, x, wp, y, a); break;
+            case 20: hipLaunchKernelGGL((conv_direct_kernel<4, KS, 20>), grid, dim3(kThreads), lds, s, x, wp, y, a); break;
+            default: san_set_error("bad cw %d", a.g.cw); return SAN_E_UNSUPPORTED;
+        }
+    } else {
+        if (a.g.cw != 4) {
+            san_set_error("direct convolution: cw %d with %d input channels", a.g.cw, a.cin);
+            return SAN_E_UNSUPPORTED;
+        }
+        hipLaunchKernelGGL((conv_direct_kernel<CK, KS, 4>), grid, dim3(kThreads), lds, s, x, wp, y, a);
+    }
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+template <int KS>
+int launch_direct(const float* x, const float* wp, float* y, const MArgs& a, hipStream_t s) {
+    if (a.cin <= 4) return launch_direct_cw<4, KS>(x, wp, y, a, s);
+    return launch_direct_cw<6, KS>(x, wp, y, a, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -665,8 +936,16 @@ int san_conv_pack_batch(const long long* jobs_dev, int njobs, void* stream) {
     return SAN_OK;
 }
 
+static bool g_direct = true;      // san_conv_direct_enable(0): every layer on the outer-product kernel (A/B, tests)
+
+int san_conv_direct_enable(int on) {
+    const int prev = g_direct ? 1 : 0;
+    if (on >= 0) g_direct = on != 0;
+    return prev;
+}
+
 int san_conv_stat_tiles(int n, int h, int w, int cin, int cout, int ks) {
-    (void)cin;
+    if (g_direct && direct_ok(cin, cout, ks)) return san_cdiv(w, kDTW) * san_cdiv(h, kDTH) * 4;      // one tile per wave
     MGeom g = mfma_geom(n, h, w, cout, ks);
     return g.tiles_x * g.tiles_y * g.WY;   // one statistics tile per wave row
 }
@@ -699,6 +978,10 @@ int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin, const float*
     a.H = h;
     a.W = w;
     a.g = mfma_geom(n, h, w, cout, ks);
+    if (g_direct && direct_ok(cin, cout, ks)) {
+        if (ks == 3) return launch_direct<3>(x, w_packed, y, a, (hipStream_t)stream);
+        return launch_direct<1>(x, w_packed, y, a, (hipStream_t)stream);
+    }
     if (ks == 3) return launch_mfma<3>(x, w_packed, y, a, (hipStream_t)stream);
     return launch_mfma<1>(x, w_packed, y, a, (hipStream_t)stream);
 }

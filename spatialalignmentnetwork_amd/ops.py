@@ -851,6 +851,15 @@ def current_precision() -> str:
     return {3: "bf16x3", 2: "bf16x2", 1: "fp8" if _FP8_FWD[0] else "bf16"}[_CONV_NP[0]]
 
 
+def conv_direct(on: bool) -> bool:
+    """Switch the direct fp32 kernel for layers with <= 4 channels on one side (csrc/san_conv_mfma.hip, round 5) on or off;
+    returns the previous setting.  Off: those layers run on the outer-product kernel as before (A/B runs, tests).  The
+    statistics-tile geometry differs between the two, so the memoised geometry queries are dropped."""
+    prev = bool(lib().query("san_conv_direct_enable", 1 if on else 0))
+    lib()._memo.clear()
+    return prev
+
+
 class conv_precision:
     """``with ops.conv_precision("bf16"): ...`` -- the mode inside the block, the previous one afterwards."""
 
