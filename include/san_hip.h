@@ -145,6 +145,10 @@ int san_conv_stat_tiles(int n, int h, int w, int cin, int cout, int ks);
  * varnet.py:139-146,96-104 and their data gradients) run on a direct fp32 kernel behind san_conv2d_fwd; 0 switches that off
  * (everything on the outer-product kernel: A/B and tests), -1 only asks.  Returns the previous setting. */
 int san_conv_direct_enable(int on);
+/* Round 5: 1x1 and transposed convolutions on fp16-format weights (unet.py's 1x1 layers, varnet.py:159-192 and their data
+ * gradients) run as one-stage GEMMs behind san_conv1x1_bf16x3_fwd / san_tconv2x2_bf16x3_fwd / san_conv_bf16x3_dgrad_amax;
+ * 0 switches that off (the tiled kernel's KS = 1 form, as before), -1 only asks.  Returns the previous setting. */
+int san_conv1x1_gemm_enable(int on);
 int san_conv2d_fwd(const float* x, int x_ctot, int x_coff, int cin,
                    const float* in_scale, const float* in_shift, float in_slope,
                    const float* w_packed, const float* bias,

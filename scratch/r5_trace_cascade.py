@@ -42,3 +42,16 @@ print("step span %.2f ms; main queue busy %.2f ms in %d launches; other queues b
     (max(int(r["End_Timestamp"]) for r in seg) - int(seg[0]["Start_Timestamp"])) / 1e6,
     sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ms) / 1e6, len(ms),
     sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg if r[qkey] != main) / 1e6, len(seg) - len(ms)))
+# the part of the step outside the cascades: before the first forward boundary and after the last backward boundary
+pf = [i for i, r in enumerate(ms) if "dc_rows320_kernel<0>" in r["Kernel_Name"]]
+pb = [i for i, r in enumerate(ms) if "dc_rows320_kernel<1>" in r["Kernel_Name"]]
+for tag, lo_, hi_ in (("head (set_input, packing, alignment + sensitivity forward)", 0, pf[0]), ("tail (sensitivity + alignment backward, optimiser)", pb[-1], len(ms))):
+    seg_ = ms[lo_:hi_]
+    print(f"==== {tag}: {len(seg_)} launches, {(int(seg_[-1]['End_Timestamp']) - int(seg_[0]['Start_Timestamp'])) / 1e3:.1f} us")
+    agg = collections.OrderedDict()
+    for r in seg_:
+        k = short(r["Kernel_Name"])
+        c, t = agg.get(k, (0, 0))
+        agg[k] = (c + 1, t + int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+        print(f"   {t / 1e3:8.1f} us  x{c:3d}  avg {t / c / 1e3:6.1f}  {k}")

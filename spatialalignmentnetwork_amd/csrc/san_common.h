@@ -9,6 +9,29 @@
 
 void san_set_error(const char* fmt, ...);
 
+// 1x1 / transposed convolution as a one-stage GEMM (san_conv1x1.hip), launched by conv_bf16x3_run (san_conv_bf16.hip) for KS = 1
+// layers whose weights are packed as two fp16 parts.  Internal to the library (not part of the ABI).
+struct SanGemm1x1Args {
+    const float* x;
+    const float* in_scale;
+    const float* in_shift;
+    const void* wp;            // packed image [chunk][block of 16 couts][part][64 lanes] x 16 B (ks = 1: one K-step per chunk)
+    const float* bias;
+    float* y;
+    float* part;               // statistics records or null: `slots` per (sample, channel) plane (x 4 interleaved when shuffling)
+    const uint32_t* amax;      // gradient input: its amax record (the input is scaled by a power of two), else null
+    float in_slope;
+    int x_ctot, x_coff, cin;
+    int y_ctot, y_coff, cout;  // cout: channels of the GEMM (4 x the real channels when shuffling)
+    int N, H, W;
+    int chunks, nblkp;
+    int shuffle;               // 1: ConvTranspose2d 2x2 s2 -- 4 virtual channels per real channel + pixel shuffle
+    int slots;
+    int ngrp, ptiles;          // (filled by the launcher)
+};
+bool san_gemm1x1_enabled();
+int san_gemm1x1_f16_run(SanGemm1x1Args a, void* stream);
+
 #define SAN_CHECK_ARG(cond, msg)                       \
     do {                                               \
         if (!(cond)) {                                 \

@@ -1333,6 +1333,34 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
         san_conv_stream_eligible(n, h, w, cin, cout, x_ctot))
         return san_conv_stream_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, p.nblkp, bias, y, y_ctot, y_coff, cout,
                                    part_stats, a.amax, n, h, w, stream, stream_f16 ? 2 : 1);
+    if (ks == 1 && a.fmt == 1 && g_conv_np == 3 && g_b16_mb < 0 && san_gemm1x1_enabled()) {
+        // round 5: the whole K range staged once, no barrier between K-steps (san_conv1x1.hip)
+        const TileGeom tg1 = tile_geom(h, w);
+        SanGemm1x1Args g{};
+        g.x = x;
+        g.in_scale = in_scale;
+        g.in_shift = in_shift;
+        g.in_slope = in_slope;
+        g.wp = w_packed;
+        g.bias = bias;
+        g.y = y;
+        g.part = part_stats;
+        g.amax = a.amax;
+        g.x_ctot = x_ctot;
+        g.x_coff = x_coff;
+        g.cin = cin;
+        g.y_ctot = y_ctot;
+        g.y_coff = y_coff;
+        g.cout = cout;
+        g.N = n;
+        g.H = h;
+        g.W = w;
+        g.chunks = p.chunks;
+        g.nblkp = p.nblkp;
+        g.shuffle = shuffle;
+        g.slots = tg1.tiles_x * tg1.tiles_y * 4;
+        return san_gemm1x1_f16_run(g, stream);
+    }
     a.dbg = g_b16_dbg;
     a.shuffle = shuffle;
     a.bias = bias;

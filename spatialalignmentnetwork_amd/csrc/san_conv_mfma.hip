@@ -28,6 +28,8 @@
 // Epilogue: bias, per-tile (count, mean, M2) statistics for Instance/BatchNorm,
 // optional per-(n, c) output affine, coalesced stores (a wave writes GW
 // consecutive pixels of one channel).
+#include <stdlib.h>
+
 #include "san_common.h"
 
 namespace {
@@ -936,7 +938,8 @@ int san_conv_pack_batch(const long long* jobs_dev, int njobs, void* stream) {
     return SAN_OK;
 }
 
-static bool g_direct = true;      // san_conv_direct_enable(0): every layer on the outer-product kernel (A/B, tests)
+// san_conv_direct_enable(0) or SAN_CONV_DIRECT=0 in the environment: every layer on the outer-product kernel (A/B, tests)
+static bool g_direct = !(getenv("SAN_CONV_DIRECT") && atoi(getenv("SAN_CONV_DIRECT")) == 0);
 
 int san_conv_direct_enable(int on) {
     const int prev = g_direct ? 1 : 0;

@@ -860,6 +860,12 @@ def conv_direct(on: bool) -> bool:
     return prev
 
 
+def conv1x1_gemm(on: bool) -> bool:
+    """Switch the one-stage GEMM form of the 1x1 / transposed convolutions (csrc/san_conv1x1.hip, round 5) on or off; returns the
+    previous setting.  Off: the tiled kernel's KS = 1 form, as before (A/B runs, tests)."""
+    return bool(lib().query("san_conv1x1_gemm_enable", 1 if on else 0))
+
+
 class conv_precision:
     """``with ops.conv_precision("bf16"): ...`` -- the mode inside the block, the previous one afterwards."""
 
