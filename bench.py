@@ -117,6 +117,9 @@ def parse_args(argv=None):
                          "CSModel.record_update and the timed steps are replays -- the same kernels, stream / event and torch "
                          "operations with the same arguments as a flat call list; the eager step is host-limited by ~5 %%)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin each rank to its own share of the host cores")
+    ap.add_argument("--digest", action="store_true",
+                    help="add `state_digest` to the line: sha256 over both networks' parameters and buffers after the timed steps "
+                         "(tests compare the one-rank RCCL run with the plain run bit for bit)")
     ap.add_argument("--launch-test", action="store_true",
                     help="(CPU) exercise only the launcher: rendezvous over gloo, barrier, max-over-ranks, one JSON line")
     return ap.parse_args(argv)
@@ -414,6 +417,8 @@ def main(argv=None):
 
     if args.mode == "train":
         net.train()
+        if dist is not None:
+            net.sync_replicas()                     # rank 0's weights, moments and sampling mask everywhere, BEFORE the first set_input
         net.time_exchange = dist is not None        # HIP events around the gradient all-reduces (communication stream)
         step = lambda: train_step(net, img_full, img_aux)
     else:
@@ -502,6 +507,16 @@ def main(argv=None):
     if args.mode == "train" and dist is not None and not args.graph:
         # (a recorded step holds ONE set of event pairs, re-recorded by every replay: the last replay's duration)
         allreduce_ms = sdist.max_over_ranks(net.exchange_ms(), dist, dev) / (1 if replaying else args.steps)
+
+    state_digest = None
+    if args.digest:
+        import hashlib
+        hsh = hashlib.sha256()
+        for mod in (net.net_R, net.net_T):
+            for k, v in mod.state_dict().items():
+                hsh.update(k.encode())
+                hsh.update(v.detach().cpu().contiguous().numpy().tobytes())
+        state_digest = hsh.hexdigest()
 
     eager_leg = None
     if args.mode == "train" and replaying and not args.graph and not args.main_only:
@@ -627,7 +642,9 @@ def main(argv=None):
                        "parallelism": f"dp{world} (independent slice shards; one RCCL all-reduce of the flat gradient "
                                       f"buffers per step)" if args.mode == "train" else
                                       f"dp{world} (independent slice shards, no data-path collective)",
-                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks, "dispatch": DISPATCH, "hip_graph": bool(args.graph),
+                       "collective_backend": sdist.BACKEND, "nccl_ranks": nccl_ranks,
+                       "native_rccl": (sdist.NATIVE["handle"] is not None) if sdist.BACKEND == "nccl" else None,
+                       "native_rccl_note": sdist.NATIVE["why"] if sdist.BACKEND == "nccl" else None, "dispatch": DISPATCH, "hip_graph": bool(args.graph),
                        "step_mode": step_mode, "hip_graph_mode": getattr(graph, "mode", None),
                        "cores_per_rank": len(my_cores) if my_cores else None},
             # the host's share of a step (time until step() returns = everything is enqueued; max over ranks): a value close
@@ -638,6 +655,9 @@ def main(argv=None):
             # bucket overlaps the alignment network's backward); null on one GPU and in --graph mode
             "allreduce_ms": allreduce_ms,
         }
+        if state_digest is not None:
+            out["state_digest"] = state_digest
+            out["optimizer_steps"] = int(net.optim_R.steps_taken()) if args.mode == "train" else 0
         if eager_leg is not None:
             out["eager_step"] = eager_leg
         if infer is not None:

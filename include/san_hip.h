@@ -626,6 +626,21 @@ int san_adamw_step_hyper(float* p, const float* g, float* m, float* v, size_t co
                          float beta2, float eps, float weight_decay, long long* step_dev, float grad_scale,
                          const float* hyper_dev, void* stream);
 
+/* ------------------------------------------------------------- gradient exchange on RCCL (round 5) */
+
+/* The data-parallel step's all-reduces as C-ABI calls (csrc/san_rccl.cpp), so that a recorded step's tape walks them like kernel
+ * launches.  The reference has no data parallelism; these replace torch.distributed.all_reduce on the flat
+ * gradient buffers inside CSModel.update().  RCCL is not linked: san_rccl_load binds the shared object at `path` (the copy the
+ * process already has -- torch's; NULL = "librccl.so.1") and returns its version code in *version (may be NULL).
+ * san_rccl_unique_id fills 128 bytes on rank 0; every rank passes them to san_rccl_comm_init (collective, blocking; the calling
+ * thread's HIP device is the rank's GPU), which returns a communicator handle.  san_rccl_allreduce_sum_f32 sums buf[0 .. count)
+ * in place over the ranks, stream-ordered on `stream`. */
+int san_rccl_load(const char* path, int* version);
+int san_rccl_unique_id(void* id128);
+int san_rccl_comm_init(const void* id128, int world, int rank, int* handle);
+int san_rccl_allreduce_sum_f32(int handle, float* buf, size_t count, void* stream);
+int san_rccl_comm_destroy(int handle);
+
 /* ------------------------------------------------------------- recorded steps */
 
 /* Walks a "tape" of recorded calls on the host, in order (csrc/san_replay.cpp; the host-side mirror of the reference's train loop

@@ -50,6 +50,8 @@ def init(backend: str, device=None, allow_fallback: bool = False):
             dist.all_reduce(t)                      # fail here, not inside the timed region
             torch.cuda.synchronize()
             BACKEND = "nccl"
+            if device is not None:
+                native_rccl(dist, device)           # the step's own communicator (collective: every rank is here)
             return dist
         except Exception as e:                     # pragma: no cover (needs a multi-GPU box)
             if not allow_fallback:
@@ -64,6 +66,98 @@ def init(backend: str, device=None, allow_fallback: bool = False):
     dist.init_process_group(backend)
     BACKEND = backend
     return dist
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Native RCCL communicator for the step's all-reduces (csrc/san_rccl.cpp, round 5): a recorded step then holds its collectives
+# as C-ABI tape entries (san_rccl_allreduce_sum_f32 on the communication stream) instead of Python closures around
+# torch.distributed.all_reduce.  torch's process group stays in charge of everything else (and of the step itself whenever the
+# native communicator cannot be built: SAN_NATIVE_RCCL=0, a backend other than nccl, a failed or timed-out ncclCommInitRank on
+# ANY rank -- the ranks agree on the outcome through the process group before anybody uses it).
+NATIVE = {"handle": None, "tried": False, "why": "not tried", "version": None}
+
+
+def _loaded_rccl_path():
+    try:
+        for line in open("/proc/self/maps"):
+            if "librccl" in line:
+                return line.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
+def native_rccl(dist, device, timeout_s: float = 120.0):
+    """Handle of the package's own RCCL communicator over the ranks of ``dist`` (built on first use: a COLLECTIVE call), or None."""
+    if NATIVE["tried"]:
+        return NATIVE["handle"]
+    from . import _lib
+    if _lib.REC is not None or torch.cuda.is_current_stream_capturing():
+        return None                     # (never built inside a recording / capture: the eager warm-up steps come first)
+    NATIVE["tried"] = True
+    if os.environ.get("SAN_NATIVE_RCCL", "1") == "0":
+        NATIVE["why"] = "SAN_NATIVE_RCCL=0"
+        return None
+    if dist is None or backend() != "nccl" or device is None or torch.device(device).type != "cuda":
+        NATIVE["why"] = f"backend {backend()}"
+        return None
+    import ctypes
+    import threading
+    lib = _lib.lib()
+    device = torch.device(device)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ok, why, handle = 1, "", ctypes.c_int(-1)
+    idbuf = torch.zeros(128, dtype=torch.uint8)
+    try:
+        ver = ctypes.c_int(0)
+        lib.call("san_rccl_load", (_loaded_rccl_path() or "").encode(), ctypes.byref(ver))
+        NATIVE["version"] = ver.value
+        if rank == 0:
+            raw = ctypes.create_string_buffer(128)
+            lib.call("san_rccl_unique_id", raw)
+            idbuf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+    except Exception as e:                                  # (every rank still takes part in the exchanges below)
+        ok, why = 0, f"{type(e).__name__}: {e}"
+    dev_id = idbuf.to(device)
+    dist.broadcast(dev_id, src=0)
+    idbytes = bytes(dev_id.cpu().numpy().tobytes())
+    if ok:
+        res = {}
+
+        def _init():
+            try:
+                torch.cuda.set_device(device)               # (the HIP device is per thread)
+                lib.call("san_rccl_comm_init", idbytes, world, rank, ctypes.byref(handle))
+                res["ok"] = True
+            except Exception as e:
+                res["err"] = f"{type(e).__name__}: {e}"
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(timeout_s)
+        if th.is_alive():
+            ok, why = 0, f"ncclCommInitRank did not return within {timeout_s:.0f} s"
+        elif not res.get("ok"):
+            ok, why = 0, res.get("err", "ncclCommInitRank failed")
+    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) and ok:
+        # one probe sum through the new communicator, checked and agreed on, before the step depends on it
+        probe = torch.ones(4, dtype=torch.float32, device=device)
+        try:
+            lib.call("san_rccl_allreduce_sum_f32", handle.value, probe.data_ptr(), 4, torch.cuda.current_stream(device).cuda_stream)
+            torch.cuda.synchronize(device)
+            good = bool((probe == float(world)).all().item())
+        except Exception as e:
+            good, why = False, f"{type(e).__name__}: {e}"
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            NATIVE["handle"], NATIVE["why"] = handle.value, "ok"
+            return handle.value
+        why = why or "probe all-reduce gave a wrong sum on some rank"
+    NATIVE["why"] = why or "another rank could not build the communicator"
+    return None
 
 
 def prebind_streams(device) -> None:
@@ -278,7 +372,12 @@ class GradExchange:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             _lib.rec(e0.record, comm)
-        _lib.rec(_collective)
+        nat = native_rccl(dist, flat.device)
+        if nat is not None:
+            # a C-ABI call on the communication stream: a tape entry of the recorded step, no Python at replay time
+            _lib.lib().call("san_rccl_allreduce_sum_f32", nat, flat.data_ptr(), flat.numel(), comm.cuda_stream)
+        else:
+            _lib.rec(_collective)
         if timed:
             _lib.rec(e1.record, comm)
             self.events.append((e0, e1))

@@ -200,3 +200,40 @@ def test_grid_sample_image_gradient_is_bit_reproducible_and_matches_autograd(S):
     im2 = g(img).requires_grad_(True)
     S.autograd.warp(im2, g(grid)).backward(g(gout))
     assert torch.equal(im2.grad, first)
+
+
+# --------------------------------------------------------------------------------- bench.py through the launcher on one-rank RCCL
+def test_bench_launcher_runs_the_exchange_on_rccl_with_one_rank():
+    """``python bench.py --gpus 1`` with SAN_DIST_SINGLE=1 brings up a one-rank RCCL process group and runs the
+    WHOLE data-parallel step through it -- communicator, probe all-reduce, per-cascade slices on the communication stream inside
+    the recorded replays, the join in front of AdamW.  The line must say so (backend nccl, measured all-reduce time, the replayed
+    step), and three steps must leave the parameters BIT-identical to the plain single-GPU run of the same command."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+           "--main-only", "--no-kernel-timer", "--digest"]
+
+    def run(single):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("SAN_DIST_SINGLE", None)
+        if single:
+            env["SAN_DIST_SINGLE"] = "1"
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    plain, single = run(False), run(True)
+    assert plain["config"]["collective_backend"] is None and plain["allreduce_ms"] is None
+    assert single["config"]["collective_backend"] == "nccl" and single["config"]["nccl_ranks"] == 1
+    assert single["allreduce_ms"] is not None and single["allreduce_ms"] >= 0.0
+    assert single["config"]["step_mode"].startswith("CSModel.update(): replay")
+    assert single["n_gpus"] == 1 and single["steps"] == 3 and single["value"] > 0
+    assert single["config"]["native_rccl"] is True, single["config"]["native_rccl_note"]     # the all-reduces are C-ABI tape entries
+    assert single["optimizer_steps"] == plain["optimizer_steps"] >= 4
+    assert single["state_digest"] == plain["state_digest"]
