@@ -26,6 +26,7 @@ import csv, glob, os, json
 R = os.environ['GRAFT_REPO_ROOT']; TAG = os.environ['TAG']
 def family(k):
     return ('cal_apply' if 'apply_kernel' in k else 'cal_rss' if 'rss_kernel' in k and 'bwd' not in k else
+            'gemm1x1' if 'gemm1x1_f16_kernel' in k else 'conv_direct' if 'conv_direct_kernel' in k else
             'conv_bf16x3_1x1' if 'conv_bf16x3_kernel' in k and (', true, 1, ' in k or ', false, 1, ' in k) else
             'conv_bf16x3' if 'conv_bf16x3_kernel' in k else
             'conv_stream' if 'conv3x3_stream_kernel' in k else

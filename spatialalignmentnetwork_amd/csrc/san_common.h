@@ -26,6 +26,7 @@ struct SanGemm1x1Args {
     int N, H, W;
     int chunks, nblkp;
     int shuffle;               // 1: ConvTranspose2d 2x2 s2 -- 4 virtual channels per real channel + pixel shuffle
+    int bf1;                   // 1: bf16-format image, one part (plain bf16 operands, one product); 0: two fp16 parts, three products
     int slots;
     int ngrp, ptiles;          // (filled by the launcher)
 };

@@ -11,7 +11,8 @@
 // straight from the packed image in L2 / L1 (already in MFMA lane order), requested one K-step ahead.  Same packed weights (two fp16
 // parts, 24 channels + 8 zero columns per K-step of 32), same three products per MAC (a1 w1 + a1 w2 + a2 w1), same epilogue
 // contract as the tiled kernel: bias, per-tile (count, mean, M2) statistics, pixel shuffle, power-of-two rescale of amax-scaled
-// gradient inputs.  Only the fp32-equivalent two-fp16-part format runs here; the narrow modes stay on the tiled kernel.
+// gradient inputs.  Formats: two fp16 parts (the fp32-equivalent mode) and one plain bf16 part (the narrow modes' one-product
+// layers: BF1); three bf16 parts and fp8 stay on the tiled kernel.
 #include <stdlib.h>
 
 #include "san_common.h"
@@ -26,12 +27,19 @@ constexpr int kMaxChunks = 12;               // K-steps staged at once (288 chan
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float fl2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
 typedef __attribute__((ext_vector_type(2))) _Float16 hf2;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 union Frag {
     u32x4 u;
     h8 h;
+    bf8 v;
 };
+__device__ __forceinline__ uint32_t cvt_pk_b(float f0, float f1) {
+    const fl2 v = {f0, f1};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));      // round to nearest even
+}
 
 __device__ __forceinline__ uint32_t cvt_pk_h(float f0, float f1) {
     const fl2 v = {f0, f1};
@@ -58,7 +66,9 @@ __host__ __device__ inline int pixel_stride(int chunks) {
 // ring of weight fragments runs kWD K-steps ahead, and a wave's statistics cover the whole tile (no cross-wave merge).
 constexpr int kWD = 4;
 
-template <int NGW, bool SHUFFLE>
+// BF1: the one-part plain-bf16 form of the narrow-precision modes (san_set_conv_precision(1): one product per MAC on part 0 of a
+// bf16-format image, activations rounded to bf16 while they are staged, no amax scale -- bf16 has fp32's exponent range).
+template <int NGW, bool SHUFFLE, bool BF1>
 __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -81,7 +91,7 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
 
     // gradient input in the fp16 format: x S (S = 2^(13 - floor(log2 max |x|)), exact) rides in the affine, the outputs get 1 / S
     float inS = 1.f, inInvS = 1.f;
-    if (a.amax) {
+    if (!BF1 && a.amax) {
         const uint32_t b = san_amax_read(a.amax);
         int e = (int)((b >> 23) & 255u);
         if (b != 0u) {
@@ -115,7 +125,7 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
 #pragma unroll
             for (int m = 0; m < NGW; ++m) {
                 dst[m][0].u = src[(m * 4 * 3 + 0) * 64];
-                dst[m][1].u = src[(m * 4 * 3 + 1) * 64];
+                if constexpr (!BF1) dst[m][1].u = src[(m * 4 * 3 + 1) * 64];
             }
         };
 #pragma unroll
@@ -150,12 +160,13 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
                             }
                             t0 = __builtin_amdgcn_fmed3f(t0, t0 * a.in_slope, lrelu_c);
                             t1 = __builtin_amdgcn_fmed3f(t1, t1 * a.in_slope, lrelu_c);
-                            split2h_pair(t0, t1, q1[i >> 1], q2[i >> 1]);
+                            if constexpr (BF1) q1[i >> 1] = cvt_pk_b(t0, t1);
+                            else split2h_pair(t0, t1, q1[i >> 1], q2[i >> 1]);
                         }
                     }
                     // (group `ngroups` = the zero columns behind the last K-step; pixels past the image are zero rows)
                     *reinterpret_cast<u32x4*>(lds1 + spx * S + g * 16) = u32x4{q1[0], q1[1], q1[2], q1[3]};
-                    *reinterpret_cast<u32x4*>(lds2 + spx * S + g * 16) = u32x4{q2[0], q2[1], q2[2], q2[3]};
+                    if constexpr (!BF1) *reinterpret_cast<u32x4*>(lds2 + spx * S + g * 16) = u32x4{q2[0], q2[1], q2[2], q2[3]};
                 }
             }
         }
@@ -171,13 +182,16 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         x1[b].u = *reinterpret_cast<const u32x4*>(xrow + (size_t)(16 * b) * S + (c + d) * (kCKC * 2));
-                        x2[b].u = *reinterpret_cast<const u32x4*>(xrow + (size_t)(16 * b) * S + (size_t)kTP * S + (c + d) * (kCKC * 2));
+                        if constexpr (!BF1) x2[b].u = *reinterpret_cast<const u32x4*>(xrow + (size_t)(16 * b) * S + (size_t)kTP * S + (c + d) * (kCKC * 2));
                     }
 #pragma unroll
                     for (int m = 0; m < NGW; ++m)
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {
-                            if constexpr (SHUFFLE) {       // D rows = channels: a lane ends with the 4 virtual channels of one real channel
+                            if constexpr (BF1) {
+                                if constexpr (SHUFFLE) acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[d][m][0].v, x1[b].v, acc[m][b], 0, 0, 0);
+                                else acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1[b].v, wq[d][m][0].v, acc[m][b], 0, 0, 0);
+                            } else if constexpr (SHUFFLE) {       // D rows = channels: a lane ends with the 4 virtual channels of one real channel
                                 acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[d][m][0].h, x1[b].h, acc[m][b], 0, 0, 0);
                                 acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[d][m][0].h, x2[b].h, acc[m][b], 0, 0, 0);
                                 acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[d][m][1].h, x1[b].h, acc[m][b], 0, 0, 0);
@@ -356,21 +370,21 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
 // SAN_CONV1X1_GEMM=0 in the environment: off from the start (same-box A/B of whole steps)
 int g_gemm1x1 = (getenv("SAN_CONV1X1_GEMM") && atoi(getenv("SAN_CONV1X1_GEMM")) == 0) ? 0 : 1;
 
-template <int NGW>
+template <int NGW, bool BF1>
 int launch_ng(const SanGemm1x1Args& a, size_t lds, hipStream_t s) {
     const dim3 grid(a.ptiles * a.ngrp * a.N);
     static bool configured[2] = {false, false};
     const int k = a.shuffle ? 1 : 0;
     if (!configured[k]) {
-        const void* fn = a.shuffle ? reinterpret_cast<const void*>(&gemm1x1_f16_kernel<NGW, true>) : reinterpret_cast<const void*>(&gemm1x1_f16_kernel<NGW, false>);
+        const void* fn = a.shuffle ? reinterpret_cast<const void*>(&gemm1x1_f16_kernel<NGW, true, BF1>) : reinterpret_cast<const void*>(&gemm1x1_f16_kernel<NGW, false, BF1>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
             san_set_error("cannot reserve 96 KB of LDS for the 1x1 GEMM");
             return SAN_E_UNSUPPORTED;
         }
         configured[k] = true;
     }
-    if (a.shuffle) hipLaunchKernelGGL((gemm1x1_f16_kernel<NGW, true>), grid, dim3(kT), lds, s, a);
-    else hipLaunchKernelGGL((gemm1x1_f16_kernel<NGW, false>), grid, dim3(kT), lds, s, a);
+    if (a.shuffle) hipLaunchKernelGGL((gemm1x1_f16_kernel<NGW, true, BF1>), grid, dim3(kT), lds, s, a);
+    else hipLaunchKernelGGL((gemm1x1_f16_kernel<NGW, false, BF1>), grid, dim3(kT), lds, s, a);
     return SAN_OK;
 }
 
@@ -402,13 +416,21 @@ int san_gemm1x1_f16_run(SanGemm1x1Args a, void* stream) {
         return SAN_E_ARG;
     }
     const int kc = a.chunks < kMaxChunks ? a.chunks : kMaxChunks;
-    const size_t lds = (size_t)2 * kTP * pixel_stride(kc);
+    const size_t lds = (size_t)(a.bf1 ? 1 : 2) * kTP * pixel_stride(kc);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    switch (NGW) {
-        case 1: rc = launch_ng<1>(a, lds, s); break;
-        case 2: rc = launch_ng<2>(a, lds, s); break;
-        default: rc = launch_ng<3>(a, lds, s); break;
+    if (a.bf1) {
+        switch (NGW) {
+            case 1: rc = launch_ng<1, true>(a, lds, s); break;
+            case 2: rc = launch_ng<2, true>(a, lds, s); break;
+            default: rc = launch_ng<3, true>(a, lds, s); break;
+        }
+    } else {
+        switch (NGW) {
+            case 1: rc = launch_ng<1, false>(a, lds, s); break;
+            case 2: rc = launch_ng<2, false>(a, lds, s); break;
+            default: rc = launch_ng<3, false>(a, lds, s); break;
+        }
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();

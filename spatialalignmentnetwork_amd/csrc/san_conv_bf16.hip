@@ -1333,7 +1333,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
         san_conv_stream_eligible(n, h, w, cin, cout, x_ctot))
         return san_conv_stream_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, p.nblkp, bias, y, y_ctot, y_coff, cout,
                                    part_stats, a.amax, n, h, w, stream, stream_f16 ? 2 : 1);
-    if (ks == 1 && a.fmt == 1 && g_conv_np == 3 && g_b16_mb < 0 && san_gemm1x1_enabled()) {
+    if (ks == 1 && ((a.fmt == 1 && g_conv_np == 3) || (a.fmt == 0 && g_conv_np == 1)) && g_b16_mb < 0 && san_gemm1x1_enabled()) {
         // round 5: the whole K range staged once, no barrier between K-steps (san_conv1x1.hip)
         const TileGeom tg1 = tile_geom(h, w);
         SanGemm1x1Args g{};
@@ -1358,6 +1358,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
         g.chunks = p.chunks;
         g.nblkp = p.nblkp;
         g.shuffle = shuffle;
+        g.bf1 = a.fmt == 0 ? 1 : 0;
         g.slots = tg1.tiles_x * tg1.tiles_y * 4;
         return san_gemm1x1_f16_run(g, stream);
     }

@@ -237,3 +237,176 @@ def test_bench_launcher_runs_the_exchange_on_rccl_with_one_rank():
     assert single["config"]["native_rccl"] is True, single["config"]["native_rccl_note"]     # the all-reduces are C-ABI tape entries
     assert single["optimizer_steps"] == plain["optimizer_steps"] >= 4
     assert single["state_digest"] == plain["state_digest"]
+
+
+# ----------------------------------------------------------------- round-5 kernels: direct small-channel convolution, one-stage GEMM
+def _act64(x, sc, sh, slope):
+    xd = x.double() * sc.double()[:, :, None, None] + sh.double()[:, :, None, None]
+    return torch.where(xd >= 0, xd, xd * slope)
+
+
+def _merge_stats(part):
+    """(mean, biased variance, count) per (sample, channel) from statistics records [n, c, tiles, 3] = (count, mean, M2)."""
+    cnt, mean, m2 = part[..., 0].double(), part[..., 1].double(), part[..., 2].double()
+    assert torch.isfinite(part).all()
+    tot = cnt.sum(-1)
+    mu = (cnt * mean).sum(-1) / tot
+    var = (m2 + cnt * (mean - mu[..., None]) ** 2).sum(-1) / tot
+    return mu, var, tot
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,ks,dgrad,aff,bias_on", [
+    (8, 4, 18, 320, 320, 3, False, True, False),        # the cascade's first convolution (varnet.py:139-146)
+    (8, 18, 2, 320, 320, 1, False, True, True),         # its output convolution
+    (8, 2, 18, 320, 320, 1, True, False, False),        # ... and their data gradients
+    (8, 18, 4, 320, 320, 3, True, False, False),
+    (2, 3, 7, 50, 37, 3, False, True, True),            # odd sizes, W % 4 != 0
+    (1, 2, 64, 96, 132, 3, False, False, True),         # several channel groups
+    (3, 20, 3, 61, 70, 3, True, False, False),          # several input chunks, partial last chunk
+    (2, 1, 8, 40, 23, 1, False, True, False),
+    (15, 2, 8, 160, 92, 3, False, False, False)])       # the sensitivity net's first layer on 15 coil planes
+def test_direct_small_channel_convolution_vs_float64_and_outer_product_kernel(S, n, cin, cout, h, w, ks, dgrad, aff, bias_on):
+    """conv_direct_kernel (csrc/san_conv_mfma.hip) behind san_conv2d_fwd: outputs and merged statistics against float64 (3e-6, the
+    bar of the fp32 convolutions; measured 1-5e-7), and within 1e-6 of the outer-product kernel it replaces for these shapes."""
+    gen = torch.Generator().manual_seed(11)
+    x = g(torch.randn(n, cin, h, w, generator=gen))
+    sc = g(torch.rand(n, cin, generator=gen) + 0.5) if aff else None
+    sh = g(torch.randn(n, cin, generator=gen) * 0.3) if aff else None
+    wt = g(torch.randn(*((cin, cout) if dgrad else (cout, cin)), ks, ks, generator=gen) * 0.1)
+    bias = g(torch.randn(cout, generator=gen)) if bias_on else None
+    y = torch.empty(n, cout, h, w, device=DEV)
+    xa = S.ops.Act(x, 0, cin, sc, sh, 0.2 if aff else 1.0)
+    xin = _act64(x, sc, sh, 0.2) if aff else x.double()
+    if dgrad:
+        want = F.conv2d(xin, wt.double().flip(2, 3).transpose(0, 1), padding=ks // 2)
+    else:
+        want = F.conv2d(xin, wt.double(), None if bias is None else bias.double(), padding=ks // 2)
+    outs = {}
+    try:
+        for on in (True, False):
+            S.ops.conv_direct(on)
+            if dgrad:
+                S.ops.conv2d_dgrad(xa, wt, S.ops.full(y))
+                part = None
+            else:
+                part = S.ops.conv2d(xa, wt, bias, S.ops.full(y), stats=True, tag="t5").clone()
+            torch.cuda.synchronize()
+            outs[on] = (y.clone(), part)
+    finally:
+        S.ops.conv_direct(True)
+    scale = want.abs().max()
+    assert ((outs[True][0].double() - want).abs().max() / scale).item() < 3e-6
+    assert ((outs[True][0] - outs[False][0]).abs().max() / scale).item() < 1e-6
+    if not dgrad:
+        mu, var, tot = _merge_stats(outs[True][1])
+        assert float((tot - h * w).abs().max()) == 0.0
+        assert ((mu - want.mean((2, 3))).abs().max() / scale).item() < 3e-6
+        wv = want.var((2, 3), unbiased=False)
+        assert ((var - wv).abs().max() / wv.max()).item() < 3e-6
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(8, 288, 144, 20, 20), (8, 144, 72, 40, 40), (8, 72, 36, 80, 80), (8, 36, 18, 160, 160),
+                                            (2, 40, 20, 23, 46), (1, 64, 16, 92, 160), (15, 16, 8, 160, 92)])
+def test_transposed_convolution_as_one_stage_gemm(S, n, cin, cout, h, w):
+    """gemm1x1_f16_kernel (csrc/san_conv1x1.hip): ConvTranspose2d 2x2 s2 (varnet.py:159-192) forward with its statistics, and its
+    data gradient on an amax-scaled gradient input, against float64 (3e-6; measured 2-6e-7) and the tiled kernel's KS = 1 form
+    (1e-6).  The unused statistics slots must be empty, finite records."""
+    gen = torch.Generator().manual_seed(12)
+    x = g(torch.randn(n, cin, h, w, generator=gen))
+    sc, sh = g(torch.rand(n, cin, generator=gen) + 0.5), g(torch.randn(n, cin, generator=gen) * 0.3)
+    wt = g(torch.randn(cin, cout, 2, 2, generator=gen) * (1.0 / cin ** 0.5))
+    xa = S.ops.Act(x, 0, cin, sc, sh, 0.2)
+    y = torch.empty(n, cout, 2 * h, 2 * w, device=DEV)
+    want = F.conv_transpose2d(_act64(x, sc, sh, 0.2), wt.double(), stride=2)
+    dyp = g(torch.randn(n, 4 * cout, h, w, generator=gen) * 3e-5)
+    rec = S.ops.AMAX.next(DEV)
+    rec.zero_()
+    rec.view(torch.float32)[0] = dyp.abs().max()
+    da = S.ops.Act(dyp, 0, 4 * cout)
+    da.amax = rec
+    dx = torch.empty(n, cin, h, w, device=DEV)
+    wv = wt.reshape(cin, 4 * cout, 1, 1)
+    wantd = F.conv2d(dyp.double(), wv.double())
+    res = {}
+    try:
+        for on in (True, False):
+            S.ops.conv1x1_gemm(on)
+            part = S.ops.tconv2x2(xa, wt, S.ops.full(y), stats=True, tag="t5").clone()
+            S.ops.conv2d(da, wv, None, S.ops.full(dx), grad_input=True)
+            torch.cuda.synchronize()
+            res[on] = (y.clone(), part, dx.clone())
+    finally:
+        S.ops.conv1x1_gemm(True)
+    scale = want.abs().max()
+    assert ((res[True][0].double() - want).abs().max() / scale).item() < 3e-6
+    assert ((res[True][0] - res[False][0]).abs().max() / scale).item() < 1e-6
+    mu, var, tot = _merge_stats(res[True][1])
+    assert float((tot - 4 * h * w).abs().max()) == 0.0
+    assert ((mu - want.mean((2, 3))).abs().max() / scale).item() < 3e-6
+    wvar = want.var((2, 3), unbiased=False)
+    assert ((var - wvar).abs().max() / wvar.max()).item() < 3e-6
+    assert ((res[True][2].double() - wantd).abs().max() / wantd.abs().max()).item() < 3e-6
+    assert ((res[True][2] - res[False][2]).abs().max() / wantd.abs().max()).item() < 1e-6
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(8, 64, 64, 160, 160), (2, 48, 40, 33, 50), (8, 128, 32, 80, 80)])
+def test_1x1_convolution_as_one_stage_gemm_with_bias_views_and_statistics(S, n, cin, cout, h, w):
+    """The plain 1x1 form (unet.py's 1x1 layers): channel views on both sides, bias, statistics; HW % 4 != 0 takes the scalar stores."""
+    gen = torch.Generator().manual_seed(13)
+    xb = g(torch.randn(n, cin + 5, h, w, generator=gen))
+    sc, sh = g(torch.rand(n, cin + 5, generator=gen) + 0.5), g(torch.randn(n, cin + 5, generator=gen) * 0.3)
+    wt = g(torch.randn(cout, cin, 1, 1, generator=gen) * (1.0 / cin ** 0.5))
+    bias = g(torch.randn(cout, generator=gen))
+    want = F.conv2d(_act64(xb[:, 2:2 + cin], sc[:, 2:2 + cin], sh[:, 2:2 + cin], 0.2), wt.double(), bias.double())
+    xa = S.ops.Act(xb, 2, cin, sc, sh, 0.2)
+    try:
+        for on in (True, False):
+            S.ops.conv1x1_gemm(on)
+            yb = torch.zeros(n, cout + 3, h, w, device=DEV)
+            part = S.ops.conv2d(xa, wt, bias, S.ops.Act(yb, 1, cout), stats=True, tag="u5")
+            torch.cuda.synchronize()
+            assert float(yb[:, 0].abs().max()) == 0.0 and float(yb[:, 1 + cout:].abs().max()) == 0.0      # nothing outside the view
+            scale = want.abs().max()
+            assert ((yb[:, 1:1 + cout].double() - want).abs().max() / scale).item() < 3e-6
+            mu, var, tot = _merge_stats(part)
+            assert float((tot - h * w).abs().max()) == 0.0
+            assert ((mu - want.mean((2, 3))).abs().max() / scale).item() < 3e-6
+            wvar = want.var((2, 3), unbiased=False)
+            assert ((var - wvar).abs().max() / wvar.max()).item() < 3e-6
+    finally:
+        S.ops.conv1x1_gemm(True)
+
+
+def test_one_stage_gemm_plain_bf16_form_matches_the_tiled_kernel(S):
+    """Narrow-precision mode (one bf16 part): the GEMM form of a transposed convolution and of its data gradient against the tiled
+    kernel's (same roundings, same accumulation order per output: <= 1e-6 of each other) and against float64 at bf16 level."""
+    n, cin, cout, h, w = 8, 72, 36, 80, 80
+    gen = torch.Generator().manual_seed(14)
+    x = g(torch.randn(n, cin, h, w, generator=gen))
+    sc, sh = g(torch.rand(n, cin, generator=gen) + 0.5), g(torch.randn(n, cin, generator=gen) * 0.3)
+    wt = g(torch.randn(cin, cout, 2, 2, generator=gen) * (1.0 / cin ** 0.5))
+    xa = S.ops.Act(x, 0, cin, sc, sh, 0.2)
+    y = torch.empty(n, cout, 2 * h, 2 * w, device=DEV)
+    want = F.conv_transpose2d(_act64(x, sc, sh, 0.2), wt.double(), stride=2)
+    dyp = g(torch.randn(n, 4 * cout, h, w, generator=gen) * 3e-5)
+    dx = torch.empty(n, cin, h, w, device=DEV)
+    wv = wt.reshape(cin, 4 * cout, 1, 1)
+    wantd = F.conv2d(dyp.double(), wv.double())
+    res = {}
+    try:
+        with S.ops.conv_precision("bf16"):
+            for on in (True, False):
+                S.ops.conv1x1_gemm(on)
+                part = S.ops.tconv2x2(xa, wt, S.ops.full(y), stats=True, tag="b5").clone()
+                S.ops.conv2d(S.ops.Act(dyp, 0, 4 * cout), wv, None, S.ops.full(dx), grad_input=True)
+                torch.cuda.synchronize()
+                res[on] = (y.clone(), part, dx.clone())
+    finally:
+        S.ops.conv1x1_gemm(True)
+    scale = want.abs().max()
+    assert ((res[True][0] - res[False][0]).abs().max() / scale).item() < 1e-6
+    assert ((res[True][2] - res[False][2]).abs().max() / wantd.abs().max()).item() < 1e-6
+    assert ((res[True][0].double() - want).abs().max() / scale).item() < 2e-2
+    assert ((res[True][2].double() - wantd).abs().max() / wantd.abs().max()).item() < 2e-2
+    mu, var, tot = _merge_stats(res[True][1])
+    assert float((tot - 4 * h * w).abs().max()) == 0.0
