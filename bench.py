@@ -34,13 +34,18 @@ Rank 0 prints ONE JSON line (metric slices/s = all slices of all ranks / max ran
                    The LAST timed step is a second recording of the same step that carries an event pair around every 10th
                    launch of a conv family and around EVERY cascade-boundary launch (run alone: the two streams are joined
                    around it); the other timed steps run without brackets.  Eager mode: every 29th launch of every step.
-  roofline_*     : the same for the fused FFT + data-consistency kernels (HBM; forward and backward boundary: `frac` = one
-                   event pair around 12 back-to-back launches right after the timed region, the in-step single-launch
-                   brackets under `per_launch_brackets`), the norm + LeakyReLU backward family (HBM, bytes = the plane
-                   passes each call really makes) and the other conv families.
-                   `event_pair_overhead_us` = the elapsed time of an event pair with nothing in between, measured in
-                   the same run, and `frac_net_of_event_overhead` = frac with that subtracted from the launch time
-                   (a 16 us kernel reads ~19.5 us between its events); `achieved` / `frac` are the RAW event figures.
+  roofline_*     : the same for the fused FFT + data-consistency kernels (HBM; forward and backward cascade boundary; round 5:
+                   `frac` / `achieved` / `avg_launch_us` = the IN-STEP brackets of all 12 + 12 boundary launches NET of the event
+                   pair's own latency (`event_pair_overhead_us`, measured in the same run with nothing between the two records);
+                   `raw_with_event_pair` = the same brackets as measured; `back_to_back_cache_warm` = one event pair around 12
+                   re-issues of the same launch right after the timed region -- its 52 MB stay in the 256 MiB Infinity Cache, an
+                   upper bound, never the headline), the norm + LeakyReLU backward family (HBM, bytes = the plane passes each
+                   call really makes) and the other conv families: `achieved` / `frac` are the RAW event figures there,
+                   `frac_net_of_event_overhead` the same with the pair's latency subtracted.
+                   `rocprof` (every roofline object, default workload only): the family's launch-weighted average kernel duration in
+                   the committed rocprofv3 --kernel-trace --stats summary of this command (profiles/rNN_train_kernel_stats.csv)
+                   and the fraction that follows from it -- the cross-check of the event figures.
+                   `traffic` / `mfma_busy`: from the committed PMC passes (profiles/rNN_pmc.json), corrected as that file states.
   cpu_baseline   : the CPU oracle (PyTorch CPU restatement of the reference, same ATen kernels) timed on this box's
                    host cores: the same step incl. torch.optim.AdamW, N = 1 and N = 8, all usable cores and 1 thread.
 """

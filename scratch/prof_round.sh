@@ -8,6 +8,7 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
+if [ "${2:-pmc}" != "pmc_only" ]; then
 for mode in overlap serial; do
   rm -rf /tmp/pbench
   if [ $mode = serial ]; then export SAN_NO_WGRAD_OVERLAP=1; EXTRA=--main-only; else unset SAN_NO_WGRAD_OVERLAP; EXTRA=; fi
@@ -15,8 +16,9 @@ for mode in overlap serial; do
   grep '"metric"' /tmp/pbench_stdout.txt | tail -1 > $R/gpurun_out/${TAG}_${mode}_bench_line.json
   for f in /tmp/pbench/*kernel_stats.csv /tmp/pbench/*/*kernel_stats.csv; do if [ -f "$f" ]; then cp "$f" $R/gpurun_out/${TAG}_${mode}_kernel_stats.csv; fi; done
 done
+fi
 unset SAN_NO_WGRAD_OVERLAP
-if [ "${2:-pmc}" = "pmc" ]; then
+if [ "${2:-pmc}" = "pmc" ] || [ "${2:-pmc}" = "pmc_only" ]; then
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_f -o p -- python $R/scratch/pmc_traffic.py > /tmp/pmc_f.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_w -o p -- python $R/scratch/pmc_traffic.py > /tmp/pmc_w.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_m -o p -- python $R/scratch/pmc_traffic.py > /tmp/pmc_m.log 2>&1
