@@ -518,6 +518,11 @@ int san_conv_bf16x3_stat_tiles(int n, int h, int w);
 int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mode, void* stream);
 int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int cout, int cin, int mode);
 int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* stream);
+/* NOTE (round 5): the batched forms write only the units that can be non-zero; an image must have been zero-filled (or packed once by
+ * san_conv_bf16x3_pack_ks, which writes everything) before its first batched pack.
+ * The same with `blocks` (1..64) workgroups per job; fp8 != 0: run the per-tensor fp8 scale pass first (needed only when a job of
+ * the run has the fp8 format).  Callers sort their jobs by size and pack each size class with a fitting grid. */
+int san_conv_bf16x3_pack_batch_grid(const long long* jobs_dev, int njobs, int blocks, int fp8, void* stream);
 int san_conv2d_bf16x3_fwd(const float* x, int x_ctot, int x_coff, int cin,
                           const float* in_scale, const float* in_shift, float in_slope,
                           const void* w_packed, const float* bias,

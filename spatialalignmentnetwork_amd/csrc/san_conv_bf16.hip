@@ -899,6 +899,10 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restr
 // mode 0: w[co][ci], mode 2: w[ci][co].
 // One thread per (chunk, step, blk, lane): its 8 values (consecutive input channels of one tap) are gathered once,
 // split three ways and written as three 16-byte vectors (one per part).
+// FULL = false (the batched re-pack of every training step): units that are zero for the image's whole life -- channels past cout
+// in the padded blocks, the fourth lane row of the last K-step, the unused part slots of the fp16 / fp8 formats -- are NOT written:
+// the caller zero-fills an image once (round 5: they were 55-90 % of the bytes the batch stored, 0.3 ms per step).
+template <bool FULL>
 __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t u, int cout,
                                           int cin, int nblkp, int mode_, int ks, const float* __restrict__ wscale) {
     const bool f16 = (mode_ & 16) != 0;            // mode + 16: two fp16 parts (parts 0, 1 of the image; part 2 zero)
@@ -916,7 +920,8 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t*
     const int g = 4 * step + (lane >> 4);
     const int tap = g / 3;
     const int ci0 = chunk * kCKC + (g - 3 * tap) * 8;
-    const bool live = co < cout && (ks == 1 ? tap == 0 : tap < 9);
+    const bool live = co < cout && (ks == 1 ? tap == 0 : tap < 9) && ci0 < cin;
+    if (!FULL && !live) return;
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 q[3];
     float v8[8];
@@ -952,15 +957,17 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t*
         q[0] = u32x4{cvt_f8x4(v8[0], v8[1], v8[2], v8[3]), cvt_f8x4(v8[4], v8[5], v8[6], v8[7]), 0u, 0u};
         q[1] = q[2] = u32x4{0u, 0u, 0u, 0u};
     }
+    const int parts = FULL ? 3 : (f8 ? 1 : (f16 ? 2 : 3));
 #pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(o + (size_t)p * 64 * 8) = q[p];
+    for (int p = 0; p < 3; ++p)
+        if (p < parts) *reinterpret_cast<u32x4*>(o + (size_t)p * 64 * 8) = q[p];
 }
 
 __global__ void pack_bf16x3_kernel(const float* __restrict__ w, uint16_t* __restrict__ packed, size_t total, int cout,
                                    int cin, int nblkp, int mode, int ks) {
     const size_t units = total / 24;
     for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x)
-        pack_unit(w, packed, u, cout, cin, nblkp, mode, ks, reinterpret_cast<const float*>(packed + total));
+        pack_unit<true>(w, packed, u, cout, cin, nblkp, mode, ks, reinterpret_cast<const float*>(packed + total));
 }
 
 // batched: 8 x int64 per job = {w, packed, cout, cin, nblkp, ks (0 = 3), mode, total}
@@ -970,7 +977,7 @@ __global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
     uint16_t* packed = reinterpret_cast<uint16_t*>(j[1]);
     const size_t units = (size_t)j[7] / 24;
     for (size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x; u < units; u += (size_t)gridDim.x * blockDim.x)
-        pack_unit(w, packed, u, (int)j[2], (int)j[3], (int)j[4], (int)j[6], j[5] == 1 ? 1 : 3, reinterpret_cast<const float*>(packed + (size_t)j[7]));
+        pack_unit<false>(w, packed, u, (int)j[2], (int)j[3], (int)j[4], (int)j[6], j[5] == 1 ? 1 : 3, reinterpret_cast<const float*>(packed + (size_t)j[7]));
 }
 
 // fp8 format: the tensor's power-of-two scale {S_w, 1 / S_w}, S_w = 2^(7 - floor(log2 max |w|)) (scaled maximum in [128, 256)),
@@ -1298,9 +1305,17 @@ int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int 
 }
 
 int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* stream) {
+    return san_conv_bf16x3_pack_batch_grid(jobs_dev, njobs, 64, 1, stream);
+}
+
+// The same with `blocks` workgroups per job (1..64) and the fp8 scale pass only when some job of the run needs it.  The caller sorts
+// its jobs by size and packs each size class with a grid that fits it (round 5): with 64 workgroups for every one of ~660 jobs, most of
+// them a few hundred weights, the launch spent its 0.3 ms dispatching 42,000 workgroups that had nothing to do.
+int san_conv_bf16x3_pack_batch_grid(const long long* jobs_dev, int njobs, int blocks, int fp8, void* stream) {
     SAN_CHECK_ARG(jobs_dev && njobs > 0, "empty job table");
-    hipLaunchKernelGGL(fp8_wscale_batch_kernel, dim3(njobs), dim3(1024), 0, (hipStream_t)stream, jobs_dev);    // (returns at once for other formats)
-    hipLaunchKernelGGL(pack_bf16x3_batch_kernel, dim3(64, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+    SAN_CHECK_ARG(blocks >= 1 && blocks <= 64, "1..64 workgroups per job");
+    if (fp8) hipLaunchKernelGGL(fp8_wscale_batch_kernel, dim3(njobs), dim3(1024), 0, (hipStream_t)stream, jobs_dev);    // (returns at once for other formats)
+    hipLaunchKernelGGL(pack_bf16x3_batch_kernel, dim3(blocks, njobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

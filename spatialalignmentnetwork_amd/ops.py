@@ -710,9 +710,13 @@ class _PackRegistryBf16(_PackRegistry):
     mode 2 data gradient; dims = (cout, cin) of the convolution that will run."""
 
     def _alloc(self, w: torch.Tensor, mode: int):
+        with _lib.untracked():                          # (a one-time zero fill: not part of a recorded step)
+            return self._alloc_zeroed(w, mode)
+
+    def _alloc_zeroed(self, w: torch.Tensor, mode: int):
         mode &= 15                                      # (+16 = two fp16 parts, +32 = one fp8 part instead of bf16 parts: same image size)
         if mode == 3:                                   # ConvTranspose2d [Cin, Cout, 2, 2] as a 1x1 conv to 4 Cout channels
-            return (4 * w.shape[1], w.shape[0], 1), torch.empty(
+            return (4 * w.shape[1], w.shape[0], 1), torch.zeros(
                 lib().query("san_conv_bf16x3_packed_bytes_ks", 4 * w.shape[1], w.shape[0], 1), device=w.device, dtype=torch.uint8)
         if mode == 2:
             cout, cin = w.shape[1], w.shape[0]          # the data-gradient conv maps forward cout -> forward cin
@@ -720,7 +724,7 @@ class _PackRegistryBf16(_PackRegistry):
             cout, cin = w.shape[0], w.shape[1]
         ks = int(w.shape[2])
         nbytes = lib().query("san_conv_bf16x3_packed_bytes_ks", cout, cin, ks)
-        return (cout, cin, ks), torch.empty(nbytes, device=w.device, dtype=torch.uint8)
+        return (cout, cin, ks), torch.zeros(nbytes, device=w.device, dtype=torch.uint8)     # (zero-filled: the batched pack skips constant-zero units)
 
     def _fill_job(self, row, j):
         cout, cin, ks = j["dims"]
@@ -732,8 +736,37 @@ class _PackRegistryBf16(_PackRegistry):
         """registry mode -> library mode: 3 (transposed) packs like a data gradient (2); bits 4 (fp16 parts) / 5 (fp8) pass through"""
         return (2 if (mode & 15) == 3 else (mode & 15)) | (mode & 48)
 
+    @staticmethod
+    def _blocks(j) -> int:
+        """Workgroups for one job: a power of two from 1 (a few hundred weights) to 64 (a 288 x 288 x 9 layer), ~8 K packed bytes each."""
+        b, want = 1, max(1, j["packed"].numel() // 8192)
+        while b < 64 and b < want:
+            b *= 2
+        return b
+
+    def ensure_table(self, device):
+        """As the base class, with the jobs sorted by size class: ``_batch`` packs each class with a grid that fits it (one launch
+        of 64 workgroups per job spent 0.3 ms per step dispatching ~42,000 idle workgroups)."""
+        stale = self.table is None or self.table.device != device or any(j["wref"]() is None for j in self.order)
+        if stale:
+            self._prune()
+            self.jobs = {k: v for k, v in sorted(self.jobs.items(), key=lambda kv: -self._blocks(kv[1]))}
+            self.table = None
+        super().ensure_table(device)
+        if stale:
+            self.classes = []                       # (first job, count, workgroups per job, any fp8 image)
+            for i, j in enumerate(self.order):
+                b, f8 = self._blocks(j), 1 if (j["mode"] & 32) else 0
+                if self.classes and self.classes[-1][2] == b:
+                    first, cnt, _, f = self.classes[-1]
+                    self.classes[-1] = (first, cnt + 1, b, f | f8)
+                else:
+                    self.classes.append((i, 1, b, f8))
+
     def _batch(self):
-        lib().call("san_conv_bf16x3_pack_batch", _p(self.table), len(self.order), _stream())
+        base = self.table.data_ptr()
+        for first, cnt, blocks, f8 in self.classes:
+            lib().call("san_conv_bf16x3_pack_batch_grid", base + first * 64, cnt, blocks, f8, _stream())
 
     def _pack_one(self, job, w):
         cout, cin, ks = job["dims"]
