@@ -92,7 +92,7 @@ def native_rccl(dist, device, timeout_s: float = 120.0):
     if NATIVE["tried"]:
         return NATIVE["handle"]
     from . import _lib
-    if _lib.REC is not None or torch.cuda.is_current_stream_capturing():
+    if _lib.REC is not None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
         return None                     # (never built inside a recording / capture: the eager warm-up steps come first)
     NATIVE["tried"] = True
     if os.environ.get("SAN_NATIVE_RCCL", "1") == "0":

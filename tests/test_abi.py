@@ -132,3 +132,34 @@ def test_library_has_no_packed_fp32_instruction(built, tmp_path):
     pk = [line.strip() for t in texts for line in t.splitlines() if re.search(r"\bv_pk_(mul|add|fma|mov)_(f32|b32)\b", line)]
     assert not pk, f"{len(pk)} packed-fp32 instructions in libsan_hip.so, e.g. {pk[:3]}"
     assert sum(t.count("v_mfma_") for t in texts) > 10000        # (the disassembly is the real one)
+
+
+def test_rccl_binding_loads_the_process_library_and_reports_errors(built):
+    """csrc/san_rccl.cpp binds RCCL at run time by path (no link dependency): the library torch ships resolves all six entry points
+    and reports its version; a bogus path is an error with a message, not a crash; a communicator handle that does not exist is
+    refused before any RCCL call (no GPU needed for any of this)."""
+    import glob
+    import torch
+    lib = built.lib()
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))
+    if not cands:
+        pytest.skip("torch ships no librccl here")
+    with pytest.raises(RuntimeError, match="cannot open"):
+        lib.call("san_rccl_load", b"/nonexistent/librccl.so", None)
+    ver = ctypes.c_int(0)
+    lib.call("san_rccl_load", cands[0].encode(), ctypes.byref(ver))
+    assert ver.value >= 20000, ver.value                     # NCCL-style version code (2.26.6 -> 22606)
+    with pytest.raises(RuntimeError, match="no such communicator"):
+        lib.call("san_rccl_allreduce_sum_f32", 12345, ctypes.c_void_p(64), 4, None)
+
+
+def test_native_rccl_is_not_attempted_without_an_nccl_group(built, monkeypatch):
+    """dist.native_rccl(): only on the nccl backend with a CUDA device; anything else answers None without touching RCCL."""
+    from spatialalignmentnetwork_amd import dist as sdist
+    monkeypatch.setitem(sdist.NATIVE, "tried", False)
+    monkeypatch.setitem(sdist.NATIVE, "handle", None)
+    assert sdist.native_rccl(None, "cpu") is None
+    assert sdist.NATIVE["tried"] is True and sdist.NATIVE["handle"] is None
+    monkeypatch.setitem(sdist.NATIVE, "tried", False)
+    monkeypatch.setenv("SAN_NATIVE_RCCL", "0")
+    assert sdist.native_rccl(object(), "cuda:0") is None and sdist.NATIVE["why"] == "SAN_NATIVE_RCCL=0"
