@@ -410,3 +410,35 @@ def test_one_stage_gemm_plain_bf16_form_matches_the_tiled_kernel(S):
     assert ((res[True][2].double() - wantd).abs().max() / wantd.abs().max()).item() < 2e-2
     mu, var, tot = _merge_stats(res[True][1])
     assert float((tot - 4 * h * w).abs().max()) == 0.0
+
+
+def test_round5_kernels_repeat_bit_identically(S):
+    """100 launches each of the direct kernel (4 -> 18, 3x3, statistics) and of the GEMM form (transposed convolution 72 -> 36 with
+    statistics, its data gradient with an amax scale) give identical bits every time (no atomics, fixed reduction orders)."""
+    gen = torch.Generator().manual_seed(15)
+    n = 8
+    x4 = g(torch.randn(n, 4, 160, 160, generator=gen))
+    w4 = g(torch.randn(18, 4, 3, 3, generator=gen) * 0.1)
+    y4 = torch.empty(n, 18, 160, 160, device=DEV)
+    x = g(torch.randn(n, 72, 80, 80, generator=gen))
+    sc, sh = g(torch.rand(n, 72, generator=gen) + 0.5), g(torch.randn(n, 72, generator=gen) * 0.3)
+    wt = g(torch.randn(72, 36, 2, 2, generator=gen) * 0.1)
+    y = torch.empty(n, 36, 160, 160, device=DEV)
+    dyp = g(torch.randn(n, 144, 80, 80, generator=gen) * 1e-4)
+    rec = S.ops.AMAX.next(DEV)
+    rec.zero_()
+    rec.view(torch.float32)[0] = dyp.abs().max()
+    da = S.ops.Act(dyp, 0, 144)
+    da.amax = rec
+    dx = torch.empty(n, 72, 80, 80, device=DEV)
+    wv = wt.reshape(72, 144, 1, 1)
+    first = None
+    for it in range(100):
+        p4 = S.ops.conv2d(S.ops.full(x4), w4, None, S.ops.full(y4), stats=True, tag="rep4")
+        pt = S.ops.tconv2x2(S.ops.Act(x, 0, 72, sc, sh, 0.2), wt, S.ops.full(y), stats=True, tag="rept")
+        S.ops.conv2d(da, wv, None, S.ops.full(dx), grad_input=True)
+        cur = [t.clone() for t in (y4, p4, y, pt, dx)]
+        if first is None:
+            first = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, cur)), it
