@@ -214,6 +214,43 @@ def tape_call_words(fn, args, flags: int = 0):
     return words
 
 
+# Events of a recorded step that only order this GPU's own streams (weight-gradient hand-offs, wait_stream): a replay tape gives them
+# RAW HIP events created without the system-scope fence (hipEventDisableSystemFence): the record then costs the stream ~1.2 us instead
+# of ~3.2 us (scratch/r5_event_flags.py; agent scope is all a same-device dependency needs).  ``light(ev)`` marks a torch event as such
+# while a step is recorded; timing events and anything the host reads stay torch's.
+LIGHT = None        # set of id(torch event) while recording
+
+
+def light(ev):
+    if REC is not None and LIGHT is not None:
+        LIGHT.add(id(ev))
+    return ev
+
+
+class RawEvents:
+    """hipEvent_t handles with hipEventDisableTiming | hipEventDisableSystemFence, owned by a recorded step's tapes."""
+    FLAGS = 0x2 | 0x20000000
+
+    def __init__(self):
+        self._hip = ctypes.CDLL("libamdhip64.so")
+        self.handles = []
+
+    def new(self) -> int:
+        e = ctypes.c_void_p()
+        rc = self._hip.hipEventCreateWithFlags(ctypes.byref(e), ctypes.c_uint(self.FLAGS))
+        if rc != 0 or not e.value:
+            raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
+        self.handles.append(e.value)
+        return e.value
+
+    def __del__(self):
+        try:
+            for h in self.handles:
+                self._hip.hipEventDestroy(ctypes.c_void_p(h))
+        except Exception:
+            pass
+
+
 class Tape:
     """A finished tape: ``run(skip_packs)`` walks it; a failing entry raises with the recorded call's name."""
 

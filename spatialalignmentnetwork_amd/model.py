@@ -592,19 +592,21 @@ class CSModel(BaseModel):
                     stray.append(f"{name} @ {site}")
                 return out
 
-        _lib.REC, _lib.KEEP = [], keep
+        _lib.REC, _lib.KEEP, _lib.LIGHT = [], keep, set()
         ops.TIMER = timer
         try:
             with _Watch():
                 run()
         finally:
-            calls, _lib.REC, _lib.KEEP = _lib.REC, None, None
+            calls, light, _lib.REC, _lib.KEEP, _lib.LIGHT = _lib.REC, _lib.LIGHT, None, None, None
             ops.TIMER = None
         torch.cuda.synchronize()
         if stray:
             raise RuntimeError(f"{what}: torch operations outside _lib.rec / _lib.untracked in the step (a host "
                                "synchronisation such as .item() counts): " + ", ".join(sorted(set(stray))))
-        return RecordedStep(calls, keep, training=what == "record_update")
+        step = RecordedStep(calls, keep, training=what == "record_update")
+        step.light = light                      # ids of the events that only order this GPU's streams (raw, fence-free in the tapes)
+        return step
 
     def _state_tensors(self):
         ts = []
@@ -745,6 +747,8 @@ class RecordedStep:
         self._packed_epoch = None
         self._ring, self._k = [], 0
         self._segs, self._own_events = None, []
+        self.light = set()
+        self._raw = None
 
     def _throttle(self) -> None:
         if not self._ring:
@@ -765,6 +769,17 @@ class RecordedStep:
         does per call."""
         segs, words, names = [], [], {}
         own = []                                # events made for wait_stream: alive as long as the step
+        # raw events without the system-scope fence for the step's own stream hand-offs (SAN_LIGHT_EVENTS=0: torch's events everywhere)
+        use_raw = os.environ.get("SAN_LIGHT_EVENTS", "1") != "0"
+        raw, raw_of = (_lib.RawEvents() if use_raw else None), {}
+
+        def handle(ev):
+            if use_raw and id(ev) in self.light:
+                h = raw_of.get(id(ev))
+                if h is None:
+                    h = raw_of[id(ev)] = raw.new()
+                return h
+            return ev.cuda_event
 
         def flush():
             if words:
@@ -774,11 +789,11 @@ class RecordedStep:
 
         def ev_record(ev, stream):
             names[len(words)] = "hipEventRecord"
-            words.extend((_lib.TAPE_EVENT_RECORD | 2 << 24, ev.cuda_event, stream.cuda_stream))
+            words.extend((_lib.TAPE_EVENT_RECORD | 2 << 24, ev if isinstance(ev, int) else handle(ev), stream.cuda_stream))
 
         def st_wait(stream, ev):
             names[len(words)] = "hipStreamWaitEvent"
-            words.extend((_lib.TAPE_STREAM_WAIT | 2 << 24, stream.cuda_stream, ev.cuda_event))
+            words.extend((_lib.TAPE_STREAM_WAIT | 2 << 24, stream.cuda_stream, ev if isinstance(ev, int) else handle(ev)))
 
         for fn, args, kind in self.calls:
             enc = None
@@ -797,9 +812,12 @@ class RecordedStep:
                     st_wait(owner, args[0])
                     continue
                 if isinstance(owner, torch.cuda.Stream) and name == "wait_stream" and len(args) == 1 and isinstance(args[0], torch.cuda.Stream):
-                    ev = torch.cuda.Event()
-                    ev.record(args[0])          # (creates the handle; harmless: nothing waits for this one)
-                    own.append(ev)
+                    if use_raw:
+                        ev = raw.new()
+                    else:
+                        ev = torch.cuda.Event()
+                        ev.record(args[0])      # (creates the handle; harmless: nothing waits for this one)
+                        own.append(ev)
                     ev_record(ev, args[0])
                     st_wait(owner, ev)
                     continue
@@ -813,11 +831,12 @@ class RecordedStep:
                 words.extend(enc)
         flush()
         self._own_events = own
+        self._raw = raw                         # (the tapes hold these handles: alive as long as the step)
         return segs
 
     def invalidate(self) -> None:
         """Forget the tapes: the next replay rebuilds them from ``calls`` (tests edit a recorded call)."""
-        self._segs, self._own_events = None, []
+        self._segs, self._own_events, self._raw = None, [], None
 
     def replay(self) -> None:
         skip_packs = (not self.training) and self._packed_epoch == ops.WEIGHT_EPOCH[0]

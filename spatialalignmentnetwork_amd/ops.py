@@ -1489,7 +1489,7 @@ def _flush_pending() -> None:
     if torch.cuda.is_current_stream_capturing():
         side.wait_stream(main)                  # (capture: fresh events, the graph keeps them as edges)
     else:
-        e0 = torch.cuda.Event() if _lib.REC is not None else _EVENTS.next()      # (a recorded step owns its events)
+        e0 = _lib.light(torch.cuda.Event()) if _lib.REC is not None else _EVENTS.next()      # (a recorded step owns its events)
         _lib.rec(e0.record, main)
         _lib.rec(side.wait_event, e0)
     _STREAM_OVERRIDE[0] = side                  # (launches take the side stream's handle; torch's current stream stays put)
@@ -1498,7 +1498,7 @@ def _flush_pending() -> None:
             fn()
     finally:
         _STREAM_OVERRIDE[0] = None
-    ev = torch.cuda.Event() if (torch.cuda.is_current_stream_capturing() or _lib.REC is not None) else _BUSY_EVENTS.next()
+    ev = _lib.light(torch.cuda.Event()) if (torch.cuda.is_current_stream_capturing() or _lib.REC is not None) else _BUSY_EVENTS.next()
     _lib.rec(ev.record, side)
     _WG["seq"] += 1
     ent = (_WG["seq"], ev)
