@@ -731,6 +731,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)
         print(json.dumps(out), file=line_out, flush=True)      # (flushed before the process group is torn down)
     if dist is not None:
+        sdist.shutdown()                        # the package's own RCCL communicator first, then torch's group
         dist.destroy_process_group()
 
 

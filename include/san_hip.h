@@ -645,6 +645,12 @@ int san_rccl_unique_id(void* id128);
 int san_rccl_comm_init(const void* id128, int world, int rank, int* handle);
 int san_rccl_allreduce_sum_f32(int handle, float* buf, size_t count, void* stream);
 int san_rccl_comm_destroy(int handle);
+/* The same sum as two collectives (round 6, SAN_GRAD_EXCHANGE=rs_ag): rank r receives the sum of every rank's chunk r of `send`
+ * (world chunks of recv_count floats) in recv -- ncclReduceScatter -- and san_rccl_allgather_f32 hands every rank's send_count
+ * floats to everybody (recv = world * send_count floats, rank order).  On a fully connected xGMI node both phases use all seven
+ * links at once; in-place forms: recv == send + rank * recv_count / send == recv + rank * send_count. */
+int san_rccl_reduce_scatter_sum_f32(int handle, const float* send, float* recv, size_t recv_count, void* stream);
+int san_rccl_allgather_f32(int handle, const float* send, float* recv, size_t send_count, void* stream);
 
 /* ------------------------------------------------------------- recorded steps */
 
@@ -658,6 +664,15 @@ int san_rccl_comm_destroy(int handle);
  * head word in *failed_word (host, may be NULL).  Entries are not validated beyond their length: a tape is built by
  * spatialalignmentnetwork_amd/model.py from calls that already ran once. */
 int san_replay_run(const void* tape, size_t n_words, int skip_packs, long long* failed_word);
+
+/* Events for the stream hand-offs of a recorded step (round 6; csrc/san_core.cpp).  san_event_create makes a hipEvent_t on
+ * `device` (the calling thread's current device is restored) without timing; light != 0 also drops the system-scope fence
+ * (hipEventDisableSystemFence: ~1.2 instead of ~3.2 us per record on the recording stream) -- for dependencies between streams
+ * of ONE GPU only; anything a peer GPU or the host observes (the gradient exchange's communication stream) takes light = 0.
+ * *event (host) receives the handle; san_event_destroy releases it.  These replace torch.cuda.Event objects inside replay tapes
+ * (train.py:212-217 has no counterpart: the reference's step is eager Python). */
+int san_event_create(int device, int light, void** event);
+int san_event_destroy(void* event);
 
 #ifdef __cplusplus
 }

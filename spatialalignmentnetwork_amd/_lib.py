@@ -228,25 +228,25 @@ def light(ev):
 
 
 class RawEvents:
-    """hipEvent_t handles with hipEventDisableTiming | hipEventDisableSystemFence, owned by a recorded step's tapes."""
-    FLAGS = 0x2 | 0x20000000
+    """hipEvent_t handles without timing, owned by a recorded step's tapes, made by libsan_hip.so itself (san_event_create:
+    the runtime the library links, on the device of the stream that will record them -- round 6).  ``new(device,
+    light)``: light drops the system-scope fence (same-GPU hand-offs only)."""
 
     def __init__(self):
-        self._hip = ctypes.CDLL("libamdhip64.so")
         self.handles = []
 
-    def new(self) -> int:
+    def new(self, device: int, light: bool = True) -> int:
         e = ctypes.c_void_p()
-        rc = self._hip.hipEventCreateWithFlags(ctypes.byref(e), ctypes.c_uint(self.FLAGS))
-        if rc != 0 or not e.value:
-            raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
+        lib().call("san_event_create", int(device), 1 if light else 0, ctypes.byref(e))
+        if not e.value:
+            raise RuntimeError("san_event_create returned no handle")
         self.handles.append(e.value)
         return e.value
 
     def __del__(self):
         try:
             for h in self.handles:
-                self._hip.hipEventDestroy(ctypes.c_void_p(h))
+                lib()._san_event_destroy(ctypes.c_void_p(h))
         except Exception:
             pass
 

@@ -1189,15 +1189,16 @@ template <int KS, int X>
 static int wgrad_vec_launch(dim3 grid, hipStream_t s, const WgradArgs& a) {
     constexpr int ACS = KS == 3 ? 456 : 264;
     constexpr size_t bytes = (2 * (size_t)(kCIB * ACS + 8 * X * kDCS) + 4 * kVT) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static SanPerDevice configured;
+    const int dev__ = san_current_device();
+    if (!configured.has(dev__)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_vec_kernel<KS, X>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
         {
             san_set_error("cannot reserve %d bytes of LDS for the weight-gradient kernel", (int)bytes);
             return SAN_E_UNSUPPORTED;
         }
-        configured = true;
+        configured.mark(dev__);
     }
     hipLaunchKernelGGL((conv_wgrad_vec_kernel<KS, X>), grid, dim3(kVT), bytes, s, a);
     return SAN_OK;

@@ -52,6 +52,21 @@ int san_gemm1x1_f16_run(SanGemm1x1Args a, void* stream);
 
 static inline int san_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: a launcher keeps one of these per kernel and asks
+// before every launch (round 6, ADVICE r5: a process-wide `static bool` left the second GPU of one process unconfigured).
+// True once the calling thread's current device has been configured through `mark`.
+struct SanPerDevice {
+    unsigned long long done[2] = {0ull, 0ull};      // devices 0 .. 127
+    bool has(int dev) const { return dev >= 0 && dev < 128 && ((done[dev >> 6] >> (dev & 63)) & 1ull); }
+    void mark(int dev) {
+        if (dev >= 0 && dev < 128) done[dev >> 6] |= 1ull << (dev & 63);
+    }
+};
+static inline int san_current_device() {
+    int d = -1;
+    return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+
 // lazy normalisation applied by every consumer: lrelu(scale*x + shift, slope)
 __device__ __forceinline__ float san_act(float x, float sc, float sh, float slope) {
     float v = fmaf(x, sc, sh);

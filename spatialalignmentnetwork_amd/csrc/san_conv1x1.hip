@@ -373,15 +373,16 @@ int g_gemm1x1 = (getenv("SAN_CONV1X1_GEMM") && atoi(getenv("SAN_CONV1X1_GEMM")) 
 template <int NGW, bool BF1>
 int launch_ng(const SanGemm1x1Args& a, size_t lds, hipStream_t s) {
     const dim3 grid(a.ptiles * a.ngrp * a.N);
-    static bool configured[2] = {false, false};
+    static SanPerDevice configured[2];
     const int k = a.shuffle ? 1 : 0;
-    if (!configured[k]) {
+    const int dev__ = san_current_device();
+    if (!configured[k].has(dev__)) {
         const void* fn = a.shuffle ? reinterpret_cast<const void*>(&gemm1x1_f16_kernel<NGW, true, BF1>) : reinterpret_cast<const void*>(&gemm1x1_f16_kernel<NGW, false, BF1>);
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
             san_set_error("cannot reserve 96 KB of LDS for the 1x1 GEMM");
             return SAN_E_UNSUPPORTED;
         }
-        configured[k] = true;
+        configured[k].mark(dev__);
     }
     if (a.shuffle) hipLaunchKernelGGL((gemm1x1_f16_kernel<NGW, true, BF1>), grid, dim3(kT), lds, s, a);
     else hipLaunchKernelGGL((gemm1x1_f16_kernel<NGW, false, BF1>), grid, dim3(kT), lds, s, a);

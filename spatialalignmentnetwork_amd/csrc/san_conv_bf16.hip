@@ -1154,14 +1154,15 @@ template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16 = fals
 int launch_bfns(const BArgs& a, hipStream_t s) {
     // (only the parts in use are allocated: 33 KB for the two-fp16-part form, 17 KB for one part -- LDS never limits residency)
     constexpr size_t lds = NP * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
+    static SanPerDevice configured;
+    const int dev__ = san_current_device();
+    if (!configured.has(dev__)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
         }
-        configured = true;
+        configured.mark(dev__);
     }
     const int total = a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
     hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8>), dim3(total), dim3(kT), lds, s, a);

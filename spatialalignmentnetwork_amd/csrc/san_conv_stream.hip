@@ -506,8 +506,10 @@ size_t stream_lds_bytes(int cin, int cout, int nprt = 2) {
 template <int MBF, int REM, int OCC, int NPRT = 2>
 int launch_stream(const SArgs& a, hipStream_t s) {
     const size_t lds = stream_lds_bytes(a.cin, a.cout, NPRT);
-    static size_t configured = 0;
-    if (lds > configured) {
+    static size_t configured_on[128] = {};      // per device: the attribute is a per-device setting (round 6)
+    const int dev__ = san_current_device();
+    size_t& configured = configured_on[dev__ >= 0 && dev__ < 128 ? dev__ : 0];
+    if (lds > configured || dev__ < 0 || dev__ >= 128) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel<MBF, REM, OCC, NPRT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the stream convolution", (int)lds);

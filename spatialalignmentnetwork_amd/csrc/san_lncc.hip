@@ -186,11 +186,25 @@ grid_sample_bwd_img_kernel(const float* __restrict__ grid, const float* __restri
 // result does not depend on the order the workgroups arrive in; a last pass converts back.  work: n*c*h*w + 1 words (the last
 // one collects the bits of max |g|).
 __global__ void __launch_bounds__(kThreads) gsb_amax_kernel(const float* __restrict__ g, size_t count, unsigned long long* __restrict__ amax) {
+    // a non-finite gradient (Inf or NaN: fmaxf would drop the NaN) is recorded as the NaN bit pattern, which orders above every
+    // finite value and above Inf in the integer maximum: the convert pass then writes NaN instead of a silently zero gradient
+    // (round 6, ADVICE r5 -- F.grid_sample's autograd propagates them; a GradScaler-style overflow check must see them)
     float mx = 0.f;
-    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) mx = fmaxf(mx, fabsf(g[i]));
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads) {
+        const float a = fabsf(g[i]);
+        bad |= !(a <= 3.402823466e+38f);
+        mx = fmaxf(mx, a);
+    }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax, (unsigned long long)__builtin_bit_cast(unsigned, mx));
+    for (int o = 32; o > 0; o >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        bad |= __shfl_xor(bad, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (bad) atomicMax(amax, 0x7FC00000ull);
+        else if (mx > 0.f) atomicMax(amax, (unsigned long long)__builtin_bit_cast(unsigned, mx));
+    }
 }
 
 __device__ __forceinline__ float gsb_scale(const unsigned long long* amax) {
@@ -233,8 +247,9 @@ __global__ void __launch_bounds__(kThreads) gsb_convert_kernel(const unsigned lo
                                                                float* __restrict__ gimg, size_t count) {
     const float scale = gsb_scale(amax);
     const double inv = scale > 0.f ? 1.0 / (double)scale : 0.0;
+    const bool nonfinite = (unsigned)*amax > 0x7F7FFFFFu;      // some |g| was Inf or NaN: the whole gradient is NaN, loudly
     for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < count; i += (size_t)gridDim.x * kThreads)
-        gimg[i] = (float)((double)(long long)work[i] * inv);
+        gimg[i] = nonfinite ? __builtin_nanf("") : (float)((double)(long long)work[i] * inv);
 }
 
 }  // namespace

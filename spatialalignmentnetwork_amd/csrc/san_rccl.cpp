@@ -18,6 +18,8 @@ struct UniqueId {
 typedef int (*get_unique_id_t)(UniqueId*);
 typedef int (*comm_init_rank_t)(void**, int, UniqueId, int);
 typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*reduce_scatter_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*all_gather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*comm_destroy_t)(void*);
 typedef const char* (*get_error_string_t)(int);
 typedef int (*get_version_t)(int*);
@@ -27,6 +29,8 @@ struct Rccl {
     get_unique_id_t get_unique_id = nullptr;
     comm_init_rank_t comm_init_rank = nullptr;
     all_reduce_t all_reduce = nullptr;
+    reduce_scatter_t reduce_scatter = nullptr;
+    all_gather_t all_gather = nullptr;
     comm_destroy_t comm_destroy = nullptr;
     get_error_string_t get_error_string = nullptr;
     get_version_t get_version = nullptr;
@@ -54,6 +58,8 @@ int san_rccl_load(const char* path, int* version) {
         g.get_unique_id = (get_unique_id_t)dlsym(dl, "ncclGetUniqueId");
         g.comm_init_rank = (comm_init_rank_t)dlsym(dl, "ncclCommInitRank");
         g.all_reduce = (all_reduce_t)dlsym(dl, "ncclAllReduce");
+        g.reduce_scatter = (reduce_scatter_t)dlsym(dl, "ncclReduceScatter");
+        g.all_gather = (all_gather_t)dlsym(dl, "ncclAllGather");
         g.comm_destroy = (comm_destroy_t)dlsym(dl, "ncclCommDestroy");
         g.get_error_string = (get_error_string_t)dlsym(dl, "ncclGetErrorString");
         g.get_version = (get_version_t)dlsym(dl, "ncclGetVersion");
@@ -116,6 +122,41 @@ int san_rccl_allreduce_sum_f32(int handle, float* buf, size_t count, void* strea
     const int rc = g.all_reduce(buf, buf, count, /* ncclFloat32 */ 7, /* ncclSum */ 0, comm, (hipStream_t)stream);
     if (rc != 0) {
         san_set_error("ncclAllReduce(%zu floats): %s", count, err(rc));
+        return SAN_E_UNSUPPORTED;
+    }
+    return SAN_OK;
+}
+
+static void* comm_of(int handle) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    return (handle >= 0 && handle < (int)g_comms.size()) ? g_comms[handle] : nullptr;
+}
+
+// recv[0 .. recv_count) = sum over ranks of their send[rank * recv_count ..): the first half of the two-phase exchange
+int san_rccl_reduce_scatter_sum_f32(int handle, const float* send, float* recv, size_t recv_count, void* stream) {
+    SAN_CHECK_ARG(send && recv, "null pointer");
+    void* comm = comm_of(handle);
+    SAN_CHECK_ARG(comm, "no such communicator");
+    SAN_CHECK_ARG(g.reduce_scatter, "the bound RCCL has no ncclReduceScatter");
+    if (recv_count == 0) return SAN_OK;
+    const int rc = g.reduce_scatter(send, recv, recv_count, /* ncclFloat32 */ 7, /* ncclSum */ 0, comm, (hipStream_t)stream);
+    if (rc != 0) {
+        san_set_error("ncclReduceScatter(%zu floats per rank): %s", recv_count, err(rc));
+        return SAN_E_UNSUPPORTED;
+    }
+    return SAN_OK;
+}
+
+// recv[r * send_count ..) = rank r's send[0 .. send_count): the second half
+int san_rccl_allgather_f32(int handle, const float* send, float* recv, size_t send_count, void* stream) {
+    SAN_CHECK_ARG(send && recv, "null pointer");
+    void* comm = comm_of(handle);
+    SAN_CHECK_ARG(comm, "no such communicator");
+    SAN_CHECK_ARG(g.all_gather, "the bound RCCL has no ncclAllGather");
+    if (send_count == 0) return SAN_OK;
+    const int rc = g.all_gather(send, recv, send_count, /* ncclFloat32 */ 7, comm, (hipStream_t)stream);
+    if (rc != 0) {
+        san_set_error("ncclAllGather(%zu floats per rank): %s", send_count, err(rc));
         return SAN_E_UNSUPPORTED;
     }
     return SAN_OK;

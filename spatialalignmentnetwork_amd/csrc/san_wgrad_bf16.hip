@@ -834,14 +834,15 @@ WBPlan wb_plan(int n, int h, int w, int cin, int cout, int max_nb = 4) {
 template <int NB>
 int launch_wb(const WBArgs& a, int grid, hipStream_t s) {
     constexpr size_t lds = (size_t)(kWaves - 1) * 9 * NB * 64 * sizeof(f4);
-    static bool configured = false;
-    if (!configured) {
+    static SanPerDevice configured;
+    const int dev__ = san_current_device();
+    if (!configured.has(dev__)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<NB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 weight gradient", (int)lds);
             return SAN_E_UNSUPPORTED;
         }
-        configured = true;
+        configured.mark(dev__);
     }
     hipLaunchKernelGGL((wgrad_bf16x3_kernel<NB>), dim3(grid), dim3(kWT), lds, s, a);
     return SAN_OK;
@@ -852,14 +853,15 @@ int g_wgrad_np = 3;            // operand parts (san_set_conv_precision)
 template <int NB, int NP, bool F16 = false>
 int launch_wdn(const WDArgs& a, int grid, hipStream_t s) {
     constexpr size_t lds = (size_t)(kWaves - 1) * 9 * NB * 64 * sizeof(f4);
-    static bool configured = false;
-    if (!configured) {
+    static SanPerDevice configured;
+    const int dev__ = san_current_device();
+    if (!configured.has(dev__)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_direct_kernel<NB, NP, F16>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 weight gradient", (int)lds);
             return SAN_E_UNSUPPORTED;
         }
-        configured = true;
+        configured.mark(dev__);
     }
     hipLaunchKernelGGL((wgrad_bf16x3_direct_kernel<NB, NP, F16>), dim3(grid), dim3(kWT), lds, s, a);
     return SAN_OK;

@@ -50,9 +50,6 @@ def init(backend: str, device=None, allow_fallback: bool = False):
             dist.all_reduce(t)                      # fail here, not inside the timed region
             torch.cuda.synchronize()
             BACKEND = "nccl"
-            if device is not None:
-                native_rccl(dist, device)           # the step's own communicator (collective: every rank is here)
-            return dist
         except Exception as e:                     # pragma: no cover (needs a multi-GPU box)
             if not allow_fallback:
                 raise RuntimeError(f"RCCL could not initialise ({type(e).__name__}: {e}); refusing to fall back to gloo "
@@ -63,9 +60,33 @@ def init(backend: str, device=None, allow_fallback: bool = False):
             except Exception:
                 pass
             backend = "gloo"
+        else:
+            if device is not None:
+                # the step's own communicator (collective: every rank is here).  Its failure only switches the native path off
+                # -- nccl itself came up, so nothing here may send the job to gloo
+                try:
+                    native_rccl(dist, device)
+                except Exception as e:
+                    NATIVE.update(handle=None, tried=True, key=_group_key(dist), why=f"{type(e).__name__}: {e}")
+            return dist
     dist.init_process_group(backend)
     BACKEND = backend
     return dist
+
+
+def shutdown() -> None:
+    """Release the package's RCCL communicator and forget the backend (call before ``destroy_process_group``; a later ``init``
+    builds a new communicator for the new group)."""
+    global BACKEND
+    h = NATIVE.get("handle")
+    if h is not None:
+        try:
+            from . import _lib
+            _lib.lib().call("san_rccl_comm_destroy", int(h))
+        except Exception:
+            pass
+    NATIVE.update(handle=None, tried=False, key=None, why="not tried")
+    BACKEND = None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -74,7 +95,23 @@ def init(backend: str, device=None, allow_fallback: bool = False):
 # torch.distributed.all_reduce.  torch's process group stays in charge of everything else (and of the step itself whenever the
 # native communicator cannot be built: SAN_NATIVE_RCCL=0, a backend other than nccl, a failed or timed-out ncclCommInitRank on
 # ANY rank -- the ranks agree on the outcome through the process group before anybody uses it).
-NATIVE = {"handle": None, "tried": False, "why": "not tried", "version": None}
+NATIVE = {"handle": None, "tried": False, "why": "not tried", "version": None, "key": None}
+
+
+def _group_key(dist):
+    """What a cached communicator belongs to: the default process group OBJECT (a re-initialised group is a new one), its
+    world size and this rank, and the backend."""
+    try:
+        if dist is None or not dist.is_initialized():
+            return None
+    except Exception:                   # (not a torch.distributed module: nothing to key on)
+        return None
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        gid = id(c10d._get_default_group())
+    except Exception:
+        gid = 0
+    return (gid, dist.get_world_size(), dist.get_rank(), backend())
 
 
 def _loaded_rccl_path():
@@ -89,12 +126,18 @@ def _loaded_rccl_path():
 
 def native_rccl(dist, device, timeout_s: float = 120.0):
     """Handle of the package's own RCCL communicator over the ranks of ``dist`` (built on first use: a COLLECTIVE call), or None."""
-    if NATIVE["tried"]:
+    key = _group_key(dist)
+    if NATIVE["tried"] and NATIVE["key"] == key:
         return NATIVE["handle"]
     from . import _lib
     if _lib.REC is not None or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
         return None                     # (never built inside a recording / capture: the eager warm-up steps come first)
-    NATIVE["tried"] = True
+    if NATIVE["handle"] is not None:    # the process group changed under a live communicator: it belongs to the old ranks
+        try:
+            _lib.lib().call("san_rccl_comm_destroy", int(NATIVE["handle"]))
+        except Exception:
+            pass
+    NATIVE.update(handle=None, tried=True, key=key, why="not tried")
     if os.environ.get("SAN_NATIVE_RCCL", "1") == "0":
         NATIVE["why"] = "SAN_NATIVE_RCCL=0"
         return None

@@ -769,15 +769,46 @@ class RecordedStep:
         does per call."""
         segs, words, names = [], [], {}
         own = []                                # events made for wait_stream: alive as long as the step
-        # raw events without the system-scope fence for the step's own stream hand-offs (SAN_LIGHT_EVENTS=0: torch's events everywhere)
+        # raw events without the system-scope fence for the step's own stream hand-offs (SAN_LIGHT_EVENTS=0: torch's events everywhere).
+        # NOT for the gradient exchange (ADVICE r5): peers read and write this GPU's memory around the collective, so every
+        # hand-off that names a communication stream keeps a system-scope event.
         use_raw = os.environ.get("SAN_LIGHT_EVENTS", "1") != "0"
         raw, raw_of = (_lib.RawEvents() if use_raw else None), {}
+        from . import dist as _sdist
+        comm_streams = {st.cuda_stream for st in _sdist.GradExchange._streams.values()}
 
-        def handle(ev):
-            if use_raw and id(ev) in self.light:
+        def raw_event(stream, light=True):
+            """A raw handle on ``stream``'s device, or None when the library cannot make one (then torch's events serve)."""
+            nonlocal use_raw
+            if not use_raw:
+                return None
+            try:
+                return raw.new(stream.device.index if stream.device.index is not None else torch.cuda.current_device(), light)
+            except Exception as e:          # (a failing helper must not take the replay down: torch's events always work)
+                print(f"[san] raw events unavailable ({type(e).__name__}: {e}); using torch events", flush=True)
+                use_raw = False
+                return None
+
+        # (decided per EVENT, before any handle is made: an event that a communication stream records or waits for anywhere in
+        # the step is torch's own on both sides)
+        heavy = set()
+        for fn, args, kind in self.calls:
+            owner, name = getattr(fn, "__self__", None), getattr(fn, "__name__", "")
+            if kind == 0 and len(args) == 1:
+                if isinstance(owner, torch.cuda.Event) and name == "record" and isinstance(args[0], torch.cuda.Stream) \
+                        and args[0].cuda_stream in comm_streams:
+                    heavy.add(id(owner))
+                elif isinstance(owner, torch.cuda.Stream) and name == "wait_event" and owner.cuda_stream in comm_streams:
+                    heavy.add(id(args[0]))
+
+        def handle(ev, stream):
+            if use_raw and id(ev) in self.light and id(ev) not in heavy:
                 h = raw_of.get(id(ev))
                 if h is None:
-                    h = raw_of[id(ev)] = raw.new()
+                    h = raw_event(stream)
+                    if h is None:
+                        return ev.cuda_event
+                    raw_of[id(ev)] = h
                 return h
             return ev.cuda_event
 
@@ -789,11 +820,11 @@ class RecordedStep:
 
         def ev_record(ev, stream):
             names[len(words)] = "hipEventRecord"
-            words.extend((_lib.TAPE_EVENT_RECORD | 2 << 24, ev if isinstance(ev, int) else handle(ev), stream.cuda_stream))
+            words.extend((_lib.TAPE_EVENT_RECORD | 2 << 24, ev if isinstance(ev, int) else handle(ev, stream), stream.cuda_stream))
 
         def st_wait(stream, ev):
             names[len(words)] = "hipStreamWaitEvent"
-            words.extend((_lib.TAPE_STREAM_WAIT | 2 << 24, stream.cuda_stream, ev if isinstance(ev, int) else handle(ev)))
+            words.extend((_lib.TAPE_STREAM_WAIT | 2 << 24, stream.cuda_stream, ev if isinstance(ev, int) else handle(ev, stream)))
 
         for fn, args, kind in self.calls:
             enc = None
@@ -812,9 +843,10 @@ class RecordedStep:
                     st_wait(owner, args[0])
                     continue
                 if isinstance(owner, torch.cuda.Stream) and name == "wait_stream" and len(args) == 1 and isinstance(args[0], torch.cuda.Stream):
-                    if use_raw:
-                        ev = raw.new()
-                    else:
+                    # (an event of the recorded stream's device; with a communication stream on either side: system scope)
+                    peer = owner.cuda_stream in comm_streams or args[0].cuda_stream in comm_streams
+                    ev = raw_event(args[0], light=not peer)
+                    if ev is None:
                         ev = torch.cuda.Event()
                         ev.record(args[0])      # (creates the handle; harmless: nothing waits for this one)
                         own.append(ev)
