@@ -383,6 +383,26 @@ int san_act_bwd_up_amax(const float* g, int g_ctot, int g_coff, const float* g2,
 int san_act_bwd_coef_amax(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
                           const float* sc, const float* sh, float slope, const float* coef,
                           float* dy, int d_ctot, int d_coff, void* amax, int n, int c, int hw, void* stream);
+
+/* One-pass norm + activation backward on WORKGROUP CLUSTERS (round 6; csrc/san_bwd.hip act_bwd_cluster_kernel): K consecutive
+ * workgroups share one reduction domain, keep their chunk of the plane in registers, exchange their two partial sums through a
+ * small record in `sync` and write dy -- g and y are read once instead of twice, one launch instead of two (InstanceNorm; replaces
+ * san_plane_dot_stats + san_act_bwd*_amax where a plane does not fit one workgroup, i.e. the 320 x 320 levels of varnet.py:139-146's
+ * backward) or three (training BatchNorm, unet.py:125: san_plane_dot_stats + san_bn_bwd_finalize + san_act_bwd_coef_amax).
+ * sync: int32 scratch of san_*_sync_words(n, c, hw) words that the caller zeroes ONCE; the kernels leave it zero.  A words
+ * query of 0 means: shape not covered, use the multi-launch form.  Tensors 16-byte aligned, hw % 4 == 0.
+ * san_act_bwd_in: g2 (may be NULL) / g2_scale as san_act_bwd_up_amax; flags / w as san_act_bwd_ex_amax; amax may be NULL.
+ * san_bn_act_bwd: dgamma[c] / dbeta[c] are accumulated into.
+ * san_act_bwd_cluster_set_tuning(on, min_hw, v, bn_on): -1 / 0 / 0 / -1 leave a setting unchanged (process-wide; tests, A/B runs). */
+int san_act_bwd_in_sync_words(int n, int c, int hw);
+int san_act_bwd_in(const float* g, int g_ctot, int g_coff, const float* g2, int g2_ctot, int g2_coff, float g2_scale,
+                   const float* y, int y_ctot, int y_coff, const float* sc, const float* sh, float slope, float* dy, int d_ctot,
+                   int d_coff, void* amax, int n, int c, int hw, int w, int flags, void* sync, void* stream);
+int san_bn_act_bwd_sync_words(int n, int c, int hw);
+int san_bn_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc, const float* sh,
+                   float slope, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dy, int d_ctot,
+                   int d_coff, void* amax, int n, int c, int hw, void* sync, void* stream);
+int san_act_bwd_cluster_set_tuning(int on, int min_hw, int v, int bn_on);
 int san_conv_bf16x3_dgrad_amax(const float* dy, int dy_ctot, int dy_coff, int cin, const void* w_packed, float* dx, int dx_ctot,
                                int dx_coff, int cout, const void* amax, int n, int h, int w, int ks, void* ws, size_t ws_bytes,
                                void* stream);

@@ -727,6 +727,53 @@ __device__ __forceinline__ void dy_store(float* __restrict__ base, int i, bf4 o,
     *reinterpret_cast<bf2*>(qf) = f;
 }
 
+// Loads of one thread's V float4 of g and y (+ the optional half-resolution second source), ALL issued before anything waits for
+// one of them: with `if (i < n4)` around each load the compiler emitted load, s_waitcnt vmcnt(0), arithmetic V times over -- two
+// requests in flight per thread (round 6; the 160 x 160 plane kernel ran at half the rate the same bytes stream at).  Indices
+// past the plane are clamped to its last element (a valid address) and their values dropped afterwards.
+template <int V, int T>
+__device__ __forceinline__ void act_bwd_load(const bf4* __restrict__ gp, const bf4* __restrict__ yp, const float* __restrict__ q2,
+                                             const G2Src g2, int base, int n4, float s, float b, float slope, bf4 (&u)[V],
+                                             bf4 (&yh)[V], float& s1, float& s2) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i = min(base + (int)threadIdx.x + T * k, n4 - 1);
+        u[k] = gp[i];
+        yh[k] = yp[i];
+    }
+    if (q2) {                                       // (uniform: a kernel argument)
+        typedef float bf2 __attribute__((ext_vector_type(2)));
+        bf2 v2[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const int i = min(base + (int)threadIdx.x + T * k, n4 - 1);
+            const int row = (int)(((float)i + 0.5f) * g2.inv_w4);           // exact for i < 2^22
+            const int c4 = i - row * g2.w4;
+            v2[k] = *reinterpret_cast<const bf2*>(q2 + (size_t)(row >> 1) * (2 * g2.w4) + 2 * c4);
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            u[k][0] = fmaf(g2.scale, v2[k][0], u[k][0]);
+            u[k][1] = fmaf(g2.scale, v2[k][0], u[k][1]);
+            u[k][2] = fmaf(g2.scale, v2[k][1], u[k][2]);
+            u[k][3] = fmaf(g2.scale, v2[k][1], u[k][3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const bool in = base + (int)threadIdx.x + T * k < n4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float t = in ? fmaf(yh[k][e], s, b) : 0.f;
+            const float uu = in ? u[k][e] * (t >= 0.f ? 1.f : slope) : 0.f;
+            yh[k][e] = t;
+            u[k][e] = uu;
+            s1 += uu;
+            s2 = fmaf(uu, t, s2);
+        }
+    }
+}
+
 // InstanceNorm + LeakyReLU backward of a whole (sample, channel) plane in ONE pass: the plane's g and y (<= V float4 per
 // thread each, 512 threads) stay in registers between the two reductions and the write of dy, so g and y are read once
 // instead of twice and there is one launch instead of two.  Planes of up to 512 * 4 * V values (V = 13: 160 x 160).
@@ -749,26 +796,7 @@ __global__ void __launch_bounds__(512) SAN_NO_PK32 act_bwd_plane_kernel(const fl
     const int n4 = hw >> 2;
     bf4 u[V], yh[V];
     float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < V; ++k) {
-        const int i = threadIdx.x + 512 * k;
-        u[k] = bf4{0.f, 0.f, 0.f, 0.f};
-        yh[k] = bf4{0.f, 0.f, 0.f, 0.f};
-        if (i < n4) {
-            bf4 gv = gp[i];
-            const bf4 yv = yp[i];
-            if (q2) gv = g2_add(gv, q2, i, g2.w4, g2.inv_w4, g2.scale);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t = fmaf(yv[e], s, b);
-                const float uu = gv[e] * (t >= 0.f ? 1.f : slope);
-                yh[k][e] = t;
-                u[k][e] = uu;
-                s1 += uu;
-                s2 = fmaf(uu, t, s2);
-            }
-        }
-    }
+    act_bwd_load<V, 512>(gp, yp, q2, g2, 0, n4, s, b, slope, u, yh, s1, s2);
     s1 = san_wave_total(s1);
     s2 = san_wave_total(s2);
     if ((threadIdx.x & 63) == 0) {
@@ -798,6 +826,143 @@ __global__ void __launch_bounds__(512) SAN_NO_PK32 act_bwd_plane_kernel(const fl
         }
     }
     san_amax_record<8>(amax, blockIdx.y * gridDim.x + blockIdx.x, mx);
+}
+
+// ---- one-pass norm + activation backward of planes that do not fit one workgroup (round 6) ------------------------------------
+// The two-kernel form reads g and y twice (bwd_stats, then act_bwd) because the plane means must exist before the first dy can
+// be written: at 320 x 320 that is 5 plane passes and two launches per layer, 2.2 ms of a training step in bwd_stats alone.
+// Here a CLUSTER of K workgroups shares one reduction domain (InstanceNorm: the K chunks of one (sample, channel) plane;
+// BatchNorm: the n * K chunks of one channel): every workgroup keeps its chunk of u and yh in registers, publishes its two partial
+// sums, waits for the other members and then writes dy -- g and y are read once, one launch.
+//   record of a cluster (int32 words, zero between launches):  [2 * members] partial sums | arrived | departed
+//   publish:  agent-scope (write-through) stores of the two floats, s_waitcnt vmcnt(0), relaxed agent-scope add on `arrived`
+//   wait:     one lane polls `arrived` with agent-scope loads (+ s_sleep), then the members' sums are read with agent-scope loads
+//             and added in member order in double -- every member computes the same bits, run to run
+//   leave:    add on `departed`; the last one out zeroes the record (sums and counters) for the next launch
+// Waiting on other workgroups of the same launch needs them to be scheduled: cluster members are CONSECUTIVE workgroups of the
+// grid and the dispatcher hands workgroups out in order, so the members of the oldest unfinished cluster are all resident or
+// finished -- it always completes and frees its slots (no cycle among waiting clusters).  The poll is bounded all the same: a
+// member that gives up writes NaN means, loudly wrong instead of a hung GPU.
+constexpr int kClT = 256;                           // threads per cluster member
+constexpr int kClPollMax = 1 << 21;                 // ~ seconds
+__host__ __device__ __forceinline__ int cluster_rec_words(int members) { return ((2 * members + 2 + 31) / 32) * 32; }      // whole 128-byte lines
+
+template <int V, int BN>
+__global__ void __launch_bounds__(kClT) SAN_NO_PK32
+act_bwd_cluster_kernel(const float* __restrict__ g, int g_ctot, int g_coff, const float* __restrict__ y, int y_ctot, int y_coff,
+                       const float* __restrict__ sc, const float* __restrict__ sh, float slope, float* __restrict__ dy, int d_ctot,
+                       int d_coff, int hw, unsigned* amax, const G2Src g2, const DyDst dd, unsigned* __restrict__ sync,
+                       const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ dgamma,
+                       float* __restrict__ dbeta, double cnt) {
+    __shared__ float red[8];
+    __shared__ float pay[2 * 256];                  // the members' partial sums (members <= 256)
+    __shared__ double tot[2];
+    // InstanceNorm: grid (K, c, n), cluster = (ch, n); BatchNorm: grid (K, n, c), cluster = ch -- members consecutive either way
+    const int K = gridDim.x, chunk = blockIdx.x;
+    const int ch = BN ? blockIdx.z : blockIdx.y, n = BN ? blockIdx.y : blockIdx.z;
+    const int members = BN ? K * (int)gridDim.y : K;
+    const int me = BN ? n * K + chunk : chunk;
+    const int cluster = BN ? ch : n * (int)gridDim.y + ch;
+    const float* q2 = g2.p ? g2.p + ((size_t)(n * g2.ctot + g2.coff + ch)) * (hw >> 2) : nullptr;
+    const float s = sc ? sc[n * y_ctot + y_coff + ch] : 1.f;
+    const float b = sh ? sh[n * y_ctot + y_coff + ch] : 0.f;
+    const bf4* gp = reinterpret_cast<const bf4*>(g + ((size_t)(n * g_ctot + g_coff + ch)) * hw);
+    const bf4* yp = reinterpret_cast<const bf4*>(y + ((size_t)(n * y_ctot + y_coff + ch)) * hw);
+    float* dp = dy + (dd.shuf ? ((size_t)(n * d_ctot + d_coff + 4 * ch)) * (hw >> 2) : ((size_t)(n * d_ctot + d_coff + ch)) * hw);
+    const int n4 = hw >> 2;
+    const int base = chunk * (kClT * V);
+    bf4 u[V], yh[V];
+    float s1 = 0.f, s2 = 0.f;
+    act_bwd_load<V, kClT>(gp, yp, q2, g2, base, n4, s, b, slope, u, yh, s1, s2);
+    s1 = san_wave_total(s1);
+    s2 = san_wave_total(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s1;
+        red[4 + (threadIdx.x >> 6)] = s2;
+    }
+    __syncthreads();
+    unsigned* rec = sync + (size_t)cluster * cluster_rec_words(members);
+    if (threadIdx.x == 0) {
+        const float p1 = (red[0] + red[1]) + (red[2] + red[3]), p2 = (red[4] + red[5]) + (red[6] + red[7]);
+        __hip_atomic_store(rec + 2 * me, __builtin_bit_cast(unsigned, p1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(rec + 2 * me + 1, __builtin_bit_cast(unsigned, p2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the sums are in memory before the arrival can be seen
+        __hip_atomic_fetch_add(rec + 2 * members, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(rec + 2 * members, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)members) {
+            if (++spins > kClPollMax) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        red[0] = spins > kClPollMax ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const bool gave_up = red[0] != 0.f;
+    for (int j = threadIdx.x; j < 2 * members; j += kClT)
+        pay[j] = __builtin_bit_cast(float, __hip_atomic_load(rec + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    if (threadIdx.x < 64) {                         // member order, double: identical in every member
+        double t1 = 0.0, t2 = 0.0;
+        if (members <= 64) {
+            if (threadIdx.x == 0)
+                for (int j = 0; j < members; ++j) {
+                    t1 += (double)pay[2 * j];
+                    t2 += (double)pay[2 * j + 1];
+                }
+        } else {
+            for (int j = threadIdx.x; j < members; j += 64) {
+                t1 += (double)pay[2 * j];
+                t2 += (double)pay[2 * j + 1];
+            }
+            t1 = san_wave_sum_d(t1);
+            t2 = san_wave_sum_d(t2);
+        }
+        // everything this member needs from the record has been read: leave; the last one out zeroes the WHOLE record (sums and
+        // counters), so the buffer is all zeros between launches whatever cluster size the next user of it has
+        unsigned left = 0u;
+        if (threadIdx.x == 0) {
+            tot[0] = t1;
+            tot[1] = t2;
+            left = __hip_atomic_fetch_add(rec + 2 * members + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        left = (unsigned)__shfl((int)left, 0, 64);
+        if (left == (unsigned)members - 1u)
+            for (int j = threadIdx.x; j < 2 * members + 2; j += 64)
+                __hip_atomic_store(rec + j, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    float m1, m2, pp = 1.f, qq = 0.f;
+    if (BN) {
+        // BatchNorm (unet.py:125): dbeta = S1, dgamma = (S2 - beta S1) / gamma; dy = sc (u - dbeta/cnt - yn dgamma/cnt), yn = (yh - beta) / gamma
+        const double ga = (double)gamma[ch], be = (double)beta[ch];
+        const double dg = (tot[1] - be * tot[0]) / ga;
+        m1 = (float)(tot[0] / cnt);
+        m2 = (float)(dg / cnt);
+        pp = (float)(1.0 / ga);
+        qq = (float)(-be / ga);
+        if (me == 0 && threadIdx.x == 0) {
+            dgamma[ch] += (float)dg;
+            dbeta[ch] += (float)tot[0];
+        }
+    } else {
+        m1 = (float)(tot[0] / hw);
+        m2 = (float)(tot[1] / hw);
+    }
+    if (gave_up) m1 = m2 = __builtin_nanf("");
+    float mx = 0.f;
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+        const int i = base + threadIdx.x + kClT * k;
+        if (i < n4) {
+            bf4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = BN ? s * (u[k][e] - m1 - fmaf(pp, yh[k][e], qq) * m2) : s * (u[k][e] - m1 - yh[k][e] * m2);
+                mx = fmaxf(mx, fabsf(o[e]));
+            }
+            dy_store(dp, i, o, dd);
+        }
+    }
+    san_amax_record<kClT / 64>(amax, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, mx);
 }
 
 __global__ void __launch_bounds__(kThreads) SAN_NO_PK32
@@ -1328,6 +1493,21 @@ __global__ void __launch_bounds__(256) partials_add_kernel(const float* __restri
     if (threadIdx.x == 0) dst[0] += (float)((double)scale * red[0]);
 }
 
+template <int BN>
+static int cluster_launch(int v, dim3 grid, hipStream_t s, const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff,
+                          const float* sc, const float* sh, float slope, float* dy, int d_ctot, int d_coff, int hw, unsigned* amax,
+                          const G2Src q, const DyDst dd, unsigned* sync, const float* gamma, const float* beta, float* dgamma,
+                          float* dbeta, double cnt) {
+#define SAN_ABC(V) hipLaunchKernelGGL((act_bwd_cluster_kernel<V, BN>), grid, dim3(kClT), 0, s, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot, d_coff, hw, amax, q, dd, sync, gamma, beta, dgamma, dbeta, cnt)
+    if (v <= 1) SAN_ABC(1);
+    else if (v <= 2) SAN_ABC(2);
+    else if (v <= 4) SAN_ABC(4);
+    else SAN_ABC(7);
+#undef SAN_ABC
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1548,6 +1728,107 @@ int san_act_bwd_ex_amax(const float* g, int g_ctot, int g_coff, const float* y, 
     SAN_CHECK_ARG((flags & ~3) == 0, "flags: 1 = shuffled store, 2 = accumulate");
     return act_bwd_impl(g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, mode, part, dy, d_ctot, d_coff, n, c, hw,
                         static_cast<unsigned*>(amax), stream, nullptr, 0, 0, 0.f, w, flags);
+}
+
+// ---- one-pass forms on workgroup clusters (act_bwd_cluster_kernel) ----
+// SAN_ACT_BWD_CLUSTER=0: off (the two-kernel form everywhere); SAN_ACT_BWD_CLUSTER_MIN: smallest plane (pixels) that takes the cluster
+// form in InstanceNorm mode (default: everything the one-workgroup plane kernel cannot hold); SAN_ACT_BWD_CLUSTER_V: float4 per thread.
+static int g_cluster_on = (getenv("SAN_ACT_BWD_CLUSTER") && atoi(getenv("SAN_ACT_BWD_CLUSTER")) == 0) ? 0 : 1;
+// Measured (N = 8, rocprof-free event timing, scratch/r6_act_bwd_cluster.py): 18 x 320^2 two launches 47.4 us, clusters of 4 float4
+// per thread 36.2 (7: 37.6, 2: 69); 36 x 160^2 one-workgroup planes 19.3, clusters 17.0 (7: 19.8); 72 x 80^2 10.8 vs 11.3 -> planes
+// from 160 x 160 up take the cluster form.  BatchNorm clusters span the batch: 64 x 160^2 three launches 44.6 us, 32 members of 7
+// float4 35.7 (56 members of 4: 48.7); 64 x 80^2 27.0 -> 12.0; 32 x 320^2 with 120 members 138 vs 85 (a cluster that is a tenth of
+// what the chip holds leaves its early members idle): clusters of up to 64 members only.
+static int g_cluster_min = getenv("SAN_ACT_BWD_CLUSTER_MIN") ? atoi(getenv("SAN_ACT_BWD_CLUSTER_MIN")) : 160 * 160;
+static int g_cluster_v = getenv("SAN_ACT_BWD_CLUSTER_V") ? atoi(getenv("SAN_ACT_BWD_CLUSTER_V")) : 4;
+static int g_bn_members_max = getenv("SAN_BN_BWD_CLUSTER_MEMBERS") ? atoi(getenv("SAN_BN_BWD_CLUSTER_MEMBERS")) : 64;
+static int g_bn_cluster_on = (getenv("SAN_BN_BWD_CLUSTER") && atoi(getenv("SAN_BN_BWD_CLUSTER")) == 0) ? 0 : 1;
+
+static int cluster_v_for(int n4, int want = 0) {
+    // float4 per thread: the configured value, or the smallest instantiated one that covers a small plane with ONE member
+    const int one = san_cdiv(n4, kClT);
+    if (want <= 0) want = g_cluster_v;
+    int v = want <= 1 ? 1 : want <= 2 ? 2 : want <= 4 ? 4 : 7;
+    if (one <= v) v = one <= 1 ? 1 : one <= 2 ? 2 : one <= 4 ? 4 : 7;
+    return v;
+}
+
+int san_act_bwd_cluster_set_tuning(int on, int min_hw, int v, int bn_on) {
+    if (bn_on >= 0) g_bn_cluster_on = bn_on ? 1 : 0;
+    if (on >= 0) g_cluster_on = on ? 1 : 0;
+    if (min_hw > 0) g_cluster_min = min_hw;
+    if (v > 0) g_cluster_v = v;
+    return SAN_OK;
+}
+
+// int32 words of zero-initialised scratch san_act_bwd_in wants for [n, c] planes of hw pixels; 0: use san_act_bwd*_amax
+int san_act_bwd_in_sync_words(int n, int c, int hw) {
+    if (!g_cluster_on || n <= 0 || c <= 0 || hw < g_cluster_min || (hw & 3)) return 0;
+    const int K = san_cdiv(hw >> 2, kClT * cluster_v_for(hw >> 2));
+    if (K < 2 || K > 256) return 0;
+    return n * c * cluster_rec_words(K);
+}
+
+// InstanceNorm + LeakyReLU backward in ONE pass for planes of any size (round 6): san_act_bwd_amax / _up_amax / _ex_amax in one
+// entry (g2 may be NULL; flags as san_act_bwd_ex_amax; w = plane width, needed with g2 or flags & 1).  sync: the scratch of
+// san_act_bwd_in_sync_words(n, c, hw) int32 words, zeroed ONCE by the caller (the kernel leaves it zero).  Needs hw % 4 == 0 and
+// 16-byte aligned g, y (and dy unless flags & 1).
+int san_act_bwd_in(const float* g, int g_ctot, int g_coff, const float* g2, int g2_ctot, int g2_coff, float g2_scale,
+                   const float* y, int y_ctot, int y_coff, const float* sc, const float* sh, float slope, float* dy, int d_ctot,
+                   int d_coff, void* amax, int n, int c, int hw, int w, int flags, void* sync, void* stream) {
+    SAN_CHECK_ARG(g && y && dy && sync, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0 && (hw & 3) == 0, "bad dims (hw % 4 == 0)");
+    SAN_CHECK_ARG((flags & ~3) == 0, "flags: 1 = shuffled store, 2 = accumulate");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    DyDst dd{0, (flags & 2) ? 1 : 0, 1, 1.f};
+    if (flags & 1) {
+        SAN_CHECK_ARG(w > 0 && (w & 3) == 0 && hw % w == 0 && ((hw / w) & 1) == 0 && (hw >> 2) < (1 << 22), "shuffled store: width % 4 == 0, even height");
+        SAN_CHECK_ARG(((uintptr_t)dy & 7) == 0, "shuffled store: 8-byte aligned destination");
+        SAN_CHECK_ARG(d_coff >= 0 && d_coff + 4 * c <= d_ctot, "bad channel view (shuffled destination)");
+        dd = DyDst{hw >> 2, dd.acc, w >> 2, 1.f / (float)(w >> 2)};
+    }
+    G2Src q{nullptr, 0, 0, 0.f, 1, 1.f};
+    if (g2) {
+        SAN_CHECK_ARG(w > 0 && (w & 3) == 0 && hw % w == 0 && ((hw / w) & 1) == 0 && (hw >> 2) < (1 << 22), "second gradient source: width % 4 == 0, even height");
+        SAN_CHECK_ARG(g2_coff >= 0 && g2_coff + c <= g2_ctot && ((uintptr_t)g2 & 7) == 0, "bad second source");
+        q = G2Src{g2, g2_ctot, g2_coff, g2_scale, w >> 2, 1.f / (float)(w >> 2)};
+    }
+    SAN_CHECK_ARG(((((uintptr_t)g | (uintptr_t)y | (dd.shuf ? (uintptr_t)0 : (uintptr_t)dy))) & 15) == 0, "16-byte aligned tensors");
+    SAN_CHECK_ARG(g_coff >= 0 && g_coff + c <= g_ctot && y_coff >= 0 && y_coff + c <= y_ctot && d_coff >= 0 &&
+                      (dd.shuf || d_coff + c <= d_ctot), "bad channel view");
+    const int v = cluster_v_for(hw >> 2);
+    const int K = san_cdiv(hw >> 2, kClT * v);
+    SAN_CHECK_ARG(K >= 1 && K <= 256, "plane too large for one cluster");
+    return cluster_launch<0>(v, dim3(K, c, n), (hipStream_t)stream, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot,
+                             d_coff, hw, static_cast<unsigned*>(amax), q, dd, static_cast<unsigned*>(sync), nullptr, nullptr, nullptr,
+                             nullptr, 1.0);
+}
+
+// Training-mode BatchNorm2d + LeakyReLU backward (unet.py:125) in ONE pass: san_plane_dot_stats + san_bn_bwd_finalize +
+// san_act_bwd_coef_amax.  dgamma / dbeta are accumulated into; sync: san_bn_act_bwd_sync_words(n, c, hw) zeroed int32 words
+// (0 words: shape not covered, use the three-launch form).
+int san_bn_act_bwd_sync_words(int n, int c, int hw) {
+    if (!g_bn_cluster_on || n <= 0 || c <= 0 || hw <= 0 || (hw & 3)) return 0;
+    const int K = san_cdiv(hw >> 2, kClT * cluster_v_for(hw >> 2, 7));
+    if ((long long)K * n > (g_bn_members_max < 256 ? g_bn_members_max : 256)) return 0;
+    return c * cluster_rec_words(K * n);
+}
+
+int san_bn_act_bwd(const float* g, int g_ctot, int g_coff, const float* y, int y_ctot, int y_coff, const float* sc, const float* sh,
+                   float slope, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dy, int d_ctot,
+                   int d_coff, void* amax, int n, int c, int hw, void* sync, void* stream) {
+    SAN_CHECK_ARG(g && y && dy && sync && gamma && beta && dgamma && dbeta, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && hw > 0 && (hw & 3) == 0, "bad dims (hw % 4 == 0)");
+    SAN_CHECK_ARG((sc == nullptr) == (sh == nullptr), "scale/shift must come together");
+    SAN_CHECK_ARG(((((uintptr_t)g | (uintptr_t)y | (uintptr_t)dy)) & 15) == 0, "16-byte aligned tensors");
+    SAN_CHECK_ARG(g_coff >= 0 && g_coff + c <= g_ctot && y_coff >= 0 && y_coff + c <= y_ctot && d_coff >= 0 && d_coff + c <= d_ctot,
+                  "bad channel view");
+    const int v = cluster_v_for(hw >> 2, 7);
+    const int K = san_cdiv(hw >> 2, kClT * v);
+    SAN_CHECK_ARG((long long)K * n <= 256, "too many cluster members");
+    return cluster_launch<1>(v, dim3(K, n, c), (hipStream_t)stream, g, g_ctot, g_coff, y, y_ctot, y_coff, sc, sh, slope, dy, d_ctot,
+                             d_coff, hw, static_cast<unsigned*>(amax), G2Src{nullptr, 0, 0, 0.f, 1, 1.f}, DyDst{0, 0, 1, 1.f},
+                             static_cast<unsigned*>(sync), gamma, beta, dgamma, dbeta, (double)n * (double)hw);
 }
 
 // uint32 words of one amax record (see san_common.h)

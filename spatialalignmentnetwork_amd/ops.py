@@ -1611,6 +1611,28 @@ def act_bwd_up_ok(y: Act) -> bool:
     return (y.h & 1) == 0 and (y.w & 3) == 0 and y.h * y.w // 4 < (1 << 22)
 
 
+def _act_bwd_in(g: Act, y: Act, dy: Act, arena: Arena, g2: Optional[Act] = None, g2_scale: float = 0.25, flags: int = 0) -> bool:
+    """The one-pass cluster form of the InstanceNorm backward (san_act_bwd_in, round 6) where the library wants it for this
+    shape and the tensors are 16-byte aligned; False: the caller runs the multi-launch form.  ``dy.amax`` is already set."""
+    hw = y.h * y.w
+    words = lib().query("san_act_bwd_in_sync_words", y.n, y.c, hw)
+    if not words:
+        return False
+    if (g.buf.data_ptr() | y.buf.data_ptr() | (0 if (flags & 1) else dy.buf.data_ptr())) % 16 or (g2 is not None and g2.buf.data_ptr() % 8):
+        return False
+    # zero once, at creation: the kernel leaves its counters zero (a recorded step replays the launch with the same buffer)
+    # (one buffer per SHAPE, not per size: a record's layout -- members' sums, then the two counters -- depends on the cluster
+    # size, and only the counters return to zero; two shapes with equal word counts must never meet in one buffer)
+    sync = arena.get(f"bwd_sync.{y.n}.{y.c}.{hw}", (words,), y.buf.device, dtype=torch.int32, zero=True)
+    args = (_p(g.buf), g.ctot, g.coff, _p(None if g2 is None else g2.buf), 0 if g2 is None else g2.ctot, 0 if g2 is None else g2.coff,
+            float(g2_scale), _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift), float(y.slope), _p(dy.buf), dy.ctot, dy.coff,
+            _p(dy.amax), y.n, y.c, hw, y.w, int(flags), _p(sync), _stream())
+    # one pass: g and y read once, dy written once (+ the quarter-size second source / the accumulated destination)
+    extra = (0.25 if g2 is not None else 0.0) + (1.0 if (flags & 2) else 0.0)
+    _timed("act_bwd", 4.0 * y.n * y.c * hw * (3.0 + extra), "B", lambda: lib().call("san_act_bwd_in", *args))
+    return True
+
+
 def act_bwd_ex(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_ARENA, unshuffle: bool = False,
                accumulate: bool = False) -> None:
     """act_bwd with a destination mode (san_act_bwd_ex_amax).  unshuffle: dy is a [n, 4c, h/2, w/2] view and receives the
@@ -1619,9 +1641,11 @@ def act_bwd_ex(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOB
     assert g.c == y.c and (dy.c == 4 * y.c if unshuffle else dy.c == y.c)
     hw = y.h * y.w
     part = None
+    dy.amax = AMAX.next(y.buf.device)
+    if instance_norm and _act_bwd_in(g, y, dy, arena, flags=(1 if unshuffle else 0) | (2 if accumulate else 0)):
+        return
     if instance_norm:
         part = arena.get("bwd_part", (y.n, y.c, lib().query("san_bwd_stat_tiles", hw), 2), y.buf.device)
-    dy.amax = AMAX.next(y.buf.device)
     eargs = (_p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift),
              float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, y.w,
              (1 if unshuffle else 0) | (2 if accumulate else 0), _stream())
@@ -1640,12 +1664,15 @@ def act_bwd(g: Act, y: Act, dy: Act, instance_norm: bool, arena: Arena = GLOBAL_
     assert g.c == y.c == dy.c
     hw = y.h * y.w
     part = None
-    if instance_norm:
-        tiles = lib().query("san_bwd_stat_tiles", hw)
-        part = arena.get("bwd_part", (y.n, y.c, tiles, 2), y.buf.device)
     dy.amax = AMAX.next(y.buf.device)
     if g2 is not None:
         assert g2.c == y.c and (2 * g2.h, 2 * g2.w) == (y.h, y.w) and act_bwd_up_ok(y)
+    if instance_norm and _act_bwd_in(g, y, dy, arena, g2, g2_scale):
+        return
+    if instance_norm:
+        tiles = lib().query("san_bwd_stat_tiles", hw)
+        part = arena.get("bwd_part", (y.n, y.c, tiles, 2), y.buf.device)
+    if g2 is not None:
         uargs = (_p(g.buf), g.ctot, g.coff, _p(g2.buf), g2.ctot, g2.coff, float(g2_scale), _p(y.buf),
                  y.ctot, y.coff, _p(y.scale), _p(y.shift), float(y.slope), 1 if instance_norm else 0, _p(part), _p(dy.buf),
                  dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, y.w, _stream())
@@ -1692,6 +1719,24 @@ def bn_bwd_coef(g: Act, y: Act, gamma: torch.Tensor, beta: torch.Tensor, dgamma:
                _p(_chk(dgamma, name="dgamma")), _p(_chk(dbeta, name="dbeta")), _p(coef), y.n, y.c, int(part.shape[2]),
                float(y.n * y.h * y.w), _stream())
     return coef
+
+
+def bn_act_bwd(g: Act, y: Act, gamma: torch.Tensor, beta: torch.Tensor, dgamma: torch.Tensor, dbeta: torch.Tensor, dy: Act,
+               arena: Arena = GLOBAL_ARENA) -> None:
+    """Training-mode BatchNorm2d + LeakyReLU backward (unet.py:125): dy = dL/dy_raw, dgamma / dbeta accumulated.  ONE launch on
+    workgroup clusters (san_bn_act_bwd, round 6) where the library covers the shape, else plane sums + finalisation + apply."""
+    assert g.c == y.c == dy.c
+    hw = y.h * y.w
+    words = lib().query("san_bn_act_bwd_sync_words", y.n, y.c, hw)
+    if words and (g.buf.data_ptr() | y.buf.data_ptr() | dy.buf.data_ptr()) % 16 == 0:
+        dy.amax = AMAX.next(y.buf.device)
+        sync = arena.get(f"bn_bwd_sync.{y.n}.{y.c}.{hw}", (words,), y.buf.device, dtype=torch.int32, zero=True)     # (per shape: see _act_bwd_in)
+        lib().call("san_bn_act_bwd", _p(g.buf), g.ctot, g.coff, _p(y.buf), y.ctot, y.coff, _p(y.scale), _p(y.shift), float(y.slope),
+                   _p(_chk(gamma, name="gamma")), _p(_chk(beta, name="beta")), _p(_chk(dgamma, name="dgamma")),
+                   _p(_chk(dbeta, name="dbeta")), _p(dy.buf), dy.ctot, dy.coff, _p(dy.amax), y.n, y.c, hw, _p(sync), _stream())
+        return
+    coef = bn_bwd_coef(g, y, gamma, beta, dgamma, dbeta, arena)
+    act_bwd_coef(g, y, coef, dy)
 
 
 def norm_finalize_bn(part: torch.Tensor, eps: float, scale: torch.Tensor, shift: torch.Tensor, coff: int, bn, bmean: torch.Tensor,

@@ -255,8 +255,7 @@ class UNet(torch.nn.Module):
                 dy = tmp(o.c, h, w, n)
                 if bn is not None and bn.training:
                     # per channel over (N, H, W): dbeta = sum u, dgamma = sum u * yn with yn = (yh - beta)/gamma
-                    coef = ops.bn_bwd_coef(g, o, bn.weight, bn.bias, _grad_of(bn.weight), _grad_of(bn.bias))
-                    ops.act_bwd_coef(g, o, coef, dy)
+                    ops.bn_act_bwd(g, o, bn.weight, bn.bias, _grad_of(bn.weight), _grad_of(bn.bias), dy)
                 else:
                     ops.act_bwd(g, o, dy, instance_norm=False)   # eval BN / plain activation read
                     if bn is not None:
