@@ -508,10 +508,20 @@ def main(argv=None):
     ops.TIMER = None
     dt = sdist.max_over_ranks(dt, dist, dev)
     host_ms = 1e3 * sdist.max_over_ranks(host_s, dist, dev) / args.steps
-    allreduce_ms = None
+    allreduce_ms = exchange_detail = None
     if args.mode == "train" and dist is not None and not args.graph:
         # (a recorded step holds ONE set of event pairs, re-recorded by every replay: the last replay's duration)
-        allreduce_ms = sdist.max_over_ranks(net.exchange_ms(), dist, dev) / (1 if replaying else args.steps)
+        per = 1 if replaying else args.steps
+        mine, exposed = net.exchange_ms() / per, net.exchange_exposed_ms() / per
+        allreduce_ms = sdist.max_over_ranks(mine, dist, dev)
+        # per rank: the collectives' time on the communication stream, how long the main stream WAITED for them at the join in
+        # front of the optimiser (exposed), and the rest (hidden behind the backward pass) -- so that the first run on a real
+        # multi-GPU node explains its own scaling
+        tot_r, exp_r = sdist.gather_over_ranks(mine, dist, dev), sdist.gather_over_ranks(exposed, dist, dev)
+        exchange_detail = {"mode": sdist.exchange_mode() if sdist.NATIVE["handle"] is not None else "allreduce",
+                           "collective_ms_per_rank": tot_r, "exposed_ms_per_rank": exp_r,
+                           "hidden_ms_per_rank": [max(0.0, a - b) for a, b in zip(tot_r, exp_r)],
+                           "slices_per_step": len(getattr(net, "exchange_slices", []) or [])}
 
     state_digest = None
     if args.digest:
@@ -659,6 +669,7 @@ def main(argv=None):
             # HIP events around the gradient all-reduces on the communication stream (per step, max over ranks; net_R's
             # bucket overlaps the alignment network's backward); null on one GPU and in --graph mode
             "allreduce_ms": allreduce_ms,
+            "exchange": exchange_detail,
         }
         if state_digest is not None:
             out["state_digest"] = state_digest

@@ -252,6 +252,23 @@ int san_bn_update_running(float* rmean, float* rvar, long long* num_batches_trac
 int san_normunet_bwd_coefs(const float* part_b, const float* part_a, int tiles, const float* scale,
                            const float* shift, int x_ctot, const float* stdv, double nel,
                            float* a_sc, float* a_sh, int g_ctot, float* m_sc, float* m_sh, int b, void* stream);
+/* NormUnet backward as two launches around the U-Net's own (round 6; varnet.py:246-332 backwards, csrc/san_bwd.hip).
+ * san_normunet_bwd_head: g_u = g_out * std (dL/dU) and part_b[b, 2, san_bwd_stat_tiles(hw), 2] = chunk sums (sum g_out,
+ *   sum g_out U), U = out_planar * isd + nshift -- san_plane_dot_stats + san_apply_fwd in one pass; the last 1x1 convolution's
+ *   bias gradient sum(g_u) = std * sum(g_out) is taken from part_b by the tail (no san_plane_stats / san_bias_grad_from_stats).
+ * san_normunet_bwd_tail: san_normunet_bwd_coefs + san_add_fwd + san_sens_grad_prop + the reference channel's InstanceNorm
+ *   backward + san_partials_add in one pass: every workgroup derives the affines of dL/dm from part_b and part_x (= san_plane_dot_stats
+ *   of (g_xh, xin) over the first xc = 2 or 3 channels), forms g_m per pixel without storing it, and applies gd[n, c] += g_m S[n, c]
+ *   (+ the sensitivity-map accumulation when gs != NULL: gs += sign1 conj(r) t1 + xs conj(g_m)); g_ref [b, 1, hw] (NULL: none;
+ *   needs xc = 3) (+)= the gradient wrt the reference input; db[2] += the bias gradient; dcw[0] += dcw_scale * sum(dcw_part[0 ..
+ *   dcw_count)) (dc_weight, varnet.py:523).  b = samples, c = coils. */
+int san_normunet_bwd_head(const float* g_out, const float* out_planar, const float* isd, const float* nshift, const float* stdv,
+                          float* g_u, float* part_b, int b, int hw, void* stream);
+int san_normunet_bwd_tail(const float* part_b, const float* part_x, int xc, const float* xin, int x_ctot, const float* x_scale,
+                          const float* x_shift, const float* stdv, double nel, const float* g_xh, int g_ctot, float* gd,
+                          const float* sens, float* gs, const float* r_planar, const float* t1, const float* xs, float sign1,
+                          float* g_ref, int ref_accumulate, float* db, const float* dcw_part, int dcw_count, float dcw_scale,
+                          float* dcw, int b, int c, int hw, void* stream);
 int san_warp_bwd_grid(const float* img, const float* grid, const float* g, float* g_off,
                       int n, int c, int h, int w, void* stream);
 int san_gradient_loss_bwd(const float* offset, float* g, float gscale, int accumulate, int n, int h, int w,

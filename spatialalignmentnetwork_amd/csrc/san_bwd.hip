@@ -1477,6 +1477,202 @@ __global__ void normunet_bwd_coefs_kernel(const float* __restrict__ partB, const
     }
 }
 
+// ---- NormUnet backward, the two ends of a cascade's U-Net backward as ONE launch each (round 6) ----------------------------------
+// HEAD (varnet.py:321-332 backwards): with U = unnorm^-1(out) = out * isd + nshift and g = dL/d out,
+//     g_u = g * std  (dL/dU)           part_b[n, ch, t] = chunk sums (sum g, sum g U)  (what san_plane_dot_stats writes)
+// replaces san_plane_dot_stats + san_apply_fwd + san_plane_stats + san_bias_grad_from_stats: the final 1x1 convolution's bias gradient
+// sum(g_u) = std * sum(g) comes out of part_b in the tail launch.  Chunks, summation order and rounding are bwd_stats_kernel's.
+__global__ void __launch_bounds__(kThreads) SAN_NO_PK32
+normunet_bwd_head_kernel(const float* __restrict__ g, const float* __restrict__ out, const float* __restrict__ isd,
+                         const float* __restrict__ nshift, const float* __restrict__ stdv, float* __restrict__ gu,
+                         float* __restrict__ part, int hw, int tiles) {
+    __shared__ float red[8];
+    const int t = blockIdx.x, ch = blockIdx.y, n = blockIdx.z;
+    const int chunk = (((hw + tiles - 1) / tiles) + 3) & ~3;
+    const int lo = t * chunk;
+    const int cnt = max(0, min(hw, lo + chunk) - lo);
+    const size_t plane = ((size_t)(n * 2 + ch)) * hw + lo;
+    const float* gp = g + plane;
+    const float* op = out + plane;
+    float* up = gu + plane;
+    const float s = isd[n * 2 + ch], b = nshift[n * 2 + ch], sd = stdv[n * 2 + ch];
+    float s1 = 0.f, s2 = 0.f;
+    if ((((uintptr_t)gp | (uintptr_t)op | (uintptr_t)up) & 15) == 0) {
+        const int c4 = cnt >> 2;
+        for (int i = threadIdx.x; i < c4; i += kThreads) {
+            const bf4 gv = reinterpret_cast<const bf4*>(gp)[i];
+            const bf4 ov = reinterpret_cast<const bf4*>(op)[i];
+            bf4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float U = fmaf(ov[e], s, b);
+                s1 += gv[e];
+                s2 = fmaf(gv[e], U, s2);
+                o[e] = fmaf(gv[e], sd, 0.f);
+            }
+            reinterpret_cast<bf4*>(up)[i] = o;
+        }
+        for (int i = 4 * c4 + threadIdx.x; i < cnt; i += kThreads) {
+            const float U = fmaf(op[i], s, b);
+            s1 += gp[i];
+            s2 = fmaf(gp[i], U, s2);
+            up[i] = fmaf(gp[i], sd, 0.f);
+        }
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += kThreads) {
+            const float U = fmaf(op[i], s, b);
+            s1 += gp[i];
+            s2 = fmaf(gp[i], U, s2);
+            up[i] = fmaf(gp[i], sd, 0.f);
+        }
+    }
+    s1 = san_wave_total(s1);
+    s2 = san_wave_total(s2);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s1;
+        red[4 + (threadIdx.x >> 6)] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float* o = part + ((size_t)(n * 2 + ch) * tiles + t) * 2;
+        o[0] = (red[0] + red[1]) + (red[2] + red[3]);
+        o[1] = (red[4] + red[5]) + (red[6] + red[7]);
+    }
+}
+
+// TAIL: everything after the U-Net's own backward, one launch over the plane (replaces san_normunet_bwd_coefs + san_add_fwd +
+// san_sens_grad_prop + the reference channel's san_act_bwd + san_partials_add + the bias gradient):
+//   coefficients of dL/dm from part_b (head) and part_x = chunk sums (sum g_xh, sum g_xh xh) of the U-Net input channels
+//   (every workgroup derives them itself, in san_normunet_bwd_coefs' order and precision: identical bits everywhere);
+//   g_m = (a_sc g_xh + a_sh) + (m_sc m + m_sh) per pixel, NOT stored: gd[n, c] += g_m S[n, c] and the sensitivity-map
+//   accumulation gS[n, c] += sign1 conj(r) t1 + x conj(g_m) at once (san_sens_grad_prop);
+//   g_ref (+)= InstanceNorm backward of the reference channel (channel 2 of g_xh / xin; plane sums from part_x);
+//   one workgroup adds the scalar gradients: db[j] += sum_n std[n, j] sum_t part_b[n, j, t, 0] (bias of the last 1x1 convolution)
+//   and dcw[0] += dcw_scale * sum(dcw_part) (dc_weight, varnet.py:523).
+struct NuTailArgs {
+    const float* part_b;       // [b, 2, tiles, 2]
+    const float* part_x;       // [b, xc, tiles, 2], xc = 2 or 3 (with the reference channel)
+    const float* x;            // xin buffer [b, x_ctot, hw] (channels 0, 1 = m planar, 2 = reference)
+    const float* x_sc;         // [b, x_ctot]
+    const float* x_sh;
+    const float* stdv;         // [b, 2]
+    const float* gxh;          // [b, g_ctot, hw]
+    float2* gd;                // [b, C, hw] in / out
+    const float2* S;           // [b, C, hw]
+    float2* gS;                // [b, C, hw] or null
+    const float* r;            // planar [b, 2, hw] (with gS)
+    const float2* t1;          // [b, C, hw] (with gS)
+    const float2* xs;          // [b, C, hw] (with gS)
+    float* g_ref;              // [b, 1, hw] or null
+    float* db;                 // [2] or null
+    const float* dcw_part;     // or null
+    float* dcw;
+    double nel;
+    float sign1, dcw_scale;
+    int tiles, x_ctot, g_ctot, xc, C, hw, b, dcw_count, ref_acc;
+};
+
+__global__ void __launch_bounds__(kThreads) SAN_NO_PK32 normunet_bwd_tail_kernel(const NuTailArgs a) {
+    __shared__ float cf[12];        // asc0 ash0 msc0 msh0 | asc1 ash1 msc1 msh1 | s2 b2 m1 m2
+    __shared__ double red[kThreads / 64];
+    const int n = blockIdx.y;
+    if (threadIdx.x < 2) {
+        const int j = threadIdx.x;
+        const float* pb = a.part_b + ((size_t)n * 2 + j) * a.tiles * 2;
+        const float* pa = a.part_x + ((size_t)n * a.xc + j) * a.tiles * 2;
+        double b1 = 0.0, b2 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int t = 0; t < a.tiles; ++t) {
+            b1 += (double)pb[2 * t];
+            b2 += (double)pb[2 * t + 1];
+            a1 += (double)pa[2 * t];
+            a2 += (double)pa[2 * t + 1];
+        }
+        const double s = (double)a.x_sc[n * a.x_ctot + j], t = (double)a.x_sh[n * a.x_ctot + j], sd = (double)a.stdv[n * 2 + j];
+        const double dmu = b1 - a1 * s, dsig = b2 - a2 * s;
+        const double cco = sd > 0.0 ? dsig / (s * (a.nel - 1.0) * sd) : 0.0;
+        cf[4 * j] = (float)s;
+        cf[4 * j + 1] = (float)(dmu / a.nel);
+        cf[4 * j + 2] = (float)(cco * s);
+        cf[4 * j + 3] = (float)(cco * t);
+    } else if (threadIdx.x == 2 && a.g_ref) {
+        const float* p = a.part_x + ((size_t)n * a.xc + 2) * a.tiles * 2;
+        double t1 = 0.0, t2 = 0.0;
+        for (int t = 0; t < a.tiles; ++t) {
+            t1 += (double)p[2 * t];
+            t2 += (double)p[2 * t + 1];
+        }
+        cf[8] = a.x_sc[n * a.x_ctot + 2];
+        cf[9] = a.x_sh[n * a.x_ctot + 2];
+        cf[10] = (float)(t1 / a.hw);
+        cf[11] = (float)(t2 / a.hw);
+    }
+    __syncthreads();
+    const float asc0 = cf[0], ash0 = cf[1], msc0 = cf[2], msh0 = cf[3], asc1 = cf[4], ash1 = cf[5], msc1 = cf[6], msh1 = cf[7];
+    const size_t HW = a.hw;
+    const float* x0 = a.x + ((size_t)n * a.x_ctot) * HW;
+    const float* g0 = a.gxh + ((size_t)n * a.g_ctot) * HW;
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < a.hw; i += gridDim.x * kThreads) {
+        const float gr = fmaf(g0[i], asc0, ash0) + fmaf(x0[i], msc0, msh0);
+        const float gi = fmaf(g0[HW + i], asc1, ash1) + fmaf(x0[HW + i], msc1, msh1);
+        float rr = 0.f, ri = 0.f;
+        if (a.gS) {
+            rr = a.r[(size_t)n * 2 * HW + i];
+            ri = a.r[(size_t)n * 2 * HW + HW + i];
+        }
+        for (int c = blockIdx.z; c < a.C; c += gridDim.z) {
+            const size_t e = ((size_t)n * a.C + c) * HW + i;
+            if (a.gS) {
+                const float2 t = a.t1[e], xv = a.xs[e];
+                float2 acc = a.gS[e];
+                acc.x += a.sign1 * (rr * t.x + ri * t.y);
+                acc.y += a.sign1 * (rr * t.y - ri * t.x);
+                acc.x += xv.x * gr + xv.y * gi;
+                acc.y += xv.y * gr - xv.x * gi;
+                a.gS[e] = acc;
+            }
+            const float2 sv = a.S[e];
+            float2 gg = a.gd[e];
+            gg.x += gr * sv.x - gi * sv.y;
+            gg.y += gr * sv.y + gi * sv.x;
+            a.gd[e] = gg;
+        }
+        if (a.g_ref && blockIdx.z == 0) {
+            const float yh = fmaf(x0[2 * HW + i], cf[8], cf[9]);
+            const float u = g0[2 * HW + i];                         // (the reference enters without an activation: slope 1)
+            const float o = cf[8] * (u - cf[10] - yh * cf[11]);
+            float* q = a.g_ref + (size_t)n * HW + i;
+            *q = a.ref_acc ? *q + o : o;
+        }
+    }
+    // the scalar gradients: the launch's first workgroup, fixed order (thread-strided double sums + a fixed tree)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+        if (a.db && threadIdx.x < 128) {
+            // bias of the last 1x1 convolution: one wave per channel, lanes over (sample, chunk), double butterfly
+            const int j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            double sb = 0.0;
+            for (int e = lane; e < a.b * a.tiles; e += 64) {
+                const int bi = e / a.tiles, t = e - bi * a.tiles;
+                sb += (double)a.stdv[bi * 2 + j] * (double)a.part_b[(((size_t)bi * 2 + j) * a.tiles + t) * 2];
+            }
+            sb = san_wave_sum_d(sb);
+            if (lane == 0) a.db[j] += (float)sb;
+        }
+        if (a.dcw_part) {
+            double sd = 0.0;
+            for (int i = threadIdx.x; i < a.dcw_count; i += kThreads) sd += (double)a.dcw_part[i];
+            sd = san_wave_sum_d(sd);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sd;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tot = 0.0;
+                for (int w = 0; w < kThreads / 64; ++w) tot += red[w];
+                a.dcw[0] += (float)((double)a.dcw_scale * tot);
+            }
+        }
+    }
+}
+
 // dst[0] += scale * sum(part[0 .. count)): double accumulation in a fixed order (thread-strided sums, then a fixed tree), one
 // workgroup.  The scalar parameter gradients that arrive as per-workgroup partials (dc_weight) without host-side glue.
 __global__ void __launch_bounds__(256) partials_add_kernel(const float* __restrict__ part, int count, float scale,
@@ -2007,6 +2203,68 @@ int san_normunet_bwd_coefs(const float* part_b, const float* part_a, int tiles, 
     const int width = g_ctot > x_ctot ? g_ctot : x_ctot;
     hipLaunchKernelGGL(normunet_bwd_coefs_kernel, dim3(san_cdiv(b * width, 64)), dim3(64), 0, (hipStream_t)stream, part_b,
                        part_a, tiles, scale, shift, x_ctot, stdv, nel, a_sc, a_sh, g_ctot, m_sc, m_sh, b);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+// NormUnet backward head / tail (normunet_bwd_head_kernel, normunet_bwd_tail_kernel): see the kernels.  part_b: fp32 [b, 2,
+// san_bwd_stat_tiles(hw), 2]; part_x: [b, xc, tiles, 2] = san_plane_dot_stats over the first xc (2, or 3 with g_ref) channels of
+// (g_xh, xin); gs / r_planar / t1 / xs may be NULL together (no sensitivity-map gradient), g_ref / db / dcw_part may be NULL.
+int san_normunet_bwd_head(const float* g_out, const float* out_planar, const float* isd, const float* nshift, const float* stdv,
+                          float* g_u, float* part_b, int b, int hw, void* stream) {
+    SAN_CHECK_ARG(g_out && out_planar && isd && nshift && stdv && g_u && part_b, "null pointer");
+    SAN_CHECK_ARG(b > 0 && hw > 0, "bad dims");
+    const int tiles = san_bwd_stat_tiles(hw);
+    hipLaunchKernelGGL(normunet_bwd_head_kernel, dim3(tiles, 2, b), dim3(kThreads), 0, (hipStream_t)stream, g_out, out_planar, isd,
+                       nshift, stdv, g_u, part_b, hw, tiles);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+int san_normunet_bwd_tail(const float* part_b, const float* part_x, int xc, const float* xin, int x_ctot, const float* x_scale,
+                          const float* x_shift, const float* stdv, double nel, const float* g_xh, int g_ctot, float* gd,
+                          const float* sens, float* gs, const float* r_planar, const float* t1, const float* xs, float sign1,
+                          float* g_ref, int ref_accumulate, float* db, const float* dcw_part, int dcw_count, float dcw_scale,
+                          float* dcw, int b, int c, int hw, void* stream) {
+    SAN_CHECK_ARG(part_b && part_x && xin && x_scale && x_shift && stdv && g_xh && gd && sens, "null pointer");
+    SAN_CHECK_ARG(!gs || (r_planar && t1 && xs), "the sensitivity-map accumulation needs r, t1 and x");
+    SAN_CHECK_ARG(b > 0 && c > 0 && hw > 0 && x_ctot >= 2 && g_ctot >= 2 && (xc == 2 || xc == 3), "bad dims");
+    SAN_CHECK_ARG(!g_ref || (xc == 3 && x_ctot >= 3 && g_ctot >= 3), "the reference channel's gradient needs three channels");
+    SAN_CHECK_ARG(!dcw_part || (dcw && dcw_count > 0), "dc_weight partials without a destination");
+    NuTailArgs a{};
+    a.part_b = part_b;
+    a.part_x = part_x;
+    a.x = xin;
+    a.x_sc = x_scale;
+    a.x_sh = x_shift;
+    a.stdv = stdv;
+    a.gxh = g_xh;
+    a.gd = (float2*)gd;
+    a.S = (const float2*)sens;
+    a.gS = (float2*)gs;
+    a.r = r_planar;
+    a.t1 = (const float2*)t1;
+    a.xs = (const float2*)xs;
+    a.g_ref = g_ref;
+    a.db = db;
+    a.dcw_part = dcw_part;
+    a.dcw = dcw;
+    a.nel = nel;
+    a.sign1 = sign1;
+    a.dcw_scale = dcw_scale;
+    a.tiles = san_bwd_stat_tiles(hw);
+    a.x_ctot = x_ctot;
+    a.g_ctot = g_ctot;
+    a.xc = xc;
+    a.C = c;
+    a.hw = hw;
+    a.b = b;
+    a.dcw_count = dcw_count;
+    a.ref_acc = ref_accumulate;
+    int bx = san_cdiv(hw, kThreads);
+    const int cap = c > 1 ? 2048 : 256;
+    if (bx > cap) bx = cap;
+    hipLaunchKernelGGL(normunet_bwd_tail_kernel, dim3(bx, b, c > 64 ? 64 : c), dim3(kThreads), 0, (hipStream_t)stream, a);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -225,6 +225,29 @@ def prebind_streams(device) -> None:
     torch.cuda.synchronize(dev)
 
 
+def exchange_mode() -> str:
+    """``SAN_GRAD_EXCHANGE``: "allreduce" (default: one ncclAllReduce per slice) or "rs_ag" (reduce-scatter + all-gather per slice;
+    native RCCL communicator only -- anything else falls back to the all-reduce)."""
+    m = os.environ.get("SAN_GRAD_EXCHANGE", "allreduce")
+    if m not in ("allreduce", "rs_ag"):
+        raise ValueError(f"SAN_GRAD_EXCHANGE={m!r}: choose allreduce or rs_ag")
+    return m
+
+
+def agree_on_failure(err, dist, device):
+    """Every rank passes its own failure (a message, or None); all of them get a message back if ANY rank failed (their own, or
+    "another rank ...") and None only if every rank succeeded: the ranks then take the same branch (CSModel.update: replay the
+    recorded step everywhere or stay eager everywhere -- a rank that failed half-way must not be left alone with the others'
+    next collective)."""
+    if dist is None:
+        return err
+    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=_scalar_device(device))
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()) and err is None:
+        err = "another rank could not record the step"
+    return err
+
+
 def single_rank_exchange() -> bool:
     """``SAN_DIST_SINGLE=1``: treat a ONE-rank process group as data-parallel, i.e. run the whole gradient exchange (RCCL
     communicator, communication stream, per-cascade slices, recorded / captured collectives) with world size 1.  A one-GPU box
@@ -264,6 +287,17 @@ def max_over_ranks(value: float, dist, device="cpu") -> float:
     t = torch.tensor([value], dtype=torch.float64, device=_scalar_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_over_ranks(value: float, dist, device="cpu"):
+    """[rank 0's value, rank 1's, ...] on every rank (bench.py: per-rank exchange timings)."""
+    if dist is None:
+        return [float(value)]
+    world = dist.get_world_size()
+    t = torch.zeros(world, dtype=torch.float64, device=_scalar_device(device))
+    t[dist.get_rank()] = value
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)        # (one-hot rows: a sum is a gather that every backend has)
+    return [float(v) for v in t.tolist()]
 
 
 def sum_over_ranks(value: float, dist, device="cpu") -> float:
@@ -375,7 +409,9 @@ class GradExchange:
         self.launched = []              # the slices (None = a whole buffer) in launch order
         self.timed = timed
         self.events = []
+        self.wait_events = []           # (before, after) the main stream's join: how long the step WAITED for the exchange
         self.comm = None
+        self.mode = exchange_mode()
 
     def _comm(self, device):
         key = str(device)
@@ -417,8 +453,21 @@ class GradExchange:
             _lib.rec(e0.record, comm)
         nat = native_rccl(dist, flat.device)
         if nat is not None:
-            # a C-ABI call on the communication stream: a tape entry of the recorded step, no Python at replay time
-            _lib.lib().call("san_rccl_allreduce_sum_f32", nat, flat.data_ptr(), flat.numel(), comm.cuda_stream)
+            # C-ABI calls on the communication stream: tape entries of the recorded step, no Python at replay time
+            world, rank = dist.get_world_size(), dist.get_rank()
+            chunk = flat.numel() // world if self.mode == "rs_ag" else 0
+            if chunk:
+                # SAN_GRAD_EXCHANGE=rs_ag: the sum as a direct reduce-scatter + all-gather, both in place (rank r owns
+                # chunk r): on a fully connected xGMI node each phase moves 1/world of the slice over every link at once.  The few
+                # elements past world * chunk take a small all-reduce.  Deterministic, but a different summation order than
+                # ncclAllReduce's for more than two ranks: all ranks of a job use the same mode (part of the recording's key).
+                base, body = flat.data_ptr(), chunk * world
+                _lib.lib().call("san_rccl_reduce_scatter_sum_f32", nat, base, base + 4 * rank * chunk, chunk, comm.cuda_stream)
+                _lib.lib().call("san_rccl_allgather_f32", nat, base + 4 * rank * chunk, base, chunk, comm.cuda_stream)
+                if flat.numel() > body:
+                    _lib.lib().call("san_rccl_allreduce_sum_f32", nat, base + 4 * body, flat.numel() - body, comm.cuda_stream)
+            else:
+                _lib.lib().call("san_rccl_allreduce_sum_f32", nat, flat.data_ptr(), flat.numel(), comm.cuda_stream)
         else:
             _lib.rec(_collective)
         if timed:
@@ -429,12 +478,25 @@ class GradExchange:
     def wait(self) -> None:
         if self.comm is not None:
             from . import _lib
-            _lib.rec(torch.cuda.current_stream().wait_stream, self.comm)
+            cur = torch.cuda.current_stream()
+            timed = self.timed and not torch.cuda.is_current_stream_capturing()
+            if timed:
+                # an event pair around the join on the MAIN stream: what it measures is the exchange the backward did not hide
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                _lib.rec(w0.record, cur)
+            _lib.rec(cur.wait_stream, self.comm)
+            if timed:
+                _lib.rec(w1.record, cur)
+                self.wait_events.append((w0, w1))
         self.works.clear()
 
     def elapsed_ms(self) -> float:
         """Sum of the collectives' durations on the communication stream (needs a prior synchronisation)."""
         return float(sum(e0.elapsed_time(e1) for e0, e1 in self.events))
+
+    def exposed_ms(self) -> float:
+        """How long the main stream waited for the exchange at the join (needs a prior synchronisation)."""
+        return float(sum(e0.elapsed_time(e1) for e0, e1 in self.wait_events))
 
 
 class ParamBucket(GradBucket):

@@ -41,7 +41,6 @@ def gradient_loss(s: torch.Tensor) -> torch.Tensor:
 AUTO_RECORD = [os.environ.get("SAN_AUTO_RECORD", "1") != "0"]
 # Data-parallel gradient exchange of net_R: "cascade" (default) = one all-reduce per cascade in reverse order, launched from
 # inside VarNet.backward as each cascade's gradients become final; "single" = the whole flat buffer afterwards.
-GRAD_BUCKETS = [os.environ.get("SAN_GRAD_BUCKETS", "cascade")]
 AUTO_AFTER = 2
 AUTO_KEEP = 3          # recordings kept besides the current one (each holds its step's tensors: ~6 GB at N = 8, 320^2)
 # Sensitivity network on an auxiliary stream beside the alignment network (forward and backward).  On by default again in round 5:
@@ -84,7 +83,7 @@ class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena", "_exchange",
-                                                         "_exchange_events", "exchange_slices", "_aux_stream", "_split_capture", "time_exchange", "_auto", "_auto_cache", "_auto_busy", "auto_record", "step_mode"}
+                                                         "_exchange_events", "_exchange_wait_events", "exchange_slices", "_aux_stream", "_split_capture", "time_exchange", "_auto", "_auto_cache", "_auto_busy", "auto_record", "step_mode", "_input_pending"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -129,6 +128,17 @@ class CSModel(BaseModel):
         assert len(extra) == 0, extra
         self.img_full = img_full.contiguous()
         self.img_aux = torch.zeros_like(img_full) if img_aux is None else img_aux.contiguous()
+        # ONCE per step (round 6): when update() will replay a recorded step for exactly this configuration, the recording
+        # contains this prologue -- computing it here as well ran 3 FFT + 3 rss launches and their host work twice per step.
+        # The derived img_* attributes then come out of the replay; a read before that (test(), get_vis(), user code)
+        # computes them on demand (__getattr__ -> _materialize_input).
+        st = self._auto_state() if self.training else None
+        if st is not None and st["step"] is not None:
+            self._input_pending = True
+            return
+        self._set_input_compute()
+
+    def _set_input_compute(self):
         pruned = self.net_mask.pruned
         keep = _keep_mask(pruned)
         self.img_k_full = ops.fft2c(self.img_full)
@@ -141,6 +151,21 @@ class CSModel(BaseModel):
         with _lib.untracked():                   # (a constant of the model, for visualisation only)
             vis = (1.0 - pruned.float()).roll(w // 2).view(1, 1, 1, w).expand(n, 1, h, w)   # fftshift2 of a column mask
         self.img_mask = vis
+
+    def _materialize_input(self) -> None:
+        """The deferred half of set_input, if it is still owed (see set_input)."""
+        if self.__dict__.get("_input_pending"):
+            self._input_pending = False
+            with ops.use_arena(ops.owner_arena(self)):
+                self._set_input_compute()
+
+    def __getattr__(self, name):
+        # (only reached when normal lookup fails: an img_* attribute read between a deferred set_input and the replay)
+        if name.startswith("img_") and self.__dict__.get("_input_pending"):
+            self._materialize_input()
+            if name in self.__dict__:
+                return self.__dict__[name]
+        raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
 
     # ---------------------------------------------------------------- forwards
     def _sens_fork(self) -> None:
@@ -214,7 +239,7 @@ class CSModel(BaseModel):
     def _backward(self, train_T: bool) -> None:
         g_rec = ops.ssim_loss_bwd(self.img_full_rss, self.img_rec, float(self.cfg.weight_sim))
         exch = getattr(self, "_exchange", None)
-        per_cascade = exch is not None and GRAD_BUCKETS[0] == "cascade"
+        per_cascade = exch is not None             # ONE bucket form: net_R's buffer goes out cascade by cascade
         if per_cascade:
             bucket = self.optim_R.bucket()
             ranges = self._cascade_ranges(bucket)
@@ -234,11 +259,6 @@ class CSModel(BaseModel):
         finally:
             self.net_R._grad_hook = None
             self.net_R.__dict__.pop("_sens_async", None)
-        if exch is not None and not per_cascade:
-            # net_R's gradients are final (its deferred weight-gradient reductions are flushed here): their all-reduce
-            # starts now, on the communication stream, and hides behind the alignment network's backward
-            ops.wgrad_flush()
-            exch.launch(self.optim_R.bucket(), after=(ops._WG["stream"], self.net_R.__dict__.get("_sens_bwd_stream")))
         if not train_T:
             return
         off = self.net_T._last_offset_nchw
@@ -263,14 +283,10 @@ class CSModel(BaseModel):
                     self._auto_make(st)
                 except Exception as e:              # the step cannot be recorded (a stray torch operation, ...): stay eager
                     err = f"{type(e).__name__}: {e}"
-                dist = _active_dist()
-                if dist is not None:
-                    # every rank replays or every rank stays eager: a replay and an eager step issue the same collectives, but a
-                    # rank that failed half-way must not be left alone with the others' next exchange
-                    flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=self.device)
-                    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                    if int(flag.item()) and err is None:
-                        err = "another rank could not record the step"
+                # every rank replays or every rank stays eager: a replay and an eager step issue the same collectives, but a
+                # rank that failed half-way must not be left alone with the others' next exchange
+                from . import dist as sdist
+                err = sdist.agree_on_failure(err, _active_dist(), self.device)
                 if err is not None:
                     st.update(step=None, full=None, aux=None, attrs=None, failed=err)
                     import warnings
@@ -279,6 +295,7 @@ class CSModel(BaseModel):
                 return self._auto_replay(st)
             st["seen"] += 1
         self.step_mode = "eager"
+        self._materialize_input()
         return self._update_eager()
 
     @_own_arena
@@ -301,7 +318,7 @@ class CSModel(BaseModel):
                tuple(p.requires_grad for o in (self.optim_R, self.optim_T) for p in o._params()),
                tuple(o.bucket().flat_p.data_ptr() for o in (self.optim_R, self.optim_T)), pr.data_ptr(), pr._version,
                ops.F16_FWD[0], ops.F16_BWD[0], ops.USE_BF16X3[0], ops.WGRAD_OVERLAP[0], ops.WGRAD_DEFER[0], SENS_OVERLAP[0],
-               bool(getattr(self, "time_exchange", False)),
+               bool(getattr(self, "time_exchange", False)), os.environ.get("SAN_GRAD_EXCHANGE", "allreduce"),
                # baked into the recording as host-side arguments: the low-frequency count of the sensitivity estimate, AdamW's
                # betas / eps (lr, weight decay and the step count live in device memory: sync_hyper)
                float(self.cfg.sparsity), int(self.cfg.shape),
@@ -327,6 +344,7 @@ class CSModel(BaseModel):
         st["attrs"] = {k: v for k, v in self.__dict__.items() if k.startswith(("img_", "loss_", "metric_")) and k != "loss_all"}
 
     def _auto_replay(self, st) -> None:
+        self._input_pending = False                     # (the replay's own prologue produces every img_* attribute)
         if self.img_full is not st["full"]:
             _lib.rec(st["full"].copy_, self.img_full)
         if self.img_aux is not st["aux"]:
@@ -387,6 +405,8 @@ class CSModel(BaseModel):
                 self.exchange_slices = list(exch.launched)      # what went out, in order (None = a whole buffer): tests, bench
                 if exch.events:
                     self._exchange_events = getattr(self, "_exchange_events", []) + exch.events
+                if exch.wait_events:
+                    self._exchange_wait_events = getattr(self, "_exchange_wait_events", []) + exch.wait_events
                 self._exchange = None
             scale = 1.0 / dist.get_world_size() if dist is not None else 1.0   # the 1/world factor rides in the optimiser kernel
             for o in opts:
@@ -407,6 +427,15 @@ class CSModel(BaseModel):
         ms = float(sum(e0.elapsed_time(e1) for e0, e1 in ev))
         if reset:
             self._exchange_events = []
+        return ms
+
+    def exchange_exposed_ms(self, reset: bool = True) -> float:
+        """How long the main stream waited for the gradient exchange at its join since the last call (``time_exchange = True``;
+        synchronise first): the part of ``exchange_ms`` the backward pass did NOT hide."""
+        ev = getattr(self, "_exchange_wait_events", [])
+        ms = float(sum(e0.elapsed_time(e1) for e0, e1 in ev))
+        if reset:
+            self._exchange_wait_events = []
         return ms
 
     @_no_auto
@@ -526,6 +555,7 @@ class CSModel(BaseModel):
                 run()
             torch.cuda.synchronize()
             self._exchange_events = []           # (only the recorded step's exchange events are kept)
+            self._exchange_wait_events = []
             step = self._record(run, "record_update", timer)
         finally:
             # ALSO when the warm-up or the recording raised (a stray torch operation, out of memory): the caller falls back to
@@ -705,6 +735,7 @@ class CSModel(BaseModel):
     def get_vis(self, content=None):
         """model.py:292-321."""
         assert content in [None, "scalars", "histograms", "images"]
+        self._materialize_input()                       # (a set_input whose derived images a replay has not produced yet)
         vis = {}
         if content in (None, "scalars"):
             vis["scalars"] = {}

@@ -497,7 +497,8 @@ def dc_rows(x: torch.Tensor, sens: torch.Tensor, k0x: Optional[torch.Tensor], ma
 
 
 def dc_rows_bwd(g: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, dc_w: torch.Tensor, g_out: torch.Tensor,
-                h_out: torch.Tensor, dk: torch.Tensor, dcw_grad: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                h_out: torch.Tensor, dk: torch.Tensor, dcw_grad: Optional[torch.Tensor] = None,
+                defer_dcw: bool = False) -> Optional[torch.Tensor]:
     """Backward form: g_out = g - dc_w ifft_x(mask fft_x(g)); h_out = -sum_c conj(S_c) g_c (planar: the gradient wrt the
     regulariser output); dL/d(dc_w) = - (fixed-order sum of the per-workgroup partials): added to ``dcw_grad`` (a 1-element
     fp32 tensor) on the device, or returned as a 0-d tensor."""
@@ -509,11 +510,18 @@ def dc_rows_bwd(g: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, dc_w: t
     # the adjoint launch does the forward boundary's work on the gradient: same SURVEY 8(d) count, its own family
     _timed("fft_dc_bwd", float((6 * c + 2) * n * h * w * 8), "B", lambda: lib().call("san_dc_rows", *bargs),
            float((5 * c + 2) * n * h * w * 8))
+    if defer_dcw:
+        return part                             # the caller adds -sum(part) to dc_weight's gradient later (normunet_bwd_tail)
     if dcw_grad is not None:
-        assert dcw_grad.numel() == 1 and dcw_grad.dtype == torch.float32 and dcw_grad.is_contiguous()
-        lib().call("san_partials_add", _p(part), int(part.numel()), -1.0, _p(dcw_grad), _stream())
+        partials_add(part, -1.0, dcw_grad)
         return None
     return -(part.double().sum()).float()
+
+
+def partials_add(part: torch.Tensor, scale: float, dst: torch.Tensor) -> None:
+    """dst[0] += scale * sum(part): fixed-order double accumulation on the device (san_partials_add)."""
+    assert dst.numel() == 1 and dst.dtype == torch.float32 and dst.is_contiguous()
+    lib().call("san_partials_add", _p(part), int(part.numel()), float(scale), _p(dst), _stream())
 
 
 def sens_grad_prop(gS: Optional[torch.Tensor], r_planar: torch.Tensor, t1: torch.Tensor, x: torch.Tensor, gm_planar: torch.Tensor,
@@ -1774,6 +1782,42 @@ def normunet_bwd_coefs(part_b: torch.Tensor, part_a: torch.Tensor, xin: Act, std
     lib().call("san_normunet_bwd_coefs", _p(part_b), _p(part_a), int(part_b.shape[2]), _p(xin.scale), _p(xin.shift), xin.ctot,
                _p(_chk(std, name="std")), float(nel), _p(a_sc), _p(a_sh), g_ctot, _p(m_sc), _p(m_sh), b, _stream())
     return a_sc, a_sh, m_sc, m_sh
+
+
+def normunet_bwd_head(g_out: torch.Tensor, out_planar: torch.Tensor, isd: torch.Tensor, nshift: torch.Tensor, std: torch.Tensor,
+                      g_u: torch.Tensor, arena: Arena = GLOBAL_ARENA, tag: str = "nu.b") -> torch.Tensor:
+    """NormUnet backward, first launch (san_normunet_bwd_head): g_u = g_out * std and the chunk sums part_b [b, 2, tiles, 2] of
+    (g_out, g_out * U) that plane_dot_part would give -- one pass instead of plane_dot_part + apply (+ plane_stats + the bias
+    gradient kernel: the tail launch takes the last convolution's bias gradient from part_b)."""
+    b, two, h, w = g_out.shape
+    assert two == 2 and out_planar.shape == g_out.shape and g_u.shape == g_out.shape
+    hw = h * w
+    part = arena.get("pdot" + tag, (b, 2, lib().query("san_bwd_stat_tiles", hw), 2), g_out.device)
+    lib().call("san_normunet_bwd_head", _p(_chk(g_out, name="g_out")), _p(_chk(out_planar, name="out")), _p(_chk(isd, name="isd")),
+               _p(_chk(nshift, name="nshift")), _p(_chk(std, name="std")), _p(_chk(g_u, name="g_u")), _p(part), b, hw, _stream())
+    return part
+
+
+def normunet_bwd_tail(part_b: torch.Tensor, part_x: torch.Tensor, xin: Act, std: torch.Tensor, nel: int, g_xh: torch.Tensor,
+                      gd: torch.Tensor, sens: torch.Tensor, gS: Optional[torch.Tensor], r_planar: Optional[torch.Tensor],
+                      t1: Optional[torch.Tensor], xs: Optional[torch.Tensor], sign1: float, g_ref: Optional[torch.Tensor],
+                      ref_accumulate: bool, db: Optional[torch.Tensor], dcw_part: Optional[torch.Tensor], dcw_scale: float,
+                      dcw: Optional[torch.Tensor]) -> None:
+    """NormUnet backward, last launch (san_normunet_bwd_tail): the affines of dL/dm, gd += g_m * S (g_m never stored), the
+    sensitivity-map accumulation, the reference channel's gradient, the last convolution's bias gradient and dc_weight's."""
+    n, c, h, w = gd.shape
+    xc = int(part_x.shape[1])
+    assert xin.coff == 0 and tuple(part_b.shape[:2]) == (n, 2) and part_x.shape[0] == n and part_x.shape[2] == part_b.shape[2]
+    assert g_xh.shape[0] == n and tuple(g_xh.shape[2:]) == (h, w) and tuple(xin.buf.shape[2:]) == (h, w)
+    if gS is not None:
+        assert r_planar is not None and t1 is not None and xs is not None
+    lib().call("san_normunet_bwd_tail", _p(part_b), _p(part_x), xc, _p(xin.buf), xin.ctot, _p(xin.scale), _p(xin.shift),
+               _p(_chk(std, name="std")), float(nel), _p(_chk(g_xh, name="g_xh")), int(g_xh.shape[1]), _p(_creal(gd, "gd")),
+               _p(_creal(sens, "sens")), _p(None if gS is None else _creal(gS, "gS")),
+               _p(None if gS is None else _chk(r_planar, name="r")), _p(None if gS is None else _creal(t1, "t1")),
+               _p(None if gS is None else _creal(xs, "x")), float(sign1), _p(None if g_ref is None else _chk(g_ref, name="g_ref")),
+               int(ref_accumulate), _p(None if db is None else _chk(db, name="db")), _p(dcw_part),
+               0 if dcw_part is None else int(dcw_part.numel()), float(dcw_scale), _p(dcw), n, c, h * w, _stream())
 
 
 def dc_weight_grad(G: torch.Tensor, k: torch.Tensor, k0: torch.Tensor, mask_f: torch.Tensor) -> torch.Tensor:

@@ -27,6 +27,9 @@ from .ops import Act, GLOBAL_ARENA as ARENA
 from .signal_utils import rss as _rss  # noqa: F401  (API parity: reference imports these names here)
 
 IN_EPS = 1e-5
+# NormUnet's backward as head + U-Net + tail launches inside a cascade (round 6; SAN_FUSED_NU_BWD=0: the separate launches)
+import os as _os
+FUSED_NU_BWD = [_os.environ.get("SAN_FUSED_NU_BWD", "1") != "0"]
 
 
 class ConvBlock(nn.Module):
@@ -261,10 +264,14 @@ class Unet(nn.Module):
         self._tapes[key] = tape
         return out
 
-    def run_bwd(self, g_conv: torch.Tensor, key: str = "unet") -> torch.Tensor:
+    def run_bwd(self, g_conv: torch.Tensor, key: str = "unet", bias_grad: bool = True,
+                input_grad: bool = True) -> Optional[torch.Tensor]:
         """Backward of the last ``run(..., key=key)``.  g_conv [N, out_chans, H, W] is the gradient
         wrt the final 1x1 conv's output BEFORE the optional output affine.  Accumulates every
-        parameter gradient and returns dL/d(T(x)) [N, in_chans, H, W] for the lazily read input."""
+        parameter gradient and returns dL/d(T(x)) [N, in_chans, H, W] for the lazily read input.
+        bias_grad=False: the caller adds the last convolution's bias gradient itself (NormUnet's fused tail);
+        input_grad=False: nobody reads dL/d(input) (the sensitivity network's input is data): the first convolution's data
+        gradient is not computed and None is returned."""
         tape = self._tapes[key]
         P = self.num_pool_layers
         x = tape["x"]
@@ -273,7 +280,8 @@ class Unet(nn.Module):
         cur = tape["last_in"]
         gc = ops.full(g_conv.contiguous())
         # final 1x1 conv (+bias): bias gradient = plane sums of g
-        ops.bias_grad_acc(ops.plane_stats(gc, tag="bgrad"), _grad_of(last.bias))
+        if bias_grad:
+            ops.bias_grad_acc(ops.plane_stats(gc, tag="bgrad"), _grad_of(last.bias))
         ops.conv2d_wgrad(cur, gc, _grad_of(last.weight), accumulate=True)
         g = Act(ARENA.get(f"bwd.g.{cur.c}.{cur.h}.{cur.w}", (n, cur.c, cur.h, cur.w), dev), 0, cur.c)
         ops.conv2d_dgrad(gc, last.weight, g)
@@ -300,8 +308,9 @@ class Unet(nn.Module):
             bin_, bmid_, bout = tape["blocks"][i]
             ch = bout.c
             # avg-pool backward (x0.25, nearest up-sampling) + the skip connection's gradient
+            want_in = input_grad or i > 0
             if ops.act_bwd_up_ok(bout):                      # summed inside the block's first activation-backward kernel
-                g_next = Act(ARENA.get(f"bwd.gp.{bin_.c}.{bin_.h}.{bin_.w}", (n, bin_.c, bin_.h, bin_.w), dev), 0, bin_.c)
+                g_next = Act(ARENA.get(f"bwd.gp.{bin_.c}.{bin_.h}.{bin_.w}", (n, bin_.c, bin_.h, bin_.w), dev), 0, bin_.c) if want_in else None
                 self.down_sample_layers[i].run_bwd(skip_g[i], bin_, bmid_, bout, g_next, g_pooled=Act(g_pool.buf, 0, ch))
                 g_pool = g_next
                 continue
@@ -314,9 +323,9 @@ class Unet(nn.Module):
             else:
                 ops.upsample2(Act(g_pool.buf, 0, ch, sc, sh, 1.0), up)
             ops.add(up, skip_g[i], up)
-            g_pool = Act(ARENA.get(f"bwd.gp.{bin_.c}.{bin_.h}.{bin_.w}", (n, bin_.c, bin_.h, bin_.w), dev), 0, bin_.c)
+            g_pool = Act(ARENA.get(f"bwd.gp.{bin_.c}.{bin_.h}.{bin_.w}", (n, bin_.c, bin_.h, bin_.w), dev), 0, bin_.c) if want_in else None
             self.down_sample_layers[i].run_bwd(up, bin_, bmid_, bout, g_pool)
-        return g_pool.buf
+        return g_pool.buf if g_pool is not None else None
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         assert not torch.is_complex(image)
@@ -387,10 +396,15 @@ class NormUnet(nn.Module):
         self._tapes[key] = (xin, out_planar, std, mean, std2[1], mean2[1])
         return out_planar
 
-    def run_bwd(self, g_out: torch.Tensor, key: str, want_ref_grad: bool = False, g_ref_acc: Optional[torch.Tensor] = None):
+    def run_bwd(self, g_out: torch.Tensor, key: str, want_ref_grad: bool = False, g_ref_acc: Optional[torch.Tensor] = None,
+                input_grad: bool = True, fuse: Optional[dict] = None):
         """Backward of the last run(key).  g_out: dL/d(output) planar [B,2,H,W].  g_ref_acc: a tensor dL/d(ref) is ADDED to
         (then also the returned one).  Returns
         (dL/d(input planar) [B,2,H,W], dL/d(ref) [B,1,H,W] or None); parameter gradients accumulate.
+        input_grad=False: the input is data (the sensitivity network): (None, None) is returned and nothing input-side is computed.
+        fuse (VarNetBlock.run_bwd_img): dict(gd, sens, gS, r, t1, xs, dcw=(partials, grad)) -- what the caller would do with
+        dL/d(input) next (gd += g_m S, the sensitivity-map accumulation) and dc_weight's pending gradient partials: done by the
+        LAST launch of this backward (ops.normunet_bwd_tail) without storing g_m; the first value returned is then None.
 
         With x^ = (m - mu)/(sigma + eps) (sigma = unbiased std of the plane), U = unet(x^, ref^) and
         out = U*sigma + mu:
@@ -402,28 +416,54 @@ class NormUnet(nn.Module):
         b, h, w, dev = xin.n, xin.h, xin.w, xin.buf.device
         nel = h * w
         g_out = g_out.contiguous()
+        top, left, hp, wp = self.pad_sizes(h, w)
+        padded = (hp, wp) != (h, w)
+        fused = fuse is not None and not padded and FUSED_NU_BWD[0]
+        zero_sh = ARENA.get("bwd.zero_sh", tuple(std.shape), dev, zero=True)
         # a constant plane (e.g. an all-zero slice) has std == 0: U cannot be recovered from U*0 + mean, and torch's
         # std backward gives that plane no d sigma term at all (isd = 0 there, written by the forward's finalisation;
         # san_normunet_bwd_coefs does the same)
-        part_b = ops.plane_dot_part(ops.full(g_out), Act(out_planar, 0, 2, isd, nshift, 1.0), "nu.b")
-        zero_sh = ARENA.get("bwd.zero_sh", tuple(std.shape), dev, zero=True)
-        top, left, hp, wp = self.pad_sizes(h, w)
-        if (hp, wp) == (h, w):
+        part_b = None
+        if fused:
             g_u = ops.wgrad_dy_buffer("bwd.g_u", (b, 2, h, w), dev, ARENA)
-            ops.apply(Act(g_out, 0, 2, std, zero_sh, 1.0), ops.full(g_u))
-            g_xh = self.unet.run_bwd(g_u, key)                     # [B, 2 or 3, H, W]
+            part_b = ops.normunet_bwd_head(g_out, out_planar, isd, nshift, std, g_u)      # one pass: g_u and the chunk sums
+            g_xh = self.unet.run_bwd(g_u, key, bias_grad=False)                          # [B, 2 or 3, H, W]
         else:
-            g_u = ops.wgrad_dy_buffer("bwd.g_u", (b, 2, hp, wp), dev, ARENA)
-            ops.window_copy(Act(g_out, 0, 2, std, zero_sh, 1.0), ops.full(g_u), top, left)     # adjoint of the crop
-            g_pad = self.unet.run_bwd(g_u, key)
-            g_xh = ARENA.get("bwd.g_xh_crop", (b, xin.c, h, w), dev)
-            ops.window_copy(ops.full(g_pad), ops.full(g_xh), -top, -left)                      # adjoint of the zero pad
+            if input_grad:
+                part_b = ops.plane_dot_part(ops.full(g_out), Act(out_planar, 0, 2, isd, nshift, 1.0), "nu.b")
+            if not padded:
+                g_u = ops.wgrad_dy_buffer("bwd.g_u", (b, 2, h, w), dev, ARENA)
+                ops.apply(Act(g_out, 0, 2, std, zero_sh, 1.0), ops.full(g_u))
+                g_xh = self.unet.run_bwd(g_u, key, input_grad=input_grad)
+            else:
+                g_u = ops.wgrad_dy_buffer("bwd.g_u", (b, 2, hp, wp), dev, ARENA)
+                ops.window_copy(Act(g_out, 0, 2, std, zero_sh, 1.0), ops.full(g_u), top, left)     # adjoint of the crop
+                g_pad = self.unet.run_bwd(g_u, key, input_grad=input_grad)
+                if input_grad:
+                    g_xh = ARENA.get("bwd.g_xh_crop", (b, xin.c, h, w), dev)
+                    ops.window_copy(ops.full(g_pad), ops.full(g_xh), -top, -left)                  # adjoint of the zero pad
+        if not input_grad:
+            assert fuse is None and not want_ref_grad
+            return None, None
+        ref = self.use_ref and want_ref_grad
+        if fused:
+            g_ref = None
+            if ref:
+                g_ref = g_ref_acc if g_ref_acc is not None else torch.empty((b, 1, h, w), device=dev)
+            xc = 3 if ref else 2
+            part_x = ops.plane_dot_part(Act(g_xh, 0, xc), xin.view(0, xc), "nu.a")
+            last = self.unet.up_conv[self.unet.num_pool_layers - 1][1]
+            dcw_part, dcw_grad = fuse.get("dcw") or (None, None)
+            ops.normunet_bwd_tail(part_b, part_x, xin, std, nel, g_xh, fuse["gd"], fuse["sens"], fuse.get("gS"), fuse.get("r"),
+                                  fuse.get("t1"), fuse.get("xs"), -1.0, g_ref, ref and g_ref_acc is not None, _grad_of(last.bias),
+                                  dcw_part, -1.0, dcw_grad)
+            return None, g_ref
         part_a = ops.plane_dot_part(Act(g_xh, 0, 2), xin.view(0, 2), "nu.a")
         a_sc, a_sh, m_sc, m_sh = ops.normunet_bwd_coefs(part_b, part_a, xin, std, nel, g_xh.shape[1])
         g_m = torch.empty((b, 2, h, w), device=dev)
         ops.add(Act(g_xh, 0, 2, a_sc, a_sh, 1.0), Act(xin.buf, xin.coff, 2, m_sc, m_sh, 1.0), ops.full(g_m))
         g_ref = None
-        if self.use_ref and want_ref_grad:
+        if ref:
             if g_ref_acc is not None:
                 # dL/d ref is the sum over the cascades (every cascade reads the same ref): accumulated in place by the kernel
                 g_ref = g_ref_acc
@@ -431,6 +471,11 @@ class NormUnet(nn.Module):
             else:
                 g_ref = torch.empty((b, 1, h, w), device=dev)
                 ops.act_bwd(Act(g_xh, 2, 1), xin.view(2, 1), ops.full(g_ref), instance_norm=True)
+        if fuse is not None:                    # (the padded form: what the fused tail would have done, as separate launches)
+            ops.sens_grad_prop(fuse.get("gS"), fuse.get("r"), fuse.get("t1"), fuse.get("xs"), g_m, fuse["gd"], fuse["sens"])
+            if fuse.get("dcw"):
+                ops.partials_add(fuse["dcw"][0], -1.0, fuse["dcw"][1])
+            return None, g_ref
         return g_m, g_ref
 
     # -- reference-compatible entry --------------------------------------
@@ -488,7 +533,7 @@ class SensitivityModel(nn.Module):
         """dL/d(sens maps) -> parameter gradients (the masked k-space input needs none)."""
         est, n, c = self._tape
         g_est = ops.sens_normalize_bwd(est, g_sens)
-        self.norm_unet.run_bwd(g_est, "sens", want_ref_grad=False)
+        self.norm_unet.run_bwd(g_est, "sens", want_ref_grad=False, input_grad=False)     # (the masked k-space is data)
 
 
 _ACS_CACHE = {}
@@ -593,9 +638,11 @@ class VarNetBlock(nn.Module):
         dev = x.device
         g_r = ARENA.get("bwd.g_r", (n, 2, h, w), dev)
         g_d = torch.empty_like(g_xout)
-        ops.dc_rows_bwd(g_xout, sens, mask_f, self.dc_weight, g_d, g_r, self._dk, dcw_grad=_grad_of(self.dc_weight))
-        g_m, g_ref = self.model.run_bwd(g_r, key, want_ref_grad, g_ref_acc)
-        ops.sens_grad_prop(g_sens, r, g_xout, x, g_m, g_d, sens)
+        # dc_weight's gradient partials, the regulariser-input gradient's way into g_d and the sensitivity-map accumulation
+        # ride in the LAST launch of the regulariser's backward (NormUnet.run_bwd, fuse=)
+        part = ops.dc_rows_bwd(g_xout, sens, mask_f, self.dc_weight, g_d, g_r, self._dk, defer_dcw=True)
+        _, g_ref = self.model.run_bwd(g_r, key, want_ref_grad, g_ref_acc,
+                                      fuse=dict(gd=g_d, sens=sens, gS=g_sens, r=r, t1=g_xout, xs=x, dcw=(part, _grad_of(self.dc_weight))))
         return g_d, g_ref
 
     def forward(self, current_kspace: torch.Tensor, ref_kspace: torch.Tensor, mask: torch.Tensor,

@@ -283,3 +283,88 @@ def test_per_cascade_buckets_match_the_single_buffer_world2():
         # the sensitivity net comes first in parameter order, the cascades follow in order
         assert ranges["sens"][0] == 0 and ranges[0][0] == ranges["sens"][1] and ranges[2][1] == total
     assert torch.equal(out[0][0], out[1][0])
+
+
+# ------------------------------------------------------------------ round 6: more than two ranks (gloo, CPU)
+def _many_ranks_worker(rank, world, port, out):
+    """What a data-parallel job does around its first step, on `world` CPU ranks: every rank builds its OWN randomly initialised
+    CSModel (different seeds), sync_replicas() makes them rank 0's, the per-cascade gradient exchange sums rank-dependent
+    gradients slice by slice in the order VarNet.backward releases them, and the ranks agree on whether a recording failed."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = sdist.init("gloo")
+    from spatialalignmentnetwork_amd import basemodel, model
+    torch.manual_seed(1000 + rank)
+    cfg = basemodel.Config(sparsity=0.25, lr=1e-4, shape=32, coils=1, reg="Rec", mask="equispaced", weight_smooth=1000.0,
+                           weight_gan=0.0, weight_gan_sim=0.0, weight_sim=1.0, use_amp=False, num_cascades=3, chans=4,
+                           sens_chans=2, pools=1, sens_pools=1)
+    net = model.CSModel(cfg)
+    bR, bT = net.optim_R.bucket(), net.optim_T.bucket()
+    bR.exp_avg.fill_(float(rank))                       # (moments, step counts and BatchNorm buffers travel too)
+    bR.steps = 7 * rank
+    for buf in net.net_T.buffers():
+        if buf.dtype.is_floating_point:
+            buf.add_(rank)
+    before = bR.flat_p.clone()
+    net.sync_replicas(d)
+    state = torch.cat([bR.flat_p, bT.flat_p, bR.exp_avg, net.net_mask.weight.data.float().reshape(-1),
+                       net.net_mask.pruned.float().reshape(-1)] + [b.float().reshape(-1) for b in net.net_T.buffers()])
+    # the exchange: rank-dependent gradients, per cascade in reverse order, then the sensitivity net's slice, then net_T's buffer
+    ranges = net._cascade_ranges(bR)
+    gen = torch.Generator().manual_seed(500 + rank)
+    bR.flat.copy_(torch.randn(bR.total, generator=gen))
+    bT.flat.copy_(torch.randn(bT.total, generator=gen))
+    exch = sdist.GradExchange(d)
+    for which in [2, 1, 0, "sens"]:
+        exch.launch(bR, rng=ranges[which])
+    exch.launch(bT)
+    exch.wait()
+    # agreement on a failed recording: nobody failed -> None everywhere; the LAST rank failed -> a message everywhere
+    ok_all = sdist.agree_on_failure(None, d, "cpu")
+    one_bad = sdist.agree_on_failure("boom" if rank == world - 1 else None, d, "cpu")
+    out[rank] = (state, bR.steps, bR.flat.clone(), bT.flat.clone(), list(exch.launched), ranges, ok_all, one_bad,
+                 bool(torch.equal(before, bR.flat_p)), sdist.gather_over_ranks(10.0 + rank, d))
+    sdist.shutdown()
+    d.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_replica_sync_per_cascade_exchange_and_agreement_on_many_ranks(world):
+    """gloo world-4 and world-8 (world 2 above): after sync_replicas every rank holds rank 0's parameters,
+    moments, step count, mask and BatchNorm buffers; the per-cascade slices partition net_R's flat buffer and every rank ends
+    with the same bits, equal to the float64 sum of all ranks' gradients to fp32 rounding; agree_on_failure gives every rank
+    the same verdict; gather_over_ranks returns the per-rank values in rank order."""
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_many_ranks_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    state0, steps0 = out[0][0], out[0][1]
+    assert steps0 == 0 and out[0][8]                     # rank 0 keeps its own state
+    wantR = wantT = None
+    for r in range(world):
+        gen = torch.Generator().manual_seed(500 + r)
+        gR = torch.randn(out[0][2].numel(), generator=gen).double()
+        gT = torch.randn(out[0][3].numel(), generator=gen).double()
+        wantR = gR if wantR is None else wantR + gR
+        wantT = gT if wantT is None else wantT + gT
+    for r in range(world):
+        state, steps, fR, fT, launched, ranges, ok_all, one_bad, unchanged, gathered = out[r]
+        assert torch.equal(state, state0) and steps == steps0
+        assert r == 0 or not unchanged                   # (the other ranks really started from different weights)
+        assert torch.equal(fR, out[0][2]) and torch.equal(fT, out[0][3])       # every rank ends with the same bits
+        assert (fR.double() - wantR).abs().max().item() < 1e-5 and (fT.double() - wantT).abs().max().item() < 1e-5
+        assert launched == [ranges[2], ranges[1], ranges[0], ranges["sens"], None]
+        spans = sorted(x for x in launched if x is not None)
+        assert spans[0][0] == 0 and spans[-1][1] == fR.numel() and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert ok_all is None and isinstance(one_bad, str)
+        assert one_bad == ("boom" if r == world - 1 else "another rank could not record the step")
+        assert gathered == [10.0 + k for k in range(world)]
+
+
+def test_exchange_mode_switch_is_validated(monkeypatch):
+    monkeypatch.setenv("SAN_GRAD_EXCHANGE", "rs_ag")
+    assert sdist.exchange_mode() == "rs_ag"
+    monkeypatch.setenv("SAN_GRAD_EXCHANGE", "ring")
+    with pytest.raises(ValueError):
+        sdist.exchange_mode()
+    monkeypatch.delenv("SAN_GRAD_EXCHANGE")
+    assert sdist.exchange_mode() == "allreduce"

@@ -217,11 +217,14 @@ def test_bench_launcher_runs_the_exchange_on_rccl_with_one_rank():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
            "--main-only", "--no-kernel-timer", "--digest"]
 
-    def run(single):
+    def run(single, mode=None):
         env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
         env.pop("SAN_DIST_SINGLE", None)
+        env.pop("SAN_GRAD_EXCHANGE", None)
         if single:
             env["SAN_DIST_SINGLE"] = "1"
+        if mode:
+            env["SAN_GRAD_EXCHANGE"] = mode
         r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -237,6 +240,16 @@ def test_bench_launcher_runs_the_exchange_on_rccl_with_one_rank():
     assert single["config"]["native_rccl"] is True, single["config"]["native_rccl_note"]     # the all-reduces are C-ABI tape entries
     assert single["optimizer_steps"] == plain["optimizer_steps"] >= 4
     assert single["state_digest"] == plain["state_digest"]
+    # round 6: the line explains the exchange per rank (collectives' time, what the main stream waited for at the join, the rest hidden)
+    ex = single["exchange"]
+    assert ex["mode"] == "allreduce" and ex["slices_per_step"] == 14           # 12 cascades + the sensitivity net + net_T's buffer
+    assert len(ex["collective_ms_per_rank"]) == len(ex["exposed_ms_per_rank"]) == len(ex["hidden_ms_per_rank"]) == 1
+    assert 0.0 <= ex["exposed_ms_per_rank"][0] and ex["collective_ms_per_rank"][0] == pytest.approx(single["allreduce_ms"])
+    # the reduce-scatter + all-gather form of the same sums (SAN_GRAD_EXCHANGE=rs_ag: ncclReduceScatter / ncclAllGather entry points
+    # on the package's communicator): with one rank both are copies in place, so the parameters must again be bit-identical
+    rsag = run(True, "rs_ag")
+    assert rsag["exchange"]["mode"] == "rs_ag" and rsag["config"]["native_rccl"] is True
+    assert rsag["state_digest"] == plain["state_digest"] and rsag["optimizer_steps"] == plain["optimizer_steps"]
 
 
 # ----------------------------------------------------------------- round-5 kernels: direct small-channel convolution, one-stage GEMM
