@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "san_common.h"
+#include "san_fin.h"
 
 namespace {
 
@@ -263,13 +264,9 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
                         // the 4 virtual channels of a real channel are 4 interleaved slot sequences of its plane
                         float* dst = a.part + ((size_t)(n * (a.cout >> 2) + (co >> 2)) * (a.slots * 4) + (co & 3)) * 3;
                         float* o = dst + (size_t)pt * 12;
-                        o[0] = cnt;
-                        o[1] = pilot + s1 * inv;
-                        o[2] = fmaxf(s2 - s1 * s1 * inv, 0.f);
-                        for (int s = pt + ptiles; s < a.slots; s += ptiles) {   // unused slots: empty records
-                            float* z = dst + (size_t)s * 12;
-                            z[0] = z[1] = z[2] = 0.f;
-                        }
+                        san_stat_store(o, cnt, pilot + s1 * inv, fmaxf(s2 - s1 * s1 * inv, 0.f), a.fin.ticket != nullptr);
+                        for (int s = pt + ptiles; s < a.slots; s += ptiles)     // unused slots: empty records
+                            san_stat_store(dst + (size_t)s * 12, 0.f, 0.f, 0.f, a.fin.ticket != nullptr);
                     }
                 }
         }
@@ -336,13 +333,9 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
                 if (kg == 0 && co < a.cout) {
                     float* dst = a.part + (size_t)(n * a.cout + co) * a.slots * 3;
                     float* o = dst + (size_t)pt * 3;
-                    o[0] = cnt;
-                    o[1] = pilot + s1 * inv;
-                    o[2] = fmaxf(s2 - s1 * s1 * inv, 0.f);
-                    for (int s = pt + ptiles; s < a.slots; s += ptiles) {       // unused slots: empty records
-                        float* z = dst + (size_t)s * 3;
-                        z[0] = z[1] = z[2] = 0.f;
-                    }
+                    san_stat_store(o, cnt, pilot + s1 * inv, fmaxf(s2 - s1 * s1 * inv, 0.f), a.fin.ticket != nullptr);
+                    for (int s = pt + ptiles; s < a.slots; s += ptiles)         // unused slots: empty records
+                        san_stat_store(dst + (size_t)s * 3, 0.f, 0.f, 0.f, a.fin.ticket != nullptr);
                 }
             }
         }
@@ -365,6 +358,10 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
             }
         }
     }
+    // in-kernel InstanceNorm finalisation: the last workgroup of a sample merges its records (san_fin.h); a transposed convolution's
+    // real channel owns the 4 interleaved slot sequences of its virtual channels
+    if (a.part && a.fin.ticket)
+        san_fin_tail<kT>(a.fin, a.part, a.N, SHUFFLE ? a.cout >> 2 : a.cout, SHUFFLE ? a.slots * 4 : a.slots, n, 1u);
 }
 
 // SAN_CONV1X1_GEMM=0 in the environment: off from the start (same-box A/B of whole steps)
@@ -412,6 +409,7 @@ int san_gemm1x1_f16_run(SanGemm1x1Args a, void* stream) {
         san_set_error("1x1 GEMM: %d channel blocks in the packed image, %d wanted", a.nblkp, a.ngrp * 4 * NGW);
         return SAN_E_ARG;
     }
+    if (a.fin.ticket) a.fin.expected = (unsigned)(a.ptiles * a.ngrp * (a.fin.batch ? a.N : 1));      // one arrival per workgroup
     if (a.part && a.slots < a.ptiles) {
         san_set_error("1x1 GEMM: %d statistics slots for %d pixel tiles", a.slots, a.ptiles);
         return SAN_E_ARG;

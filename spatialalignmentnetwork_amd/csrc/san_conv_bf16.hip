@@ -25,6 +25,7 @@
 // 7 K-steps of 4 groups (one zero group of padding).  In the weights-direct form (WD, MB <= 4) the weights skip
 // LDS and are read by the K-steps straight from L2, which leaves room for three workgroups per CU.
 #include "san_common.h"
+#include "san_fin.h"
 
 #include <cstdint>
 #include <cstdlib>
@@ -35,7 +36,7 @@ void san_wgrad_set_parts(int parts);             // san_wgrad_bf16.hip
 // san_conv_stream.hip: the persistent form for the high-resolution few-channel layers (fp16-format weights)
 int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
                         const void* w_packed, int nblkp, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
-                        const void* amax, int n, int h, int w, void* stream, int nprt);
+                        const void* amax, int n, int h, int w, void* stream, int nprt, const SanFin* fin);
 
 // Tuning switches, both measured and left off (scratch/README.md, round 2): HALFX = the K-loop's activation operand reads run
 // half a K-step ahead (two of a wave's four pixel blocks per set: 32 operand registers fewer) -- neutral, the register peak is
@@ -111,6 +112,7 @@ struct BArgs {
                                // chunk staged, epilogue start, end; HW_ID; XCC_ID -- null in normal use
     const uint32_t* amax;      // fp16 format on a GRADIENT input: the tensor's amax record (san_common.h); the input is scaled by a power of two
     const float* f8_tail;      // fp8 format: {S_w, 1 / S_w} behind the packed image (the per-tensor power-of-two weight scale)
+    SanFin fin;                // in-kernel finalisation of the statistics (san_fin.h; ticket null: off)
 };
 
 // x / d for 0 <= x, d >= 1 with the host's multiplier m (BArgs.m_*); m == 0: plain division
@@ -679,9 +681,8 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     const int co = cb0 + 16 * m;
                     if (kg == 0 && co < a.cout) {
                         float* o = a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
-                        o[0] = cnt;
-                        o[1] = cnt > 0.f ? pilot + s1 * inv : 0.f;
-                        o[2] = cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f;
+                        san_stat_store(o, cnt, cnt > 0.f ? pilot + s1 * inv : 0.f, cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f,
+                                       a.fin.ticket != nullptr);
                     }
                 }
             }
@@ -711,6 +712,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             }
         }
         mark(3);
+        if (a.S == 1 && a.part && a.fin.ticket) san_fin_tail<kT>(a.fin, a.part, a.N, a.cout, ntile * 4, n, 1u);
         return;
     }
     // acc[m][b][r] = output channel co = (cg MB + m) 16 + 4 (lane >> 4) + r at tile pixel (trow[b], tcol[b])
@@ -789,9 +791,8 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     // transposed convolution: the 4 virtual channels of a real channel are 4 more statistics tiles
                     float* o = a.shuffle ? a.part + ((size_t)(n * (a.cout >> 2) + (co >> 2)) * (tiles * 4) + (tile * 4 + wave) * 4 + (co & 3)) * 3
                                          : a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
-                    o[0] = cnt;
-                    o[1] = cnt > 0.f ? pilot + s1 * inv : 0.f;
-                    o[2] = cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f;
+                    san_stat_store(o, cnt, cnt > 0.f ? pilot + s1 * inv : 0.f, cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f,
+                                   a.fin.ticket != nullptr);
                 }
             }
     }
@@ -813,6 +814,8 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     }
             }
         }
+        // (transposed form: a real channel's statistic = its 4 virtual channels' records, 16 per tile)
+        if (a.part && a.fin.ticket) san_fin_tail<kT>(a.fin, a.part, a.N, a.cout >> 2, ntile * 16, n, 1u);
         return;
     }
 #pragma unroll
@@ -827,6 +830,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     if (valid[b]) dst[oy[b] * W + ox[b]] = acc[m][b][r];
             }
         }
+    if (a.part && a.fin.ticket) san_fin_tail<kT>(a.fin, a.part, a.N, a.cout, ntile * 4, n, 1u);
 }
 
 // ---------------------------------------------------------------- split-K second pass
@@ -1133,6 +1137,7 @@ int pick_mb_f16(int cin, int cout, int tiles) {
 }
 
 int g_conv_np = 3;             // operand parts of the bf16 convolutions / weight gradients (san_set_conv_precision)
+int g_fin_on = (getenv("SAN_FIN_INKERNEL") && atoi(getenv("SAN_FIN_INKERNEL")) == 0) ? 0 : 1;      // in-kernel norm finalisation (san_fin.h)
 
 // Which packed weight images hold two fp16 parts (packed with mode + 16) instead of bf16 parts: recorded by the pack entry
 // points (host side), looked up by the launchers, so the convolution entry points need no format argument.
@@ -1325,7 +1330,16 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
                            float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
                            float* part_stats, int n, int h, int w, int ks, void* stream, int shuffle = 0,
                            void* ws = nullptr, size_t ws_bytes = 0, const void* amax = nullptr, float* fin_scale = nullptr,
-                           float* fin_shift = nullptr, int fin_ctot = 0, int fin_coff = 0, float fin_eps = 0.f) {
+                           float* fin_shift = nullptr, int fin_ctot = 0, int fin_coff = 0, float fin_eps = 0.f,
+                           const SanFin* fin_in = nullptr) {
+    // in-kernel finalisation (san_fin.h): the affine destination + a zeroed ticket array; returns 1 when the launch finalised
+    SanFin fin{};
+    if (fin_in && fin_in->ticket && part_stats && g_fin_on) {
+        fin = *fin_in;
+    } else if (fin_in) {
+        fin_in = nullptr;
+    }
+    const bool fin_on = fin.ticket != nullptr;
     SAN_CHECK_ARG(x && w_packed && y, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + (shuffle ? cout / 4 : cout) <= y_ctot, "bad channel view");
@@ -1347,8 +1361,10 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     const bool stream_f16 = a.fmt == 1 && g_conv_np == 3, stream_bf1 = a.fmt == 0 && g_conv_np == 1 && (cout == 18 || cout == 36);
     if (ks == 3 && (stream_f16 || stream_bf1) && !shuffle && g_b16_mb < 0 && g_b16_wd < 0 &&
         san_conv_stream_eligible(n, h, w, cin, cout, x_ctot))
+    {
         return san_conv_stream_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, p.nblkp, bias, y, y_ctot, y_coff, cout,
-                                   part_stats, a.amax, n, h, w, stream, stream_f16 ? 2 : 1);
+                                   part_stats, a.amax, n, h, w, stream, stream_f16 ? 2 : 1, fin_on ? &fin : nullptr);      // (1: finalised)
+    }
     if (ks == 1 && ((a.fmt == 1 && g_conv_np == 3) || (a.fmt == 0 && g_conv_np == 1)) && g_b16_mb < 0 && san_gemm1x1_enabled()) {
         // round 5: the whole K range staged once, no barrier between K-steps (san_conv1x1.hip)
         const TileGeom tg1 = tile_geom(h, w);
@@ -1376,7 +1392,9 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
         g.shuffle = shuffle;
         g.bf1 = a.fmt == 0 ? 1 : 0;
         g.slots = tg1.tiles_x * tg1.tiles_y * 4;
-        return san_gemm1x1_f16_run(g, stream);
+        if (fin_on) g.fin = fin;                       // (expected arrivals: filled by the launcher, which knows its grid)
+        const int rc = san_gemm1x1_f16_run(g, stream);
+        return rc == SAN_OK && fin_on ? 1 : rc;
     }
     a.dbg = g_b16_dbg;
     a.shuffle = shuffle;
@@ -1413,6 +1431,10 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
             a.S = S;
             a.ws = static_cast<float*>(ws);
         }
+    }
+    if (a.S == 1 && fin_on) {
+        a.fin = fin;
+        a.fin.expected = (unsigned)(a.tiles_x * a.tiles_y * a.cgs * (fin.batch ? a.N : 1));    // one arrival per workgroup
     }
     {
         const unsigned long long total = (unsigned long long)a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
@@ -1455,6 +1477,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
+    if (a.S == 1 && fin_on) return 1;                   // the last workgroup of every sample wrote the affine
     if (a.S > 1) {
         const TileGeom tgs = tile_geom(h, w);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(n * cout), dim3(256), 0, s, a.ws, a.S, bias, y, y_ctot, y_coff, part_stats,
@@ -1539,6 +1562,78 @@ int san_conv2d_bf16x3_fwd_ws_in(const float* x, int x_ctot, int x_coff, int cin,
                                    part_stats, n, h, w, 3, stream, 0, ws, ws_bytes, nullptr, scale, shift, sc_ctot, sc_coff, eps);
     *finalised = rc == 1 ? 1 : 0;
     return rc == 1 ? SAN_OK : rc;
+}
+
+// Forward convolution + the FINALISATION of the normalisation that follows it, in one launch (round 6, san_fin.h): the last
+// workgroup of a reduction domain merges the statistics records and writes the lazy affine -- no san_norm_finalize launch.
+// kind: 3 = 3x3 (san_conv2d_bf16x3_fwd_ws: ws / ws_bytes may be NULL / 0), 1 = 1x1 (san_conv1x1_bf16x3_fwd), 2 = transposed 2x2
+// (san_tconv2x2_bf16x3_fwd: cout = real output channels, bias must be NULL).  scale / shift: [n, sc_ctot] views at channel offset
+// sc_coff; ticket: int32 scratch of n words zeroed ONCE by the caller (left zero).  *finalised (host) = 1: the affine is written;
+// 0: this shape / mode keeps the separate launch (part_stats holds the records as usual).
+static int conv_fin_impl(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
+                         const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats, int n,
+                         int h, int w, int kind, void* ws, size_t ws_bytes, const SanFin& fin, int* finalised, void* stream) {
+    SAN_CHECK_ARG(fin.scale && fin.shift && finalised && part_stats && fin.ticket, "null pointer");
+    SAN_CHECK_ARG(kind == 1 || kind == 2 || kind == 3, "kind: 3 = 3x3, 1 = 1x1, 2 = transposed 2x2");
+    SAN_CHECK_ARG(fin.sc_coff >= 0 && fin.sc_coff + cout <= fin.sc_ctot, "bad scale/shift view");
+    SAN_CHECK_ARG(kind != 2 || bias == nullptr, "the transposed convolution has no bias");
+    int rc;
+    if (kind == 3)
+        rc = conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout, part_stats, n, h,
+                             w, 3, stream, 0, ws, ws_bytes, nullptr, fin.batch ? nullptr : fin.scale, fin.batch ? nullptr : fin.shift,
+                             fin.sc_ctot, fin.sc_coff, fin.eps, &fin);
+    else
+        rc = conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff,
+                             kind == 2 ? 4 * cout : cout, part_stats, n, h, w, 1, stream, kind == 2 ? 1 : 0, nullptr, 0, nullptr, nullptr,
+                             nullptr, 0, 0, 0.f, &fin);
+    *finalised = rc == 1 ? 1 : 0;
+    return rc == 1 ? SAN_OK : rc;
+}
+
+int san_conv_bf16x3_fwd_fin(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
+                            const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
+                            int n, int h, int w, int kind, void* ws, size_t ws_bytes, float* scale, float* shift, int sc_ctot,
+                            int sc_coff, float eps, void* ticket, int* finalised, void* stream) {
+    SanFin fin{};
+    fin.ticket = static_cast<unsigned*>(ticket);
+    fin.scale = scale;
+    fin.shift = shift;
+    fin.sc_ctot = sc_ctot;
+    fin.sc_coff = sc_coff;
+    fin.eps = eps;
+    return conv_fin_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout, part_stats, n, h, w,
+                         kind, ws, ws_bytes, fin, finalised, stream);
+}
+
+// The same for training-mode BatchNorm2d (unet.py:125; san_norm_finalize_bn's arithmetic): ONE reduction domain (all samples), the
+// affine gamma / sqrt(var_b + eps), beta - mean * that for every sample, the batch mean / unbiased variance in bmean / bvar [c] and
+// the running statistics (+ *num_batches_tracked) updated with `momentum` and `var_factor`.  ticket: one zeroed int32 word.
+int san_conv_bf16x3_fwd_fin_bn(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
+                               float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
+                               float* part_stats, int n, int h, int w, int kind, float* scale, float* shift, int sc_ctot, int sc_coff,
+                               float eps, const float* gamma, const float* beta, float* bmean, float* bvar, float* rmean, float* rvar,
+                               long long* num_batches_tracked, float momentum, float var_factor, void* ticket, int* finalised,
+                               void* stream) {
+    SAN_CHECK_ARG((rmean == nullptr) == (rvar == nullptr), "running mean / variance come together");
+    SanFin fin{};
+    fin.ticket = static_cast<unsigned*>(ticket);
+    fin.scale = scale;
+    fin.shift = shift;
+    fin.sc_ctot = sc_ctot;
+    fin.sc_coff = sc_coff;
+    fin.eps = eps;
+    fin.batch = 1;
+    fin.gamma = gamma;
+    fin.beta = beta;
+    fin.bmean = bmean;
+    fin.bvar = bvar;
+    fin.rmean = rmean;
+    fin.rvar = rvar;
+    fin.nbt = num_batches_tracked;
+    fin.momentum = momentum;
+    fin.var_factor = var_factor;
+    return conv_fin_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout, part_stats, n, h, w,
+                         kind, nullptr, 0, fin, finalised, stream);
 }
 
 // Data gradient on fp16-format weights (packed with mode 2 + 16): x = dy [n, cout_fwd, h, w] materialised, amax = device

@@ -120,12 +120,14 @@ class UNet(torch.nn.Module):
         """conv(+bias) raw into ``out`` and the lazy BatchNorm affine into out.scale/shift."""
         conv, bn = seq[conv_i], seq[conv_i + 1]
         if bn.training:
-            part = ops.conv2d(x, conv.weight, conv.bias, out, stats=True, tag=tag)
             c = conv.weight.shape[0]
             bmean = ARENA.get(f"{tag}.bmean", (c,), x.buf.device)
             bvar = ARENA.get(f"{tag}.bvar", (c,), x.buf.device)
             m, factor = _running_factors(bn, x.n * x.h * x.w, count_scale)
-            ops.norm_finalize_bn(part, BN_EPS, out.scale, out.shift, out.coff, bn, bmean, bvar, m, factor)
+            # (where the convolution can, its last workgroup finalises the batch statistics itself: None comes back)
+            part = ops.conv2d(x, conv.weight, conv.bias, out, stats=True, tag=tag, batch_norm=(BN_EPS, bn, bmean, bvar, m, factor))
+            if part is not None:
+                ops.norm_finalize_bn(part, BN_EPS, out.scale, out.shift, out.coff, bn, bmean, bvar, m, factor)
         else:
             ops.conv2d(x, conv.weight, conv.bias, out, stats=False)
             ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS,
