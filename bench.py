@@ -296,7 +296,7 @@ ROCPROF_FAMILIES = {      # KernelTimer family -> kernel-name fragments of the r
     "wgrad3x3_bf16x3": (("wgrad_bf16x3_direct_kernel<",),),
     "fft_dc": (("dc_rows320_kernel<0>",), ("dc_rows368_kernel<0>",)),
     "fft_dc_bwd": (("dc_rows320_kernel<1>",), ("dc_rows368_kernel<1>",)),
-    "act_bwd": (("act_bwd_kernel",), ("act_bwd_plane_kernel<",), ("bwd_stats_kernel",), ("act_bwd_coef_kernel",)),
+    "act_bwd": (("act_bwd_kernel",), ("act_bwd_plane_kernel<",), ("bwd_stats_kernel",), ("act_bwd_coef_kernel",), ("act_bwd_cluster_kernel<",)),
     "conv3x3": (("conv_mfma_kernel<", ", 3, "), ("conv_direct_kernel<", ", 3, ")),
 }
 
@@ -737,6 +737,21 @@ def main(argv=None):
                     ent["rocprof"] = {"avg_launch_us": us, "launches_in_profile": calls, "source": src}
                     if work:
                         ent["rocprof"]["frac"] = work / (us * 1e-6) / (1e12 if ent["unit"] == "TFLOP/s" else 1e9) / ent["peak"]
+            # The cascade-boundary entries' HEADLINE is the conservative one of the two measurements: a bracketed launch
+            # runs alone (the streams are joined around it), rocprofv3 sees it as shipped, beside the weight gradients of the side
+            # stream -- for the backward boundary that is 0.44 against 0.7.  `frac` / `achieved` / `avg_launch_us` = the slower figure;
+            # the bracket figure stays under `in_step_alone_net_of_event_pair`.
+            for fam in ("fft_dc", "fft_dc_bwd"):
+                ent = out.get("roofline" if dom == fam else "roofline_" + fam)
+                if ent is None or not ent.get("rocprof", {}).get("frac"):
+                    continue
+                ent["in_step_alone_net_of_event_pair"] = {k: ent[k] for k in ("achieved", "frac", "avg_launch_us") if k in ent}
+                if ent["rocprof"]["frac"] < ent["frac"]:
+                    ent["frac"] = ent["rocprof"]["frac"]
+                    ent["achieved"] = ent["frac"] * HBM_PEAK_GBS
+                    ent["avg_launch_us"] = ent["rocprof"]["avg_launch_us"]
+                    ent["timing"] = ("as shipped: rocprofv3 --kernel-trace --stats of this command (" + ent["rocprof"]["source"] +
+                                     "); the in-step bracket of the launch run alone is `in_step_alone_net_of_event_pair`")
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)

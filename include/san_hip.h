@@ -338,6 +338,13 @@ int san_bn_eval_affine(const float* gamma, const float* beta, const float* rmean
  */
 int san_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
                      float* y, int y_ctot, int y_coff, int n, int c, int h, int w, void* stream);
+/* InstanceNorm finalisation + 2 x 2 average pooling in ONE launch (round 6): san_norm_finalize(SAN_NORM_INSTANCE) of x's records
+ * and san_avgpool2_fwd of x read through the affine just computed -- the encoder levels' conv -> IN -> LeakyReLU -> avg_pool2d
+ * (varnet.py:95-99).  Every workgroup of a plane merges the plane's records itself (the same order and arithmetic as
+ * san_norm_finalize: identical bits), the first writes scale / shift, each pools its share.  h, w even. */
+int san_norm_finalize_pool(const float* part, int n, int c, int tiles, float eps, float* scale, float* shift, int sc_ctot, int sc_coff,
+                           const float* x, int x_ctot, int x_coff, float slope, float* y, int y_ctot, int y_coff, int h, int w,
+                           void* stream);
 int san_upsample2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
                       float* y, int y_ctot, int y_coff, int n, int c, int h, int w, void* stream);
 /* y[n, 4c+2dy+dx, i, j] = x[n, c, 2i+dy, 2j+dx]: x [n,c,2h,2w] -> y [n,4c,h,w] (h, w = OUTPUT dims).

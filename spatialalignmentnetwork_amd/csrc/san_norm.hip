@@ -204,6 +204,95 @@ __global__ void __launch_bounds__(kThreads) avgpool2_kernel(const EwArgs a) {
     }
 }
 
+// InstanceNorm finalisation + 2 x 2 average pooling of the activated plane in ONE launch (round 6): the encoder levels of the
+// U-Net run conv -> IN -> LeakyReLU -> avg_pool2d (varnet.py:95-99); norm_finalize_kernel (one workgroup per plane, ~5 us of
+// launch for 2-5 KB of records) and avgpool2_kernel were two launches per level.  Here EVERY workgroup of a plane merges the
+// plane's records itself -- norm_finalize_kernel's order and arithmetic exactly, so the affine is the same bits -- the first one
+// writes (scale, shift), and each pools its share of the plane with avgpool2_kernel's arithmetic.  The redundant merges read
+// K x 19 KB per plane from L2; a workgroup spends ~2 us on them.
+// grid: (K, c, n)
+__global__ void __launch_bounds__(256)
+norm_finalize_pool_kernel(const float* __restrict__ part, int c, int tiles, float eps, float* __restrict__ scale,
+                          float* __restrict__ shift, int sc_ctot, int sc_coff, const float* __restrict__ x, int x_ctot, int x_coff,
+                          float slope, float* __restrict__ y, int y_ctot, int y_coff, int h, int w) {
+    __shared__ double red[3][4];
+    __shared__ float aff[2];
+    const int ch = blockIdx.y, n = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int total = tiles;
+    constexpr int kKeep = 8;
+    float kc[kKeep], km[kKeep], k2[kKeep];
+    double cnt = 0.0, s = 0.0;
+    auto rec = [&](int e) -> const float* { return part + ((size_t)(n * c + ch) * tiles + e) * 3; };
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i) {
+        const int e = tid + 256 * i;
+        kc[i] = km[i] = k2[i] = 0.f;
+        if (e < total) {
+            const float* p = rec(e);
+            kc[i] = p[0];
+            km[i] = p[1];
+            k2[i] = p[2];
+            cnt += (double)kc[i];
+            s += (double)kc[i] * (double)km[i];
+        }
+    }
+    for (int e = tid + 256 * kKeep; e < total; e += 256) {
+        const float* p = rec(e);
+        cnt += (double)p[0];
+        s += (double)p[0] * (double)p[1];
+    }
+    cnt = san_wave_sum_d(cnt);
+    s = san_wave_sum_d(s);
+    if (lane == 0) {
+        red[0][wv] = cnt;
+        red[1][wv] = s;
+    }
+    __syncthreads();
+    cnt = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double mean = cnt > 0.0 ? s / cnt : 0.0;
+    double m2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i) {
+        const double d = (double)km[i] - mean;
+        m2 += (double)k2[i] + (double)kc[i] * d * d;
+    }
+    for (int e = tid + 256 * kKeep; e < total; e += 256) {
+        const float* p = rec(e);
+        const double d = (double)p[1] - mean;
+        m2 += (double)p[2] + (double)p[0] * d * d;
+    }
+    m2 = san_wave_sum_d(m2);
+    if (lane == 0) red[2][wv] = m2;
+    __syncthreads();
+    if (tid == 0) {
+        m2 = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        const double var_b = cnt > 0.0 ? m2 / cnt : 0.0;
+        const float sc = (float)(1.0 / sqrt(var_b + (double)eps));
+        const float sh = (float)(-mean) * sc;
+        aff[0] = sc;
+        aff[1] = sh;
+        if (blockIdx.x == 0) {
+            scale[n * sc_ctot + sc_coff + ch] = sc;
+            shift[n * sc_ctot + sc_coff + ch] = sh;
+        }
+    }
+    __syncthreads();
+    const float sc = aff[0], sh = aff[1];
+    const int oh = h >> 1, ow = w >> 1;
+    const float* xp = x + ((size_t)(n * x_ctot + x_coff + ch)) * h * w;
+    float* yp = y + ((size_t)(n * y_ctot + y_coff + ch)) * oh * ow;
+    for (int i = blockIdx.x * 256 + tid; i < oh * ow; i += gridDim.x * 256) {
+        const int oy = i / ow, ox = i - oy * ow;
+        const float2 r0 = *reinterpret_cast<const float2*>(xp + (size_t)(2 * oy) * w + 2 * ox);
+        const float2 r1 = *reinterpret_cast<const float2*>(xp + (size_t)(2 * oy + 1) * w + 2 * ox);
+        const float v = (san_act(r0.x, sc, sh, slope) + san_act(r0.y, sc, sh, slope)) +
+                        (san_act(r1.x, sc, sh, slope) + san_act(r1.y, sc, sh, slope));
+        yp[i] = v * 0.25f;
+    }
+}
+
 __global__ void __launch_bounds__(kThreads) upsample2_kernel(const EwArgs a) {
     const int ch = blockIdx.y, n = blockIdx.z;
     const int ow = a.w * 2;
@@ -411,6 +500,24 @@ int san_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, co
     a.x = x; a.sc = sc; a.sh = sh; a.slope = slope; a.x_ctot = x_ctot; a.x_coff = x_coff;
     a.y = y; a.y_ctot = y_ctot; a.y_coff = y_coff; a.n = n; a.c = c; a.h = h; a.w = w;
     hipLaunchKernelGGL(avgpool2_kernel, ew_grid((h / 2) * (w / 2) * 4, c, n), dim3(kThreads), 0, (hipStream_t)stream, a);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+// san_norm_finalize(SAN_NORM_INSTANCE) of the records `part` [n, c, tiles, 3] of x's channels [x_coff, x_coff + c) AND
+// san_avgpool2_fwd of x read through the affine just computed, in one launch: y [n, y_ctot, h/2, w/2] channels from y_coff =
+// avg_pool2d(lrelu(IN(x), slope)).  scale / shift: [n, sc_ctot] views at sc_coff (the same channels of x).  h, w even.
+int san_norm_finalize_pool(const float* part, int n, int c, int tiles, float eps, float* scale, float* shift, int sc_ctot, int sc_coff,
+                           const float* x, int x_ctot, int x_coff, float slope, float* y, int y_ctot, int y_coff, int h, int w,
+                           void* stream) {
+    SAN_CHECK_ARG(part && scale && shift && x && y, "null pointer");
+    SAN_CHECK_ARG(n > 0 && c > 0 && tiles > 0 && h >= 2 && w >= 2 && (h % 2 == 0) && (w % 2 == 0), "bad dims (h, w even)");
+    SAN_CHECK_ARG(check_view(sc_ctot, sc_coff, c) && check_view(x_ctot, x_coff, c) && check_view(y_ctot, y_coff, c), "bad channel view");
+    int K = san_cdiv((h / 2) * (w / 2), 256 * 12);      // ~12 output pixels per thread
+    if (K < 1) K = 1;
+    if (K > 8) K = 8;
+    hipLaunchKernelGGL(norm_finalize_pool_kernel, dim3(K, c, n), dim3(256), 0, (hipStream_t)stream, part, c, tiles, eps, scale, shift,
+                       sc_ctot, sc_coff, x, x_ctot, x_coff, slope, y, y_ctot, y_coff, h, w);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -251,7 +251,7 @@ def agree_on_failure(err, dist, device):
 def single_rank_exchange() -> bool:
     """``SAN_DIST_SINGLE=1``: treat a ONE-rank process group as data-parallel, i.e. run the whole gradient exchange (RCCL
     communicator, communication stream, per-cascade slices, recorded / captured collectives) with world size 1.  A one-GPU box
-    cannot show the transport, but it does run every RCCL call site of the step (tests/test_hip_parity_r4.py,
+    cannot show the transport, but it does run every RCCL call site of the step (tests/test_gpu_dist.py,
     ``bench.py`` with the variable set); sums over one rank leave the gradients unchanged, so the step must equal the plain one
     bit for bit."""
     return os.environ.get("SAN_DIST_SINGLE", "0") == "1"

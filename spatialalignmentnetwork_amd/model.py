@@ -46,7 +46,7 @@ AUTO_KEEP = 3          # recordings kept besides the current one (each holds its
 # Sensitivity network on an auxiliary stream beside the alignment network (forward and backward).  On by default again in round 5:
 # the misread that made co-resident kernels of two streams disagree needs a packed-fp32 instruction in the victim
 # (scratch/probe/pk32_two_stream_repro.hip), the library has none (build.py NO_PK32, tests/test_abi.py), and
-# tests/test_hip_parity_r5.py holds 50 overlapped steps at N = 8, 320^2 and 10 at 15 x 640 x 368 to the serial step bit for bit.
+# tests/test_gpu_step_runtime.py holds 50 overlapped steps at N = 8, 320^2 and 10 at 15 x 640 x 368 to the serial step bit for bit.
 SENS_OVERLAP_DEFAULT = os.environ.get("SAN_SENS_OVERLAP", "1") != "0"
 SENS_OVERLAP = [SENS_OVERLAP_DEFAULT]
 _SENS_DBG = int(os.environ.get("SAN_SENS_DBG", "0"))      # 1: forward branch only, 2: backward branch only (debugging)
@@ -271,7 +271,7 @@ class CSModel(BaseModel):
         """One optimisation step (model.py:193-216).  The first AUTO_AFTER calls with a given configuration run eagerly; the
         next one records the step (``record_update`` on private copies of the inputs; the recording itself does not advance
         the model) and from then on every call copies the current ``img_full`` / ``img_aux`` into the recording's static inputs
-        and replays it -- bit-identical to the eager step (tests/test_hip_parity_r4.py).  Anything the recording depends on
+        and replays it -- bit-identical to the eager step (tests/test_gpu_step_runtime.py).  Anything the recording depends on
         (shapes, regime, loss weights, convolution precision, world size, train / eval flags, requires_grad pattern, parameter
         and mask storage) is part of a key that is compared on every call: a change drops the recording and the step runs
         eagerly again.  ``step_mode`` says which form the last call took."""

@@ -1095,6 +1095,15 @@ def norm_finalize(part: torch.Tensor, mode: int, eps: float, scale: torch.Tensor
                int(scale.shape[1]), coff, _p(aux_a), _p(aux_b), _stream())
 
 
+def norm_finalize_pool(part: torch.Tensor, eps: float, x: Act, y: Act) -> None:
+    """InstanceNorm finalisation of x's records (into x.scale / x.shift) and y = avg_pool2d(lrelu(IN(x))) in one launch
+    (san_norm_finalize_pool): the same bits as norm_finalize + avgpool2."""
+    n, c, tiles, _ = part.shape
+    assert c == x.c == y.c and (x.h, x.w) == (2 * y.h, 2 * y.w) and x.scale is not None
+    lib().call("san_norm_finalize_pool", _p(part), n, c, tiles, float(eps), _p(x.scale), _p(x.shift), int(x.scale.shape[1]), x.coff,
+               _p(x.buf), x.ctot, x.coff, float(x.slope), _p(y.buf), y.ctot, y.coff, x.h, x.w, _stream())
+
+
 def plane_stats(x: Act, arena: Arena = GLOBAL_ARENA, tag: str = "") -> torch.Tensor:
     tiles = lib().query("san_plane_stat_tiles", x.h * x.w)
     part = arena.get("pstat" + tag, (x.n, x.c, tiles, 3), x.buf.device)

@@ -30,6 +30,8 @@ IN_EPS = 1e-5
 # NormUnet's backward as head + U-Net + tail launches inside a cascade (round 6; SAN_FUSED_NU_BWD=0: the separate launches)
 import os as _os
 FUSED_NU_BWD = [_os.environ.get("SAN_FUSED_NU_BWD", "1") != "0"]
+# InstanceNorm finalisation + average pooling of an encoder level in one launch (round 6; SAN_FUSED_FIN_POOL=0: two launches)
+FUSED_FIN_POOL = [_os.environ.get("SAN_FUSED_FIN_POOL", "1") != "0"]
 
 
 class ConvBlock(nn.Module):
@@ -47,15 +49,22 @@ class ConvBlock(nn.Module):
             nn.LeakyReLU(negative_slope=0.2, inplace=True),
         )
 
-    def run(self, x: Act, mid: Act, out: Act, tag: str) -> Act:
-        """x -> mid (raw) -> out (raw); fills the scale/shift of mid and out."""
+    def run(self, x: Act, mid: Act, out: Act, tag: str, pooled: Optional[Act] = None) -> Act:
+        """x -> mid (raw) -> out (raw); fills the scale/shift of mid and out.  pooled: also avg_pool2d of the block's activated
+        output (the encoder levels, varnet.py:95-99) -- in the SAME launch as the second InstanceNorm's finalisation where that
+        is a launch (ops.norm_finalize_pool), else by avgpool2."""
         # (split-K layers -- deep K on small planes -- finalise the InstanceNorm affine in their reduction pass: None)
         part = ops.conv2d(x, self.layers[0].weight, None, mid, stats=True, tag=tag, instance_norm_eps=IN_EPS)
         if part is not None:
             ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, mid.scale, mid.shift, mid.coff)
         part = ops.conv2d(mid, self.layers[3].weight, None, out, stats=True, tag=tag, instance_norm_eps=IN_EPS)
+        if part is not None and pooled is not None and FUSED_FIN_POOL[0]:
+            ops.norm_finalize_pool(part, IN_EPS, out, pooled)
+            return out
         if part is not None:
             ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
+        if pooled is not None:
+            ops.avgpool2(out, pooled)
         return out
 
     def run_bwd(self, g_out: Act, x: Act, mid: Act, out: Act, g_in: Optional[Act], g_pooled: Optional[Act] = None) -> None:
@@ -222,17 +231,16 @@ class Unet(nn.Module):
         for i in range(P):
             cat = _arena_act(f"{tagp}.cat{i}", n, 2 * ch, hh, ww, dev, 0.2)   # [0,ch): up path, [ch,2ch): skip
             mid = _arena_act(f"{tagp}.mid{i}", n, ch, hh, ww, dev, 0.2)
-            self.down_sample_layers[i].run(cur, mid, cat.view(ch, ch), tagp)
+            pooled = Act(ARENA.get(f"{tagp}.pool{i}", (n, ch, hh // 2, ww // 2), dev), 0, ch)
+            odd = bool((hh | ww) & 1)
+            self.down_sample_layers[i].run(cur, mid, cat.view(ch, ch), tagp, pooled=None if odd else pooled)
             tape["blocks"].append((cur, mid, cat.view(ch, ch)))
             cats.append(cat)
-            pooled = Act(ARENA.get(f"{tagp}.pool{i}", (n, ch, hh // 2, ww // 2), dev), 0, ch)
-            if (hh | ww) & 1:
+            if odd:
                 # F.avg_pool2d drops the odd last row / column (varnet.py:99): activate + crop, then pool
                 even = Act(ARENA.get(f"{tagp}.even{i}", (n, ch, hh & ~1, ww & ~1), dev), 0, ch)
                 ops.window_copy(cat.view(ch, ch), even)
                 ops.avgpool2(even, pooled)
-            else:
-                ops.avgpool2(cat.view(ch, ch), pooled)
             tape["pooled"].append(pooled)
             cur = pooled
             hh, ww, ch = hh // 2, ww // 2, ch * 2

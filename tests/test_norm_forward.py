@@ -171,3 +171,33 @@ def test_tickets_return_to_zero_and_every_launch_sees_its_own_records(S):
     torch.cuda.synchronize()
     tk = ops.GLOBAL_ARENA.get("fin_ticket", (8,), torch.device(DEV), dtype=torch.int32, zero=True)
     assert int(tk.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("n,c,h,w", [(8, 18, 320, 320), (8, 36, 160, 160), (4, 72, 80, 80), (2, 144, 40, 24), (3, 5, 16, 32)])
+def test_finalisation_and_average_pooling_in_one_launch_is_bit_identical(S, n, c, h, w):
+    """san_norm_finalize_pool (round 6) == san_norm_finalize + san_avgpool2_fwd bit for bit: the affine of the convolution's records
+    and avg_pool2d(lrelu(IN(y))) (the U-Net encoder levels, varnet.py:95-99), also through channel views."""
+    ops = S.ops
+    ops.FIN_INKERNEL[0] = False
+    x = g(philox("fp.x", (n, c, h, w)) * 2)
+    wt = g(philox("fp.w", (c, c, 3, 3)) * 0.1)
+    outs = []
+    for fused in (False, True):
+        cat = ops.Act(torch.zeros((n, 2 * c, h, w), device=DEV), 0, 2 * c, torch.zeros((n, 2 * c), device=DEV), torch.zeros((n, 2 * c), device=DEV), 0.2)
+        y = cat.view(c, c)
+        pooled = ops.Act(torch.full((n, c + 1, h // 2, w // 2), -7.0, device=DEV), 1, c)
+        part = ops.conv2d(ops.full(x), wt, None, y, stats=True, tag=".fp")
+        if part is None:
+            pytest.skip("this layer finalises in its split-K reduction")
+        if fused:
+            ops.norm_finalize_pool(part, 1e-5, y, pooled)
+        else:
+            ops.norm_finalize(part, ops.NORM_INSTANCE, 1e-5, y.scale, y.shift, y.coff)
+            ops.avgpool2(y, pooled)
+        torch.cuda.synchronize()
+        outs.append((cat.scale.clone(), cat.shift.clone(), pooled.buf.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[1][2][:, 0].min()) == -7.0 == float(outs[1][2][:, 0].max())           # the channel outside the view is untouched
+    want = F.avg_pool2d(F.leaky_relu(F.instance_norm(F.conv2d(x.double(), wt.double(), padding=1), eps=1e-5), 0.2), 2)
+    assert ((outs[1][2][:, 1:].double() - want).abs().max() / want.abs().max()).item() < 5e-6
