@@ -593,27 +593,13 @@ int san_conv2d_bf16x3_fwd_ws_in(const float* x, int x_ctot, int x_coff, int cin,
                                 int cout, float* part_stats, int n, int h, int w, void* ws, size_t ws_bytes, float* scale,
                                 float* shift, int sc_ctot, int sc_coff, float eps, int* finalised, void* stream);
 
-/* Convolution + the FINALISATION of the normalisation that follows it in ONE launch (round 6; csrc/san_fin.h).  The reference
- * runs conv -> InstanceNorm2d / BatchNorm2d as separate modules (varnet.py:139-146, 171-176; unet.py:119-126); here the convolution
- * emits statistics records and the LAST workgroup of a reduction domain (InstanceNorm: a sample; BatchNorm: the launch) merges them
- * in a fixed order and writes the lazy affine -- the 2-5 KB san_norm_finalize launch per layer (299 per training step) disappears.
- * Records travel write-through, one relaxed agent-scope add per workgroup on the domain's ticket; nothing waits for another
- * workgroup.  kind: 3 = 3x3 (as san_conv2d_bf16x3_fwd_ws; ws / ws_bytes may be NULL / 0), 1 = 1x1 (san_conv1x1_bf16x3_fwd), 2 =
- * transposed 2x2 (san_tconv2x2_bf16x3_fwd; cout = real channels, bias NULL).  scale / shift: [n, sc_ctot] views, channels from
- * sc_coff.  ticket: int32 scratch (n words; BatchNorm: 1) zeroed ONCE by the caller, left zero by every launch.  *finalised
- * (host int): 1 = the affine is written; 0 = this shape keeps the separate launch and part_stats holds the records.
- * _bn: training BatchNorm2d as san_norm_finalize_bn (batch mean / unbiased variance to bmean / bvar [c], running statistics and
- * *num_batches_tracked updated; rmean / rvar / num_batches_tracked may be NULL together). */
-int san_conv_bf16x3_fwd_fin(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
-                            const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
-                            int n, int h, int w, int kind, void* ws, size_t ws_bytes, float* scale, float* shift, int sc_ctot,
-                            int sc_coff, float eps, void* ticket, int* finalised, void* stream);
-int san_conv_bf16x3_fwd_fin_bn(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
-                               float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
-                               float* part_stats, int n, int h, int w, int kind, float* scale, float* shift, int sc_ctot, int sc_coff,
-                               float eps, const float* gamma, const float* beta, float* bmean, float* bvar, float* rmean, float* rvar,
-                               long long* num_batches_tracked, float momentum, float var_factor, void* ticket, int* finalised,
-                               void* stream);
+/* Per-tensor power-of-two scale of fp16-format weight images (round 6): on = 1 / 0 switches it for images packed FROM NOW ON
+ * (returns the previous setting; on < 0 only queries).  With it the packed image holds w * S_w (max |w| S_w in [2^13, 2^14)), {S_w,
+ * 1 / S_w} sit behind the image and the convolution kernels multiply their accumulators by 1 / S_w: weights of any magnitude keep 22
+ * mantissa bits (unscaled: fp16's range as it is -- a 0.1-sized weight loses 3e-7 to the denormal floor of its second part).  Off
+ * by default (a max pass over every weight per optimiser step); the caller initialises the 8 bytes behind a new image to {1.f, 1.f}.
+ * Replaces nothing in the reference (its weights are fp32, varnet.py:139-146); it is part of this library's operand format. */
+int san_conv_f16_wscale_enable(int on);
 
 /* The same kernel as a 1x1 convolution (the alignment net's 1x1 layers, unet.py:64-77; the data gradient of
  * the transposed convolutions): weights packed with the _ks entry points (ks = 1 or 3; the plain ones are

@@ -129,7 +129,7 @@ class SanLibrary:
     # size / eligibility / geometry queries are pure functions of their integer arguments (and of the tuning hooks, whose
     # setters clear the cache): memoised, ~2,800 of them per training step otherwise cross ctypes
     _STATEFUL = frozenset({"san_get_conv_precision", "san_wgrad_defer", "san_wgrad_defer_pending", "san_version",
-                           "san_conv_direct_enable", "san_conv1x1_gemm_enable"})
+                           "san_conv_direct_enable", "san_conv1x1_gemm_enable", "san_conv_f16_wscale_enable"})
 
     def call(self, name: str, *args):
         """Call an int-returning entry point; raise RuntimeError on failure.  (~2,000 calls per training step: the function

@@ -9,24 +9,6 @@
 
 void san_set_error(const char* fmt, ...);
 
-// In-kernel finalisation of normalisation statistics by the last workgroup of a reduction domain (san_fin.h, round 6).
-struct SanFin {
-    unsigned* ticket;          // null: no in-kernel finalisation (the caller launches san_norm_finalize)
-    float* scale;              // [n][sc_ctot], channels from sc_coff
-    float* shift;
-    const float* gamma;        // BatchNorm: affine parameters (may be null), batch statistics out, running statistics in / out
-    const float* beta;
-    float* bmean;
-    float* bvar;
-    float* rmean;
-    float* rvar;
-    long long* nbt;
-    float eps, momentum, var_factor;
-    int sc_ctot, sc_coff;
-    int batch;                 // 1: BatchNorm domain (all samples), 0: InstanceNorm (per sample)
-    unsigned expected;         // arrivals that complete a domain
-};
-
 // 1x1 / transposed convolution as a one-stage GEMM (san_conv1x1.hip), launched by conv_bf16x3_run (san_conv_bf16.hip) for KS = 1
 // layers whose weights are packed as two fp16 parts.  Internal to the library (not part of the ABI).
 struct SanGemm1x1Args {
@@ -38,6 +20,7 @@ struct SanGemm1x1Args {
     float* y;
     float* part;               // statistics records or null: `slots` per (sample, channel) plane (x 4 interleaved when shuffling)
     const uint32_t* amax;      // gradient input: its amax record (the input is scaled by a power of two), else null
+    const float* w_tail;       // fp16-format weights: {S_w, 1 / S_w} behind the packed image (the accumulators get 1 / S_w), else null
     float in_slope;
     int x_ctot, x_coff, cin;
     int y_ctot, y_coff, cout;  // cout: channels of the GEMM (4 x the real channels when shuffling)
@@ -47,7 +30,6 @@ struct SanGemm1x1Args {
     int bf1;                   // 1: bf16-format image, one part (plain bf16 operands, one product); 0: two fp16 parts, three products
     int slots;
     int ngrp, ptiles;          // (filled by the launcher)
-    SanFin fin;                // in-kernel InstanceNorm finalisation (ticket null: off)
 };
 bool san_gemm1x1_enabled();
 int san_gemm1x1_f16_run(SanGemm1x1Args a, void* stream);

@@ -16,7 +16,6 @@
 #include <stdlib.h>
 
 #include "san_common.h"
-#include "san_fin.h"
 
 namespace {
 
@@ -208,6 +207,7 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
         }
     }
 
+    if (!BF1 && a.w_tail) inInvS *= a.w_tail[1];          // fp16-format weights may be stored x S_w (round 6): exact power of two
     // ------------------------------------------------------------ epilogue
 #pragma unroll
     for (int m = 0; m < NGW; ++m)
@@ -264,9 +264,13 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
                         // the 4 virtual channels of a real channel are 4 interleaved slot sequences of its plane
                         float* dst = a.part + ((size_t)(n * (a.cout >> 2) + (co >> 2)) * (a.slots * 4) + (co & 3)) * 3;
                         float* o = dst + (size_t)pt * 12;
-                        san_stat_store(o, cnt, pilot + s1 * inv, fmaxf(s2 - s1 * s1 * inv, 0.f), a.fin.ticket != nullptr);
-                        for (int s = pt + ptiles; s < a.slots; s += ptiles)     // unused slots: empty records
-                            san_stat_store(dst + (size_t)s * 12, 0.f, 0.f, 0.f, a.fin.ticket != nullptr);
+                        o[0] = cnt;
+                        o[1] = pilot + s1 * inv;
+                        o[2] = fmaxf(s2 - s1 * s1 * inv, 0.f);
+                        for (int s = pt + ptiles; s < a.slots; s += ptiles) {   // unused slots: empty records
+                            float* z = dst + (size_t)s * 12;
+                            z[0] = z[1] = z[2] = 0.f;
+                        }
                     }
                 }
         }
@@ -333,9 +337,13 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
                 if (kg == 0 && co < a.cout) {
                     float* dst = a.part + (size_t)(n * a.cout + co) * a.slots * 3;
                     float* o = dst + (size_t)pt * 3;
-                    san_stat_store(o, cnt, pilot + s1 * inv, fmaxf(s2 - s1 * s1 * inv, 0.f), a.fin.ticket != nullptr);
-                    for (int s = pt + ptiles; s < a.slots; s += ptiles)         // unused slots: empty records
-                        san_stat_store(dst + (size_t)s * 3, 0.f, 0.f, 0.f, a.fin.ticket != nullptr);
+                    o[0] = cnt;
+                    o[1] = pilot + s1 * inv;
+                    o[2] = fmaxf(s2 - s1 * s1 * inv, 0.f);
+                    for (int s = pt + ptiles; s < a.slots; s += ptiles) {       // unused slots: empty records
+                        float* z = dst + (size_t)s * 3;
+                        z[0] = z[1] = z[2] = 0.f;
+                    }
                 }
             }
         }
@@ -358,10 +366,6 @@ __global__ void __launch_bounds__(kT) gemm1x1_f16_kernel(const SanGemm1x1Args a)
             }
         }
     }
-    // in-kernel InstanceNorm finalisation: the last workgroup of a sample merges its records (san_fin.h); a transposed convolution's
-    // real channel owns the 4 interleaved slot sequences of its virtual channels
-    if (a.part && a.fin.ticket)
-        san_fin_tail<kT>(a.fin, a.part, a.N, SHUFFLE ? a.cout >> 2 : a.cout, SHUFFLE ? a.slots * 4 : a.slots, n, 1u);
 }
 
 // SAN_CONV1X1_GEMM=0 in the environment: off from the start (same-box A/B of whole steps)
@@ -409,7 +413,6 @@ int san_gemm1x1_f16_run(SanGemm1x1Args a, void* stream) {
         san_set_error("1x1 GEMM: %d channel blocks in the packed image, %d wanted", a.nblkp, a.ngrp * 4 * NGW);
         return SAN_E_ARG;
     }
-    if (a.fin.ticket) a.fin.expected = (unsigned)(a.ptiles * a.ngrp * (a.fin.batch ? a.N : 1));      // one arrival per workgroup
     if (a.part && a.slots < a.ptiles) {
         san_set_error("1x1 GEMM: %d statistics slots for %d pixel tiles", a.slots, a.ptiles);
         return SAN_E_ARG;

@@ -25,7 +25,6 @@
 // 7 K-steps of 4 groups (one zero group of padding).  In the weights-direct form (WD, MB <= 4) the weights skip
 // LDS and are read by the K-steps straight from L2, which leaves room for three workgroups per CU.
 #include "san_common.h"
-#include "san_fin.h"
 
 #include <cstdint>
 #include <cstdlib>
@@ -36,7 +35,7 @@ void san_wgrad_set_parts(int parts);             // san_wgrad_bf16.hip
 // san_conv_stream.hip: the persistent form for the high-resolution few-channel layers (fp16-format weights)
 int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
                         const void* w_packed, int nblkp, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
-                        const void* amax, int n, int h, int w, void* stream, int nprt, const SanFin* fin);
+                        const void* amax, int n, int h, int w, void* stream, int nprt, const float* w_tail);
 
 // Tuning switches, both measured and left off (scratch/README.md, round 2): HALFX = the K-loop's activation operand reads run
 // half a K-step ahead (two of a wave's four pixel blocks per set: 32 operand registers fewer) -- neutral, the register peak is
@@ -111,8 +110,7 @@ struct BArgs {
     unsigned long long* dbg;   // tuning hook (san_conv_bf16x3_debug_timeline): per workgroup 8 x u64 = 100 MHz clock at start, first
                                // chunk staged, epilogue start, end; HW_ID; XCC_ID -- null in normal use
     const uint32_t* amax;      // fp16 format on a GRADIENT input: the tensor's amax record (san_common.h); the input is scaled by a power of two
-    const float* f8_tail;      // fp8 format: {S_w, 1 / S_w} behind the packed image (the per-tensor power-of-two weight scale)
-    SanFin fin;                // in-kernel finalisation of the statistics (san_fin.h; ticket null: off)
+    const float* f8_tail;      // fp8 and fp16 formats: {S_w, 1 / S_w} behind the packed image (the per-tensor power-of-two weight scale)
 };
 
 // x / d for 0 <= x, d >= 1 with the host's multiplier m (BArgs.m_*); m == 0: plain division
@@ -320,6 +318,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             }
         }
     }
+    if constexpr (F16) inInvS *= a.f8_tail[1];          // the fp16-format weights' 1 / S_w (round 6; 1 unless the scale is switched on)
     if constexpr (F8) {
         inS = kF8ActScale;
         inInvS = a.f8_tail[1] * (1.f / kF8ActScale);
@@ -602,7 +601,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
     // plus a write-back (four reads + two writes over all accumulators); now there is one read pass.
     {
         float osc = 1.f;
-        if constexpr (F16 || F8) osc = (F8 || a.amax) ? inInvS : 1.f;
+        if constexpr (F16 || F8) osc = inInvS;
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -681,8 +680,9 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     const int co = cb0 + 16 * m;
                     if (kg == 0 && co < a.cout) {
                         float* o = a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
-                        san_stat_store(o, cnt, cnt > 0.f ? pilot + s1 * inv : 0.f, cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f,
-                                       a.fin.ticket != nullptr);
+                        o[0] = cnt;
+                        o[1] = cnt > 0.f ? pilot + s1 * inv : 0.f;
+                        o[2] = cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f;
                     }
                 }
             }
@@ -712,7 +712,6 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             }
         }
         mark(3);
-        if (a.S == 1 && a.part && a.fin.ticket) san_fin_tail<kT>(a.fin, a.part, a.N, a.cout, ntile * 4, n, 1u);
         return;
     }
     // acc[m][b][r] = output channel co = (cg MB + m) 16 + 4 (lane >> 4) + r at tile pixel (trow[b], tcol[b])
@@ -791,8 +790,9 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     // transposed convolution: the 4 virtual channels of a real channel are 4 more statistics tiles
                     float* o = a.shuffle ? a.part + ((size_t)(n * (a.cout >> 2) + (co >> 2)) * (tiles * 4) + (tile * 4 + wave) * 4 + (co & 3)) * 3
                                          : a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
-                    san_stat_store(o, cnt, cnt > 0.f ? pilot + s1 * inv : 0.f, cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f,
-                                   a.fin.ticket != nullptr);
+                    o[0] = cnt;
+                    o[1] = cnt > 0.f ? pilot + s1 * inv : 0.f;
+                    o[2] = cnt > 0.f ? fmaxf(s2 - s1 * s1 * inv, 0.f) : 0.f;
                 }
             }
     }
@@ -814,8 +814,6 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     }
             }
         }
-        // (transposed form: a real channel's statistic = its 4 virtual channels' records, 16 per tile)
-        if (a.part && a.fin.ticket) san_fin_tail<kT>(a.fin, a.part, a.N, a.cout >> 2, ntile * 16, n, 1u);
         return;
     }
 #pragma unroll
@@ -830,7 +828,6 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     if (valid[b]) dst[oy[b] * W + ox[b]] = acc[m][b][r];
             }
         }
-    if (a.part && a.fin.ticket) san_fin_tail<kT>(a.fin, a.part, a.N, a.cout, ntile * 4, n, 1u);
 }
 
 // ---------------------------------------------------------------- split-K second pass
@@ -911,7 +908,12 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t*
                                           int cin, int nblkp, int mode_, int ks, const float* __restrict__ wscale) {
     const bool f16 = (mode_ & 16) != 0;            // mode + 16: two fp16 parts (parts 0, 1 of the image; part 2 zero)
     const bool f8 = (mode_ & 32) != 0;             // mode + 32: one fp8 e4m3 part x the tensor's scale (low 8 bytes of the part-0 slot)
-    const float wS = f8 ? wscale[0] : 1.f;
+    // fp8 AND (round 6, opt-in: san_conv_f16_wscale_enable) fp16 formats: the tensor's power-of-two scale S_w (exact), written behind
+    // the image by the wscale pass ({1, 1} when off).  The fp16 parts then hold w S_w with max |w| S_w in [2^13, 2^14): the second
+    // part is a NORMAL fp16 number for every weight within 2^-16 of the largest one -- unscaled, a 0.1-sized weight leaves its second
+    // part in the denormals (absolute floor 2^-25: 3e-7 of the weight, the per-layer error of rounds 2-5) and a 1e-4-sized tensor
+    // keeps 11 bits.  The kernels multiply the accumulators by 1 / S_w.
+    const float wS = (f8 || f16) ? wscale[0] : 1.f;
     const int mode = mode_ & 15;
     const int lane = (int)(u & 63);
     size_t r = u >> 6;
@@ -945,8 +947,8 @@ __device__ __forceinline__ void pack_unit(const float* __restrict__ w, uint16_t*
         v8[i + 1] = v[1] * wS;
         uint32_t a1, a2, a3 = 0, b1, b2, b3 = 0;
         if (f16) {
-            split2h(v[0], a1, a2);
-            split2h(v[1], b1, b2);
+            split2h(v8[i], a1, a2);
+            split2h(v8[i + 1], b1, b2);
         } else {
             split3(v[0], a1, a2, a3);
             split3(v[1], b1, b2, b3);
@@ -986,7 +988,8 @@ __global__ void pack_bf16x3_batch_kernel(const long long* __restrict__ jobs) {
 
 // fp8 format: the tensor's power-of-two scale {S_w, 1 / S_w}, S_w = 2^(7 - floor(log2 max |w|)) (scaled maximum in [128, 256)),
 // written behind the packed image.  One 1024-thread workgroup per tensor (max is order-independent); launched before the packing kernel.
-__device__ __forceinline__ void fp8_wscale(const float* __restrict__ w, size_t count, float* __restrict__ tail) {
+// (round 6: also the fp16-part format, `target` = 13: scaled maximum in [2^13, 2^14), as the gradient inputs' amax scale)
+__device__ __forceinline__ void fp8_wscale(const float* __restrict__ w, size_t count, float* __restrict__ tail, int target = 7) {
     __shared__ float red[16];
     float m = 0.f;
     if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
@@ -1011,24 +1014,25 @@ __device__ __forceinline__ void fp8_wscale(const float* __restrict__ w, size_t c
         int e = (int)((__builtin_bit_cast(uint32_t, m) >> 23) & 255u);       // biased exponent of the maximum
         float S = 1.f, inv = 1.f;
         if (m > 0.f && m < __builtin_inff()) {
-            e = e < 10 ? 10 : (e > 240 ? 240 : e);
-            S = __builtin_bit_cast(float, (uint32_t)(127 + 7 - (e - 127)) << 23);
-            inv = __builtin_bit_cast(float, (uint32_t)(127 - 7 + (e - 127)) << 23);
+            e = e < 14 ? 14 : (e > 240 ? 240 : e);
+            S = __builtin_bit_cast(float, (uint32_t)(127 + target - (e - 127)) << 23);
+            inv = __builtin_bit_cast(float, (uint32_t)(127 - target + (e - 127)) << 23);
         }
         tail[0] = S;
         tail[1] = inv;
     }
 }
 
-__global__ void __launch_bounds__(1024) fp8_wscale_kernel(const float* __restrict__ w, size_t count, float* __restrict__ tail) {
-    fp8_wscale(w, count, tail);
+__global__ void __launch_bounds__(1024) fp8_wscale_kernel(const float* __restrict__ w, size_t count, float* __restrict__ tail, int target) {
+    fp8_wscale(w, count, tail, target);
 }
 
 __global__ void __launch_bounds__(1024) fp8_wscale_batch_kernel(const long long* __restrict__ jobs) {
     const long long* j = jobs + 8 * (size_t)blockIdx.x;
-    if (((int)j[6] & 32) == 0) return;
+    const int m = (int)j[6];
+    if ((m & 32) == 0 && !((m & 16) && (m & 256))) return;      // fp8 images, and fp16 images that asked for a scale (bit 8)
     fp8_wscale(reinterpret_cast<const float*>(j[0]), (size_t)j[2] * (size_t)j[3] * (j[5] == 1 ? 1 : 9),
-               reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(j[1]) + (size_t)j[7]));
+               reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(j[1]) + (size_t)j[7]), (m & 32) ? 7 : 13);
 }
 
 int g_b16_wd = -1;             // tuning hook (SAN_B16_WD=0/1 at first use): force the weights-direct choice
@@ -1137,7 +1141,10 @@ int pick_mb_f16(int cin, int cout, int tiles) {
 }
 
 int g_conv_np = 3;             // operand parts of the bf16 convolutions / weight gradients (san_set_conv_precision)
-int g_fin_on = (getenv("SAN_FIN_INKERNEL") && atoi(getenv("SAN_FIN_INKERNEL")) == 0) ? 0 : 1;      // in-kernel norm finalisation (san_fin.h)
+// Per-tensor power-of-two scale of the fp16-format weight images (round 6, san_conv_f16_wscale_enable / SAN_F16_WSCALE=1).  OFF by
+// default: it costs a max pass over every weight per optimiser step (+0.6 ms of a 41 ms step as measured) and buys 20 % of the
+// end-to-end error (12 cascades, 320^2: 7.8e-5 -> 6.1e-5 vs float64; per layer 3e-7 -> 1e-7) and weights of ANY magnitude.
+int g_f16_wscale = (getenv("SAN_F16_WSCALE") && atoi(getenv("SAN_F16_WSCALE")) == 1) ? 1 : 0;
 
 // Which packed weight images hold two fp16 parts (packed with mode + 16) instead of bf16 parts: recorded by the pack entry
 // points (host side), looked up by the launchers, so the convolution entry points need no format argument.
@@ -1214,6 +1221,14 @@ extern "C" {
 // Narrow-precision modes of every bf16 matrix-core convolution and weight gradient (BASELINE configs 2 / 5 name bf16 /
 // fp8 U-Net convolutions judged by PSNR): parts = 3 fp32-equivalent (default), 2 = 16 mantissa bits (three products),
 // 1 = plain bf16 (one product).  FFT, data consistency, normalisation statistics and losses stay fp32 in every mode.
+// 1 / 0: fp16-format weight images packed FROM NOW ON carry / do not carry the tensor's power-of-two scale (see g_f16_wscale);
+// on < 0: query.  Returns the previous setting.  Images packed earlier keep what they have (re-pack them: the registry's epoch).
+int san_conv_f16_wscale_enable(int on) {
+    const int prev = g_f16_wscale;
+    if (on >= 0) g_f16_wscale = on ? 1 : 0;
+    return prev;
+}
+
 int san_set_conv_precision(int parts) {
     SAN_CHECK_ARG(parts >= 1 && parts <= 3, "parts must be 1, 2 or 3");
     g_conv_np = parts;
@@ -1273,9 +1288,9 @@ int san_conv_bf16x3_pack_ks(const float* w, void* packed, int cout, int cin, int
     // mode 2: `cout`, `cin` are those of the DATA-GRADIENT convolution (cout = forward cin, cin = forward cout)
     const BPlan p = bplan(cout, cin, ks);
     note_format(packed, mode);
-    if (mode & 32) {
+    if ((mode & 32) || ((mode & 16) && g_f16_wscale)) {
         hipLaunchKernelGGL(fp8_wscale_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, w, (size_t)cout * cin * (ks == 1 ? 1 : 9),
-                           reinterpret_cast<float*>(static_cast<uint16_t*>(packed) + p.packed_elems));
+                           reinterpret_cast<float*>(static_cast<uint16_t*>(packed) + p.packed_elems), (mode & 32) ? 7 : 13);
         SAN_LAUNCH_CHECK();
     }
     size_t blocks = (p.packed_elems + 255) / 256;
@@ -1301,7 +1316,7 @@ int san_conv_bf16x3_pack_job_ks(long long* job8, const float* w, void* packed, i
     job8[3] = cin;
     job8[4] = p.nblkp;
     job8[5] = ks;
-    job8[6] = mode;
+    job8[6] = mode | (((mode & 16) && g_f16_wscale) ? 256 : 0);       // (bit 8: this fp16 image carries a per-tensor scale)
     job8[7] = (long long)p.packed_elems;
     return SAN_OK;
 }
@@ -1330,16 +1345,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
                            float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
                            float* part_stats, int n, int h, int w, int ks, void* stream, int shuffle = 0,
                            void* ws = nullptr, size_t ws_bytes = 0, const void* amax = nullptr, float* fin_scale = nullptr,
-                           float* fin_shift = nullptr, int fin_ctot = 0, int fin_coff = 0, float fin_eps = 0.f,
-                           const SanFin* fin_in = nullptr) {
-    // in-kernel finalisation (san_fin.h): the affine destination + a zeroed ticket array; returns 1 when the launch finalised
-    SanFin fin{};
-    if (fin_in && fin_in->ticket && part_stats && g_fin_on) {
-        fin = *fin_in;
-    } else if (fin_in) {
-        fin_in = nullptr;
-    }
-    const bool fin_on = fin.ticket != nullptr;
+                           float* fin_shift = nullptr, int fin_ctot = 0, int fin_coff = 0, float fin_eps = 0.f) {
     SAN_CHECK_ARG(x && w_packed && y, "null pointer");
     SAN_CHECK_ARG(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "bad dims");
     SAN_CHECK_ARG(x_coff >= 0 && x_coff + cin <= x_ctot && y_coff >= 0 && y_coff + (shuffle ? cout / 4 : cout) <= y_ctot, "bad channel view");
@@ -1356,15 +1362,13 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     SAN_CHECK_ARG(a.fmt != 1 || g_conv_np == 3, "fp16-format weights are for the fp32-equivalent mode only");
     SAN_CHECK_ARG(a.fmt != 2 || g_conv_np == 1, "fp8-format weights are for the one-part mode only (san_set_conv_precision(1))");
     a.amax = a.fmt == 1 ? static_cast<const uint32_t*>(amax) : nullptr;
-    a.f8_tail = a.fmt == 2 ? reinterpret_cast<const float*>(static_cast<const uint16_t*>(w_packed) + p.packed_elems) : nullptr;
+    a.f8_tail = a.fmt >= 1 ? reinterpret_cast<const float*>(static_cast<const uint16_t*>(w_packed) + p.packed_elems) : nullptr;     // {S_w, 1 / S_w}
     // the persistent form: two fp16 parts (fp32-equivalent mode) or one bf16 part (cout 18 / 36: the network's layers)
     const bool stream_f16 = a.fmt == 1 && g_conv_np == 3, stream_bf1 = a.fmt == 0 && g_conv_np == 1 && (cout == 18 || cout == 36);
     if (ks == 3 && (stream_f16 || stream_bf1) && !shuffle && g_b16_mb < 0 && g_b16_wd < 0 &&
         san_conv_stream_eligible(n, h, w, cin, cout, x_ctot))
-    {
         return san_conv_stream_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, p.nblkp, bias, y, y_ctot, y_coff, cout,
-                                   part_stats, a.amax, n, h, w, stream, stream_f16 ? 2 : 1, fin_on ? &fin : nullptr);      // (1: finalised)
-    }
+                                   part_stats, a.amax, n, h, w, stream, stream_f16 ? 2 : 1, stream_f16 ? a.f8_tail : nullptr);
     if (ks == 1 && ((a.fmt == 1 && g_conv_np == 3) || (a.fmt == 0 && g_conv_np == 1)) && g_b16_mb < 0 && san_gemm1x1_enabled()) {
         // round 5: the whole K range staged once, no barrier between K-steps (san_conv1x1.hip)
         const TileGeom tg1 = tile_geom(h, w);
@@ -1391,10 +1395,9 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
         g.nblkp = p.nblkp;
         g.shuffle = shuffle;
         g.bf1 = a.fmt == 0 ? 1 : 0;
+        g.w_tail = a.fmt == 1 ? a.f8_tail : nullptr;
         g.slots = tg1.tiles_x * tg1.tiles_y * 4;
-        if (fin_on) g.fin = fin;                       // (expected arrivals: filled by the launcher, which knows its grid)
-        const int rc = san_gemm1x1_f16_run(g, stream);
-        return rc == SAN_OK && fin_on ? 1 : rc;
+        return san_gemm1x1_f16_run(g, stream);
     }
     a.dbg = g_b16_dbg;
     a.shuffle = shuffle;
@@ -1431,10 +1434,6 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
             a.S = S;
             a.ws = static_cast<float*>(ws);
         }
-    }
-    if (a.S == 1 && fin_on) {
-        a.fin = fin;
-        a.fin.expected = (unsigned)(a.tiles_x * a.tiles_y * a.cgs * (fin.batch ? a.N : 1));    // one arrival per workgroup
     }
     {
         const unsigned long long total = (unsigned long long)a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
@@ -1477,7 +1476,6 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
-    if (a.S == 1 && fin_on) return 1;                   // the last workgroup of every sample wrote the affine
     if (a.S > 1) {
         const TileGeom tgs = tile_geom(h, w);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(n * cout), dim3(256), 0, s, a.ws, a.S, bias, y, y_ctot, y_coff, part_stats,
@@ -1562,78 +1560,6 @@ int san_conv2d_bf16x3_fwd_ws_in(const float* x, int x_ctot, int x_coff, int cin,
                                    part_stats, n, h, w, 3, stream, 0, ws, ws_bytes, nullptr, scale, shift, sc_ctot, sc_coff, eps);
     *finalised = rc == 1 ? 1 : 0;
     return rc == 1 ? SAN_OK : rc;
-}
-
-// Forward convolution + the FINALISATION of the normalisation that follows it, in one launch (round 6, san_fin.h): the last
-// workgroup of a reduction domain merges the statistics records and writes the lazy affine -- no san_norm_finalize launch.
-// kind: 3 = 3x3 (san_conv2d_bf16x3_fwd_ws: ws / ws_bytes may be NULL / 0), 1 = 1x1 (san_conv1x1_bf16x3_fwd), 2 = transposed 2x2
-// (san_tconv2x2_bf16x3_fwd: cout = real output channels, bias must be NULL).  scale / shift: [n, sc_ctot] views at channel offset
-// sc_coff; ticket: int32 scratch of n words zeroed ONCE by the caller (left zero).  *finalised (host) = 1: the affine is written;
-// 0: this shape / mode keeps the separate launch (part_stats holds the records as usual).
-static int conv_fin_impl(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
-                         const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats, int n,
-                         int h, int w, int kind, void* ws, size_t ws_bytes, const SanFin& fin, int* finalised, void* stream) {
-    SAN_CHECK_ARG(fin.scale && fin.shift && finalised && part_stats && fin.ticket, "null pointer");
-    SAN_CHECK_ARG(kind == 1 || kind == 2 || kind == 3, "kind: 3 = 3x3, 1 = 1x1, 2 = transposed 2x2");
-    SAN_CHECK_ARG(fin.sc_coff >= 0 && fin.sc_coff + cout <= fin.sc_ctot, "bad scale/shift view");
-    SAN_CHECK_ARG(kind != 2 || bias == nullptr, "the transposed convolution has no bias");
-    int rc;
-    if (kind == 3)
-        rc = conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout, part_stats, n, h,
-                             w, 3, stream, 0, ws, ws_bytes, nullptr, fin.batch ? nullptr : fin.scale, fin.batch ? nullptr : fin.shift,
-                             fin.sc_ctot, fin.sc_coff, fin.eps, &fin);
-    else
-        rc = conv_bf16x3_run(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff,
-                             kind == 2 ? 4 * cout : cout, part_stats, n, h, w, 1, stream, kind == 2 ? 1 : 0, nullptr, 0, nullptr, nullptr,
-                             nullptr, 0, 0, 0.f, &fin);
-    *finalised = rc == 1 ? 1 : 0;
-    return rc == 1 ? SAN_OK : rc;
-}
-
-int san_conv_bf16x3_fwd_fin(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
-                            const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
-                            int n, int h, int w, int kind, void* ws, size_t ws_bytes, float* scale, float* shift, int sc_ctot,
-                            int sc_coff, float eps, void* ticket, int* finalised, void* stream) {
-    SanFin fin{};
-    fin.ticket = static_cast<unsigned*>(ticket);
-    fin.scale = scale;
-    fin.shift = shift;
-    fin.sc_ctot = sc_ctot;
-    fin.sc_coff = sc_coff;
-    fin.eps = eps;
-    return conv_fin_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout, part_stats, n, h, w,
-                         kind, ws, ws_bytes, fin, finalised, stream);
-}
-
-// The same for training-mode BatchNorm2d (unet.py:125; san_norm_finalize_bn's arithmetic): ONE reduction domain (all samples), the
-// affine gamma / sqrt(var_b + eps), beta - mean * that for every sample, the batch mean / unbiased variance in bmean / bvar [c] and
-// the running statistics (+ *num_batches_tracked) updated with `momentum` and `var_factor`.  ticket: one zeroed int32 word.
-int san_conv_bf16x3_fwd_fin_bn(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift,
-                               float in_slope, const void* w_packed, const float* bias, float* y, int y_ctot, int y_coff, int cout,
-                               float* part_stats, int n, int h, int w, int kind, float* scale, float* shift, int sc_ctot, int sc_coff,
-                               float eps, const float* gamma, const float* beta, float* bmean, float* bvar, float* rmean, float* rvar,
-                               long long* num_batches_tracked, float momentum, float var_factor, void* ticket, int* finalised,
-                               void* stream) {
-    SAN_CHECK_ARG((rmean == nullptr) == (rvar == nullptr), "running mean / variance come together");
-    SanFin fin{};
-    fin.ticket = static_cast<unsigned*>(ticket);
-    fin.scale = scale;
-    fin.shift = shift;
-    fin.sc_ctot = sc_ctot;
-    fin.sc_coff = sc_coff;
-    fin.eps = eps;
-    fin.batch = 1;
-    fin.gamma = gamma;
-    fin.beta = beta;
-    fin.bmean = bmean;
-    fin.bvar = bvar;
-    fin.rmean = rmean;
-    fin.rvar = rvar;
-    fin.nbt = num_batches_tracked;
-    fin.momentum = momentum;
-    fin.var_factor = var_factor;
-    return conv_fin_impl(x, x_ctot, x_coff, cin, in_scale, in_shift, in_slope, w_packed, bias, y, y_ctot, y_coff, cout, part_stats, n, h, w,
-                         kind, nullptr, 0, fin, finalised, stream);
 }
 
 // Data gradient on fp16-format weights (packed with mode 2 + 16): x = dy [n, cout_fwd, h, w] materialised, amax = device

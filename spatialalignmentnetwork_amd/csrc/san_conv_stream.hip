@@ -17,7 +17,6 @@
 // each, plus 32 LDS reads per thread, cost more than the prefetch returned: scratch/attempts/r4_stream_v1_ablation.txt.)
 // Reference work replaced: nn.Conv2d(3x3, padding 1, bias False) of varnet.py:139-146 (ConvBlock) and its autograd data gradient.
 #include "san_common.h"
-#include "san_fin.h"
 
 #include <cstdint>
 #include <cstdlib>
@@ -55,9 +54,8 @@ struct SArgs {
     const float* bias;
     float* y;
     float* part;               // statistics [n][cout][tiles * 4][3] or null
-    SanFin fin;                // in-kernel finalisation (ticket null: off): a wave then MERGES the statistics of its consecutive tiles
-                               // of a sample and writes ONE record per run, at the slot of the run's first tile
     const uint32_t* amax;      // gradient input: amax record (san_common.h) or null
+    const float* w_tail;       // fp16-format weights: {S_w, 1 / S_w} behind the packed image (NPRT = 2), else null
     float in_slope;
     int x_ctot, x_coff, cin;
     int y_ctot, y_coff, cout;
@@ -108,46 +106,6 @@ __device__ __forceinline__ void dma_x4(uint32_t lds_addr, uint32_t voff, v4i rs,
 }
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// The last workgroup of sample n merges the sample's records (fin mode).  Which slots hold records follows from the tile order
-// alone: XCD x owns the tiles [tb, te), its P workgroups take them round-robin, so inside a sample's share [lo, hi) of that range the
-// runs (one workgroup's consecutive tiles of the sample) start at the first min(P, hi - lo) tiles -- at most 8 intervals of
-// consecutive slots, enumerated in tile order (never in arrival order).
-constexpr int kFinIv = 72;                          // intervals of run starts: at most 8 + samples - 1 (BatchNorm: samples <= 64)
-__device__ __forceinline__ void stream_fin_merge(const SanFin& f, const float* __restrict__ part, int N, int cout, int ntile, int total, int P,
-                                                 int n) {
-    __shared__ double red[3 * kT];
-    __shared__ int iv_n[kFinIv], iv_lo[kFinIv], iv_pre[kFinIv + 1], iv_cnt;
-    const int n_lo = f.batch ? 0 : n, n_hi = f.batch ? N : n + 1;
-    if (threadIdx.x == 0) {
-        int acc = 0, k = 0;
-        for (int x = 0; x < 8; ++x) {
-            const int tb = (int)(((long long)total * x) >> 3), te = (int)(((long long)total * (x + 1)) >> 3);
-            if (tb >= te) continue;
-            for (int b = max(n_lo, tb / ntile); b < n_hi && b * ntile < te; ++b) {
-                const int lo = max(tb, b * ntile), hi = min(te, (b + 1) * ntile);
-                if (lo >= hi || k >= kFinIv) continue;
-                iv_n[k] = b;
-                iv_lo[k] = lo - b * ntile;
-                iv_pre[k] = acc;
-                acc += min(P, hi - lo);
-                ++k;
-            }
-        }
-        iv_pre[k] = acc;
-        iv_cnt = k;
-    }
-    __syncthreads();
-    const int nk = iv_cnt, runs = iv_pre[nk];
-    const int tiles4 = ntile * 4;
-    san_fin_merge<kT>(f, [&](int ch, int e) -> const float* {
-        const int r = e >> 2, w = e & 3;
-        int k = 0;
-        for (int j = 1; j < nk; ++j) k += r >= iv_pre[j] ? 1 : 0;
-        const int slot = (iv_lo[k] + r - iv_pre[k]) * 4 + w;
-        return part + ((size_t)(iv_n[k] * cout + ch) * tiles4 + slot) * 3;
-    }, runs * 4, N, cout, n_lo, red);
-}
 
 // MBF full blocks of 16 output channels + (REM > 0) one partial block of REM channels; OCC = resident waves per SIMD the
 // register allocation aims at
@@ -290,6 +248,7 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
             inInvS = __builtin_bit_cast(float, (uint32_t)(e - 13) << 23);
         }
     }
+    if (NPRT == 2 && a.w_tail) inInvS *= a.w_tail[1];    // fp16-format weights may be stored x S_w (round 6): exact power of two
     // lazy-affine table of image n: [chunk][scale 24 | shift 24]
     auto load_aff = [&](int n_) {
         if (tid < a.chunks * 48) {
@@ -329,13 +288,6 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
     }
-
-    // fin mode: this wave's statistics merged over the tiles of its current run (lanes kg == 0: channel 16 m + nn)
-    const bool fin_on = a.part != nullptr && a.fin.ticket != nullptr;
-    float run_mean[MB], run_m2[MB];
-    int run_tiles = 0, run_first = 0;
-#pragma unroll
-    for (int m = 0; m < MB; ++m) run_mean[m] = run_m2[m] = 0.f;
 
     if (!multi) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the resident weight image (and, once, the first prefetch)
     for (;;) {
@@ -471,7 +423,7 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
                     acc[MBF][b] = f4{e[0], e[1], e[2], e[3]};
                 }
             }
-            if (a.amax) {
+            if (a.amax || a.w_tail) {                   // (1 / S of a gradient input and / or 1 / S_w of scaled fp16 weights)
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -502,23 +454,11 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
                     s1 += __shfl_xor(s1, 32, 64);
                     s2 += __shfl_xor(s2, 32, 64);
                     const int co = 16 * m + nn;
-                    const float mean_t = pilot + s1 * (1.f / 64.f), m2_t = fmaxf(s2 - s1 * s1 * (1.f / 64.f), 0.f);
-                    if (fin_on) {
-                        // Chan's merge of this tile's (64, mean, M2) into the run's (64 run_tiles, mean, M2)
-                        if (run_tiles == 0) {
-                            run_mean[m] = mean_t;
-                            run_m2[m] = m2_t;
-                        } else {
-                            const float na = 64.f * (float)run_tiles, nab = na + 64.f;
-                            const float d = mean_t - run_mean[m];
-                            run_mean[m] += d * (64.f / nab);
-                            run_m2[m] += m2_t + d * d * (na * 64.f / nab);
-                        }
-                    } else if (kg == 0 && co < a.cout) {
+                    if (kg == 0 && co < a.cout) {
                         float* o = a.part + ((size_t)(n * a.cout + co) * tiles + tile * 4 + wave) * 3;
                         o[0] = 64.f;
-                        o[1] = mean_t;
-                        o[2] = m2_t;
+                        o[1] = pilot + s1 * (1.f / 64.f);
+                        o[2] = fmaxf(s2 - s1 * s1 * (1.f / 64.f), 0.f);
                     }
                 }
             }
@@ -532,23 +472,6 @@ __global__ void __launch_bounds__(kT, OCC) conv3x3_stream_kernel(const SArgs a) 
                     const int q = 64 * wave + 16 * b + 4 * kg;
                     if (co < a.cout && !(a.abl & 16)) *reinterpret_cast<f4*>(dst + (y0 + (q >> 5)) * W + x0 + (q & 31)) = acc[m][b];
                     acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            if (fin_on) {
-                if (run_tiles == 0) run_first = tile;
-                ++run_tiles;
-                if (!more || nn_ != n) {                // the run ends here: one record per wave and channel, then the sample's ticket
-                    const int tiles = ntile * 4;
-#pragma unroll
-                    for (int m = 0; m < MB; ++m) {
-                        const int co = 16 * m + nn;
-                        if (kg == 0 && co < a.cout)
-                            san_stat_store(a.part + ((size_t)(n * a.cout + co) * tiles + run_first * 4 + wave) * 3, 64.f * (float)run_tiles,
-                                           run_mean[m], run_m2[m], true);
-                    }
-                    if (san_fin_arrive<kT>(a.fin, n, (unsigned)run_tiles))
-                        stream_fin_merge(a.fin, a.part, a.N, a.cout, ntile, a.total, per_xcd, n);
-                    run_tiles = 0;
                 }
             }
         }
@@ -623,15 +546,16 @@ int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot)
     if (cin > 4 * kCKC) return 0;
     if (!(cout == 18 || cout == 32 || cout == 36 || cout == 16 || cout == 48)) return 0;
     if ((unsigned long long)n * x_ctot * h * w * 4ull >= 0x7fffffffull) return 0;
-    return stream_lds_bytes(cin, cout) <= 160 * 1024 - 8 * 1024 ? 1 : 0;      // everything resident (+ 7 KB of static LDS: the in-kernel finalisation's scratch)
+    return stream_lds_bytes(cin, cout) <= 160 * 1024 ? 1 : 0;      // everything resident
 }
 
 }  // extern "C"
 
 int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const float* in_scale, const float* in_shift, float in_slope,
                         const void* w_packed, int nblkp, const float* bias, float* y, int y_ctot, int y_coff, int cout, float* part_stats,
-                        const void* amax, int n, int h, int w, void* stream, int nprt, const SanFin* fin) {
+                        const void* amax, int n, int h, int w, void* stream, int nprt, const float* w_tail) {
     SArgs a{};
+    a.w_tail = w_tail;
     a.x = x;
     a.in_scale = in_scale;
     a.in_shift = in_shift;
@@ -655,10 +579,6 @@ int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const f
     a.chunks = san_cdiv(cin, kCKC);
     a.nblkp = nblkp;
     a.total = n * a.tiles_x * a.tiles_y;
-    if (fin && fin->ticket && part_stats && !(fin->batch && n + 8 > kFinIv)) {
-        a.fin = *fin;
-        a.fin.expected = (unsigned)(fin->batch ? a.total : a.tiles_x * a.tiles_y);     // arrivals are counted in tiles
-    }
     a.x_bytes = (unsigned)((size_t)n * x_ctot * h * w * 4);
     a.w_bytes = (unsigned)((size_t)a.chunks * kSteps * nblkp * 3 * 64 * 16);
     auto magic = [&](int d) -> unsigned {
@@ -690,5 +610,5 @@ int san_conv_stream_run(const float* x, int x_ctot, int x_coff, int cin, const f
     }
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
-    return a.fin.ticket ? 1 : SAN_OK;                  // 1: the launch finalised the normalisation statistics itself (san_fin.h)
+    return SAN_OK;
 }

@@ -713,6 +713,30 @@ class _PackRegistry:
 PACKS = _PackRegistry()
 
 
+def _scale_tail_one(buf: torch.Tensor) -> torch.Tensor:
+    """The 16 bytes behind a packed image hold the tensor's power-of-two scale {S_w, 1 / S_w} (fp8 format always, fp16 format when
+    f16_weight_scale is on): {1, 1} until a scale pass writes them."""
+    buf[-16:-8].view(torch.float32).fill_(1.0)
+    return buf
+
+
+F16_WSCALE = [os.environ.get("SAN_F16_WSCALE", "0") == "1"]
+
+
+def f16_weight_scale(on: bool) -> bool:
+    """Switch the per-tensor power-of-two scale of the fp16-format weight images (san_conv_f16_wscale_enable, round 6) on or off;
+    returns the previous setting.  Every registered image is re-packed (scaled, or unscaled with its scale words back at 1)."""
+    prev = bool(lib().query("san_conv_f16_wscale_enable", 1 if on else 0))
+    F16_WSCALE[0] = bool(on)
+    for j in PACKS16.jobs.values():
+        if j["mode"] & 16:
+            _scale_tail_one(j["packed"])
+            j["version"] = -1
+    PACKS16.table = None
+    PACKS16.epoch = -1
+    return prev
+
+
 class _PackRegistryBf16(_PackRegistry):
     """The same bookkeeping for the bf16x3 kernels' weight images (csrc/san_conv_bf16.hip): mode 0 forward,
     mode 2 data gradient; dims = (cout, cin) of the convolution that will run."""
@@ -724,15 +748,15 @@ class _PackRegistryBf16(_PackRegistry):
     def _alloc_zeroed(self, w: torch.Tensor, mode: int):
         mode &= 15                                      # (+16 = two fp16 parts, +32 = one fp8 part instead of bf16 parts: same image size)
         if mode == 3:                                   # ConvTranspose2d [Cin, Cout, 2, 2] as a 1x1 conv to 4 Cout channels
-            return (4 * w.shape[1], w.shape[0], 1), torch.zeros(
-                lib().query("san_conv_bf16x3_packed_bytes_ks", 4 * w.shape[1], w.shape[0], 1), device=w.device, dtype=torch.uint8)
+            return (4 * w.shape[1], w.shape[0], 1), _scale_tail_one(torch.zeros(
+                lib().query("san_conv_bf16x3_packed_bytes_ks", 4 * w.shape[1], w.shape[0], 1), device=w.device, dtype=torch.uint8))
         if mode == 2:
             cout, cin = w.shape[1], w.shape[0]          # the data-gradient conv maps forward cout -> forward cin
         else:
             cout, cin = w.shape[0], w.shape[1]
         ks = int(w.shape[2])
         nbytes = lib().query("san_conv_bf16x3_packed_bytes_ks", cout, cin, ks)
-        return (cout, cin, ks), torch.zeros(nbytes, device=w.device, dtype=torch.uint8)     # (zero-filled: the batched pack skips constant-zero units)
+        return (cout, cin, ks), _scale_tail_one(torch.zeros(nbytes, device=w.device, dtype=torch.uint8))     # (zero-filled: the batched pack skips constant-zero units)
 
     def _fill_job(self, row, j):
         cout, cin, ks = j["dims"]
@@ -764,7 +788,7 @@ class _PackRegistryBf16(_PackRegistry):
         if stale:
             self.classes = []                       # (first job, count, workgroups per job, any fp8 image)
             for i, j in enumerate(self.order):
-                b, f8 = self._blocks(j), 1 if (j["mode"] & 32) else 0
+                b, f8 = self._blocks(j), 1 if ((j["mode"] & 32) or ((j["mode"] & 16) and F16_WSCALE[0])) else 0     # (images with a per-tensor scale: the wscale pass)
                 if self.classes and self.classes[-1][2] == b:
                     first, cnt, _, f = self.classes[-1]
                     self.classes[-1] = (first, cnt + 1, b, f | f8)
@@ -936,52 +960,19 @@ def packed_weight(w: torch.Tensor, transposed: bool = False) -> torch.Tensor:
     return PACKS.get(w, 1 if transposed else 0)
 
 
-# In-kernel finalisation of the normalisation statistics by the last workgroup of a reduction domain (csrc/san_fin.h, round 6,
-# VERDICT r5 item 1a).  Built, parity-green (tests/test_norm_forward.py) -- and OFF by default: measured per layer (N = 8, same box,
-# scratch/r6_fin_layers.py, profiles/r06_fin_inkernel_layers.txt) the convolution + its finalisation take 4-34 us LONGER in one launch
-# than in two (18->18 @320^2 58.2 -> 63.9 us, 72->72 @80^2 36.0 -> 43.5, transposed 36->18 @160^2 42.6 -> 76.1; whole step 42.6 ->
-# 48.8 ms): every workgroup waits for its record stores and for the ticket's round trip, and the last arriver's merge (acquire fence,
-# a few thousand records, double-precision Chan updates, LDS folds) is a 10 us serial tail where the separate launch costs ~6.
-# SAN_FIN_INKERNEL=1 switches it on (A/B runs, tests).
-FIN_INKERNEL = [os.environ.get("SAN_FIN_INKERNEL", "0") == "1"]
-
-
-def _fin_ticket(n: int, device, arena: "Arena") -> torch.Tensor:
-    """The arrival counters of the in-kernel normalisation finalisation (san_conv_bf16x3_fwd_fin): n int32 words that are zero
-    between launches (every launch leaves them zero), so ONE buffer per arena serves every layer."""
-    return arena.get("fin_ticket", (max(int(n), 1),), device, dtype=torch.int32, zero=True)
-
-
-def _bf16x3_launch(ks: int, bargs, n: int, h: int, w: int, cin: int, cout: int, device, arena: "Arena", fin=None, bn=None) -> bool:
+def _bf16x3_launch(ks: int, bargs, n: int, h: int, w: int, cin: int, cout: int, device, arena: "Arena", fin=None) -> bool:
     """bargs = the arguments of san_conv2d_bf16x3_fwd (stream last).  3x3 layers that the library wants to split over K
     (deep K, few tiles: san_conv_bf16x3_ws_bytes > 0) get the scratch for the partial outputs.  fin = (scale, shift, coff,
-    eps) of a following InstanceNorm, bn = (scale, shift, coff, eps, gamma, beta, bmean, bvar, rmean, rvar, nbt, momentum, factor)
-    of a following training BatchNorm: the launch finalises the lazy affine itself where it can -- the last workgroup of a
-    reduction domain merges the records (round 6), a split launch in its reduction pass -- and True is returned."""
-    nbytes = lib().query("san_conv_bf16x3_ws_bytes", n, h, w, cin, cout, 3) if ks == 3 else 0
-    ws = arena.scratch("b16_splitk", nbytes, device) if nbytes else None
-    has_part = bargs[13] is not None
-    if has_part and (fin is not None or bn is not None) and FIN_INKERNEL[0]:
-        done = ctypes.c_int(0)
-        if _lib.KEEP is not None:
-            _lib.KEEP.append(done)              # its address is part of the recorded call
-        if bn is None:
-            scale, shift, coff, eps = fin
-            lib().call("san_conv_bf16x3_fwd_fin", *bargs[:-1], ks, _p(ws), nbytes, _p(scale), _p(shift), int(scale.shape[1]), int(coff),
-                       float(eps), _p(_fin_ticket(n, device, arena)), ctypes.c_void_p(ctypes.addressof(done)), bargs[-1])
-        else:
-            scale, shift, coff, eps, gamma, beta, bmean, bvar, rmean, rvar, nbt, momentum, factor = bn
-            lib().call("san_conv_bf16x3_fwd_fin_bn", *bargs[:-1], ks, _p(scale), _p(shift), int(scale.shape[1]), int(coff), float(eps),
-                       _p(gamma), _p(beta), _p(bmean), _p(bvar), _p(rmean), _p(rvar), _p(nbt), float(momentum), float(factor),
-                       _p(_fin_ticket(n, device, arena)), ctypes.c_void_p(ctypes.addressof(done)), bargs[-1])
-        return bool(done.value)
+    eps) of a following InstanceNorm: a split launch finalises the lazy affine in its reduction pass (returns True)."""
     if ks != 3:
         lib().call("san_conv1x1_bf16x3_fwd", *bargs)
         return False
+    nbytes = lib().query("san_conv_bf16x3_ws_bytes", n, h, w, cin, cout, 3)
     if nbytes == 0:
         lib().call("san_conv2d_bf16x3_fwd", *bargs)
         return False
-    if fin is not None and has_part:
+    ws = arena.scratch("b16_splitk", nbytes, device)
+    if fin is not None and bargs[13] is not None:
         scale, shift, coff, eps = fin
         done = ctypes.c_int(0)
         if _lib.KEEP is not None:
@@ -996,14 +987,12 @@ def _bf16x3_launch(ks: int, bargs, n: int, h: int, w: int, cin: int, cout: int, 
 def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, stats: bool = False,
            out_scale: Optional[torch.Tensor] = None, out_shift: Optional[torch.Tensor] = None,
            arena: Arena = GLOBAL_ARENA, tag: str = "", grad_input: bool = False,
-           instance_norm_eps: Optional[float] = None, batch_norm=None) -> Optional[torch.Tensor]:
+           instance_norm_eps: Optional[float] = None) -> Optional[torch.Tensor]:
     """y.buf[:, y.coff:y.coff+cout] = conv(T(x)) (+bias).  Returns the per-tile
     statistics partials [N, cout, tiles, 3] when ``stats``.  ``grad_input``: x is a gradient (arbitrary magnitude):
     keep the bf16 operand split, whose exponent range is fp32's.  ``instance_norm_eps``: the layer is followed by
-    InstanceNorm2d on y (y.scale / y.shift): where the launch can finalise that affine itself it does (the last workgroup of each
-    sample merges the statistics, round 6; split-K layers in their reduction pass) and None is returned -- the caller runs
-    norm_finalize only on a returned tensor.  ``batch_norm`` = (eps, bn module, bmean, bvar, momentum, variance factor): the same
-    for a training-mode BatchNorm2d (the arguments of norm_finalize_bn)."""
+    InstanceNorm2d on y (y.scale / y.shift): where the launch can finalise that affine itself (split-K layers) it does and
+    None is returned -- the caller runs norm_finalize only on a returned tensor."""
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert cin == x.c and cout == y.c, (cin, x.c, cout, y.c)
     assert x.buf.shape[2:] == y.buf.shape[2:]
@@ -1027,16 +1016,10 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
                  y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
         fin = (y.scale, y.shift, y.coff, instance_norm_eps) if (instance_norm_eps is not None and stats and y.scale is not None) else None
-        bnf = None
-        if batch_norm is not None and stats and y.scale is not None:
-            eps, bnm, bmean, bvar, momentum, factor = batch_norm
-            bnf = (y.scale, y.shift, y.coff, eps, bnm.weight, bnm.bias, bmean, bvar, _chk(bnm.running_mean, name="running_mean"),
-                   _chk(bnm.running_var, name="running_var"), _chk(bnm.num_batches_tracked, torch.int64, "num_batches_tracked"),
-                   momentum, factor)
         done = [False]
 
         def _go():
-            done[0] = _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena, fin, bnf)
+            done[0] = _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena, fin)
 
         _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
                _go, _conv_abytes(n, h, w, cin, cout, ks), _products(fmt != 0))
@@ -1053,8 +1036,7 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
 
 
 def tconv2x2(x: Act, weight: torch.Tensor, y: Act, stats: bool = False, arena: Arena = GLOBAL_ARENA,
-             tag: str = "", instance_norm_eps: Optional[float] = None) -> Optional[torch.Tensor]:
-    """``instance_norm_eps``: as conv2d -- None is returned when the launch finalised y's InstanceNorm affine itself."""
+             tag: str = "") -> Optional[torch.Tensor]:
     cin, cout = weight.shape[0], weight.shape[1]
     assert cin == x.c and cout == y.c
     assert y.h == 2 * x.h and y.w == 2 * x.w
@@ -1064,15 +1046,6 @@ def tconv2x2(x: Act, weight: torch.Tensor, y: Act, stats: bool = False, arena: A
         if stats:
             tiles = 4 * lib().query("san_conv_bf16x3_stat_tiles", x.n, x.h, x.w)
             part = arena.get("tpart" + tag, (x.n, cout, tiles, 3), x.buf.device)
-        if stats and instance_norm_eps is not None and y.scale is not None and FIN_INKERNEL[0]:
-            done = ctypes.c_int(0)
-            if _lib.KEEP is not None:
-                _lib.KEEP.append(done)
-            fargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(None), _p(y.buf), y.ctot, y.coff,
-                     cout, _p(part), x.n, x.h, x.w, 2, _p(None), 0, _p(y.scale), _p(y.shift), int(y.scale.shape[1]), int(y.coff),
-                     float(instance_norm_eps), _p(_fin_ticket(x.n, x.buf.device, arena)), ctypes.c_void_p(ctypes.addressof(done)), _stream())
-            _timed("tconv2x2_bf16x3", 2.0 * x.n * x.h * x.w * 4 * cout * cin, "FLOP", lambda: lib().call("san_conv_bf16x3_fwd_fin", *fargs))
-            return None if done.value else part
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(y.buf), y.ctot, y.coff,
                  cout, _p(part), x.n, x.h, x.w, _stream())
         _timed("tconv2x2_bf16x3", 2.0 * x.n * x.h * x.w * 4 * cout * cin, "FLOP", lambda: lib().call("san_tconv2x2_bf16x3_fwd", *bargs))

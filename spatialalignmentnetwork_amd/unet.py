@@ -124,10 +124,8 @@ class UNet(torch.nn.Module):
             bmean = ARENA.get(f"{tag}.bmean", (c,), x.buf.device)
             bvar = ARENA.get(f"{tag}.bvar", (c,), x.buf.device)
             m, factor = _running_factors(bn, x.n * x.h * x.w, count_scale)
-            # (where the convolution can, its last workgroup finalises the batch statistics itself: None comes back)
-            part = ops.conv2d(x, conv.weight, conv.bias, out, stats=True, tag=tag, batch_norm=(BN_EPS, bn, bmean, bvar, m, factor))
-            if part is not None:
-                ops.norm_finalize_bn(part, BN_EPS, out.scale, out.shift, out.coff, bn, bmean, bvar, m, factor)
+            part = ops.conv2d(x, conv.weight, conv.bias, out, stats=True, tag=tag)
+            ops.norm_finalize_bn(part, BN_EPS, out.scale, out.shift, out.coff, bn, bmean, bvar, m, factor)
         else:
             ops.conv2d(x, conv.weight, conv.bias, out, stats=False)
             ops.bn_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var, BN_EPS,

@@ -110,10 +110,8 @@ class TransposeConvBlock(nn.Module):
     def run(self, x: Act, out: Act, tag: str, also: Optional[Act] = None) -> Act:
         """``also``: a second view whose (scale, shift) receive the same InstanceNorm affine (the reflect-padded copy
         of ``out`` inside the concatenation buffer, Unet.run)."""
-        # (the launch finalises the InstanceNorm affine itself where it can: None; the reflect-padded second view keeps the records)
-        part = ops.tconv2x2(x, self.layers[0].weight, out, stats=True, tag=tag, instance_norm_eps=IN_EPS if also is None else None)
-        if part is not None:
-            ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
+        part = ops.tconv2x2(x, self.layers[0].weight, out, stats=True, tag=tag)
+        ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, out.scale, out.shift, out.coff)
         if also is not None:
             ops.norm_finalize(part, ops.NORM_INSTANCE, IN_EPS, also.scale, also.shift, also.coff)
         return out

@@ -716,3 +716,53 @@ def test_round5_kernels_repeat_bit_identically(S):
             first = cur
         else:
             assert all(torch.equal(a, b) for a, b in zip(first, cur)), it
+
+
+# ------------------------------------------------------------------ round 6: operand RANGE of the fp16 two-part forward format
+@pytest.mark.parametrize("n,cin,cout,h,w,ks", [(2, 72, 72, 40, 40, 3), (1, 18, 18, 320, 320, 3), (2, 64, 64, 16, 32, 1), (1, 288, 144, 20, 20, 3)])
+@pytest.mark.parametrize("ws", [1e-4, 1.0, 50.0])
+@pytest.mark.parametrize("xs", [1e-5, 1.0, 3e4])
+def test_f16x2_forward_operand_ranges(S, n, cin, cout, h, w, ks, xs, ws):
+    """[round 6] The FORWARD fp16 two-part form over the operand ranges, on the tiled, persistent, one-stage GEMM and
+    split-K kernels; the input is read through a lazy affine that brings an O(1) tensor to magnitude `xs`, the weights are `ws`-sized.
+
+    WEIGHTS: fp16's range as it is by default (trained weights are O(0.01 - 1): every element then keeps >= 19 bits and the layer
+    3e-7); with the per-tensor power-of-two scale switched on (ops.f16_weight_scale(True) / SAN_F16_WSCALE=1: the packed image
+    holds w S_w, max |w| S_w in [2^13, 2^14), the accumulators get 1 / S_w) weights of ANY magnitude are exact to 22 bits --
+    asserted for 1e-4-sized and 50-sized tensors.  ACTIVATIONS have fp16's range as it is (normalised tensors are O(1) by
+    construction, images are <= 1): at |x| = 1e-5 the second part sits in the denormals and the format keeps only an ABSOLUTE
+    accuracy of 2^-25 per element -- asserted as such -- and the documented way out is the three-part bf16 form (fp32's exponent
+    range: ops.F16_FWD[0] = False / SAN_NO_F16X2=1), which holds 3e-6 there too."""
+    ops = S.ops
+    x = philox("rg.x", (n, cin, h, w))                  # (|activated input| <= 1.25 xs: 3.75e4 at the top, inside fp16's 65504)
+    wt = philox("rg.w", (cout, cin, ks, ks)) * ws
+    sc = torch.full((n, cin), xs)
+    sh = torch.full((n, cin), 0.25 * xs)
+    act = lambda t: torch.nn.functional.leaky_relu(t * xs + 0.25 * xs, 0.2)     # noqa: E731
+    y64 = torch.nn.functional.conv2d(act(x.double()), wt.double(), padding=ks // 2)
+
+    def run():
+        y = torch.empty((n, cout, h, w), device=DEV)
+        ops.conv2d(ops.Act(g(x), 0, cin, g(sc), g(sh), 0.2), g(wt), None, ops.full(y))
+        torch.cuda.synchronize()
+        return y.cpu().double()
+
+    assert ops.F16_FWD[0] and ops.lib().query("san_get_conv_precision") == 3
+    prev = ops.f16_weight_scale(ws != 1.0)              # (O(1) weights: the default, unscaled format)
+    try:
+        e16 = rel_err(run(), y64)
+        y16 = run()
+    finally:
+        ops.f16_weight_scale(prev)
+    if xs >= 1.0:
+        assert e16 < 3e-6, (xs, ws, e16)
+    else:
+        # the activations' absolute floor: |error| <= 2^-25 per element of the lazily activated input, times the weights it meets
+        bound = 2.0 ** -25 * wt.double().abs().sum(dim=(1, 2, 3)).max().item()
+        assert (y16 - y64).abs().max().item() <= 1.5 * bound
+        ops.F16_FWD[0] = False
+        try:
+            e3 = rel_err(run(), y64)
+        finally:
+            ops.F16_FWD[0] = True
+        assert e3 < 3e-6, (xs, ws, e3)
