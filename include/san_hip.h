@@ -345,6 +345,12 @@ int san_avgpool2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, co
 int san_norm_finalize_pool(const float* part, int n, int c, int tiles, float eps, float* scale, float* shift, int sc_ctot, int sc_coff,
                            const float* x, int x_ctot, int x_coff, float slope, float* y, int y_ctot, int y_coff, int h, int w,
                            void* stream);
+/* Channel `ch` of src [n, ctot, hw] (raw values) with its lazy-affine entries src_scale / src_shift [n, ctot] copied into `count`
+ * (<= 16) tensors of the same shape in ONE launch; dst / dst_scale / dst_shift are HOST arrays of `count` device pointers (read
+ * during the call).  The cascades' shared reference channel: NormUnet's `ref` input is InstanceNorm-ed once and concatenated into
+ * every cascade's U-Net input (varnet.py:315-319) -- three launches per cascade before. */
+int san_replicate_channel(const float* src, const float* src_scale, const float* src_shift, const void* dst, const void* dst_scale,
+                          const void* dst_shift, int count, int n, int ctot, int ch, int hw, void* stream);
 int san_upsample2_fwd(const float* x, int x_ctot, int x_coff, const float* sc, const float* sh, float slope,
                       float* y, int y_ctot, int y_coff, int n, int c, int h, int w, void* stream);
 /* y[n, 4c+2dy+dx, i, j] = x[n, c, 2i+dy, 2j+dx]: x [n,c,2h,2w] -> y [n,4c,h,w] (h, w = OUTPUT dims).

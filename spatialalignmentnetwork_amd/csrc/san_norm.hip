@@ -293,6 +293,36 @@ norm_finalize_pool_kernel(const float* __restrict__ part, int c, int tiles, floa
     }
 }
 
+// One lazily normalised channel -- its raw plane and its (scale, shift) entries -- copied from one tensor into up to 16 others of
+// the same shape (round 6).  The 12 cascades of a training step keep their own U-Net input buffers, and every one of them holds the
+// SAME InstanceNorm-ed reference image as channel 2 (varnet.py:315-319): set_ref ran apply + plane_stats + norm_finalize per cascade,
+// 36 launches of 4-10 us at the head of a step; now once, plus this launch.
+struct ReplArgs {
+    const float* src;
+    const float* ssc;
+    const float* ssh;
+    float* dst[16];
+    float* dsc[16];
+    float* dsh[16];
+    int ctot, ch, n, hw, count;
+};
+__global__ void __launch_bounds__(kThreads) replicate_channel_kernel(const ReplArgs a) {
+    const int n = blockIdx.y, k = blockIdx.z;
+    const size_t off = ((size_t)(n * a.ctot + a.ch)) * a.hw;
+    const float* sp = a.src + off;
+    float* dp = a.dst[k] + off;
+    if ((a.hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(sp) | reinterpret_cast<uintptr_t>(dp)) & 15) == 0) {
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < a.hw / 4; i += gridDim.x * kThreads)
+            reinterpret_cast<float4*>(dp)[i] = reinterpret_cast<const float4*>(sp)[i];
+    } else {
+        for (int i = blockIdx.x * kThreads + threadIdx.x; i < a.hw; i += gridDim.x * kThreads) dp[i] = sp[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.dsc[k][n * a.ctot + a.ch] = a.ssc[n * a.ctot + a.ch];
+        a.dsh[k][n * a.ctot + a.ch] = a.ssh[n * a.ctot + a.ch];
+    }
+}
+
 __global__ void __launch_bounds__(kThreads) upsample2_kernel(const EwArgs a) {
     const int ch = blockIdx.y, n = blockIdx.z;
     const int ow = a.w * 2;
@@ -518,6 +548,36 @@ int san_norm_finalize_pool(const float* part, int n, int c, int tiles, float eps
     if (K > 8) K = 8;
     hipLaunchKernelGGL(norm_finalize_pool_kernel, dim3(K, c, n), dim3(256), 0, (hipStream_t)stream, part, c, tiles, eps, scale, shift,
                        sc_ctot, sc_coff, x, x_ctot, x_coff, slope, y, y_ctot, y_coff, h, w);
+    SAN_LAUNCH_CHECK();
+    return SAN_OK;
+}
+
+// Channel `ch` of src [n, ctot, hw] (raw values) and its lazy-affine entries src_scale / src_shift [n, ctot] copied into `count`
+// (<= 16) tensors of the same shape: dst / dst_scale / dst_shift are HOST arrays of `count` device pointers.  The cascades' shared
+// reference channel (NormUnet.set_ref, varnet.py:315-319) in one launch instead of three per cascade.
+int san_replicate_channel(const float* src, const float* src_scale, const float* src_shift, const void* dst, const void* dst_scale,
+                          const void* dst_shift, int count, int n, int ctot, int ch, int hw, void* stream) {
+    SAN_CHECK_ARG(src && src_scale && src_shift && dst && dst_scale && dst_shift, "null pointer");
+    SAN_CHECK_ARG(count >= 1 && count <= 16 && n > 0 && hw > 0 && ch >= 0 && ch < ctot, "bad dims (count <= 16)");
+    ReplArgs a{};
+    a.src = src;
+    a.ssc = src_scale;
+    a.ssh = src_shift;
+    for (int k = 0; k < count; ++k) {
+        a.dst[k] = static_cast<float* const*>(dst)[k];
+        a.dsc[k] = static_cast<float* const*>(dst_scale)[k];
+        a.dsh[k] = static_cast<float* const*>(dst_shift)[k];
+        SAN_CHECK_ARG(a.dst[k] && a.dsc[k] && a.dsh[k], "null destination");
+    }
+    a.ctot = ctot;
+    a.ch = ch;
+    a.n = n;
+    a.hw = hw;
+    a.count = count;
+    int bx = san_cdiv(hw, kThreads * 8);
+    if (bx < 1) bx = 1;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(replicate_channel_kernel, dim3(bx, n, count), dim3(kThreads), 0, (hipStream_t)stream, a);
     SAN_LAUNCH_CHECK();
     return SAN_OK;
 }

@@ -83,7 +83,7 @@ class CSModel(BaseModel):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.memo_init = set(self.__dict__.keys()) | {"memo_init", "_aux_abs", "_replicas_synced", "conv_dtype", "bwd_dtype", "_san_arena", "_exchange",
-                                                         "_exchange_events", "_exchange_wait_events", "exchange_slices", "_aux_stream", "_split_capture", "time_exchange", "_auto", "_auto_cache", "_auto_busy", "auto_record", "step_mode", "_input_pending"}
+                                                         "_exchange_events", "_exchange_wait_events", "exchange_slices", "_aux_stream", "_split_capture", "time_exchange", "_auto", "_auto_cache", "_auto_busy", "auto_record", "step_mode", "_input_pending", "_sens_mark"}
 
     def build(self, cfg):
         super().build(cfg)
@@ -174,22 +174,36 @@ class CSModel(BaseModel):
         (1.9 of the 4.4 ms in front of the first cascade); VarNet._forward_impl joins.  Backward likewise (VarNet._backward_impl:
         1.2 ms beside the alignment network's 4.3 ms).  SAN_SENS_OVERLAP=0: in line, as the reference orders them."""
         R = self.net_R
-        if not SENS_OVERLAP[0] or self.device.type != "cuda" or not hasattr(R, "sens_net") or not hasattr(self, "img_k_sampled"):
+        mark = self.__dict__.pop("_sens_mark", None)
+        if mark is None:
             return
-        aux = self.__dict__.get("_aux_stream")
-        if aux is None:
-            aux = self._aux_stream = torch.cuda.Stream(device=self.device)
+        aux = self._aux_stream
         arena = ops.owner_arena(R.sens_net)
         main = torch.cuda.current_stream()
-        ops.ensure_packs(self.device)                   # (stale weight images are re-packed on the main stream, before the fork)
         mk = self.img_k_sampled.detach().contiguous()
         nlf = int(self.cfg.shape * self.cfg.sparsity * 0.32)
-        _lib.rec(aux.wait_stream, main)
+        _lib.rec(aux.wait_event, mark)                  # (everything the sensitivity network reads was queued before the mark)
         with ops.aux_region(aux, arena):
             sens = R.sens_net(mk, nlf)
         R._sens_pre = (sens, (mk.data_ptr(), tuple(mk.shape), nlf), aux, arena)
         if _SENS_DBG == 2:
             _lib.rec(main.wait_stream, aux)
+
+    def _sens_mark_fork(self) -> None:
+        """The POINT of the main stream the sensitivity branch forks from (an event; stale weight images are re-packed first).
+        The branch's ~200 launches are queued LATER, by _sens_fork at the end of forwardT: queued here, in front of the alignment
+        network's launches, they kept the host busy for 0.55 ms during which the main queue had nothing to run (round 6,
+        profiles/r06_main_queue_gaps.txt) -- now the host feeds the main stream first and the auxiliary one while that runs."""
+        R = self.net_R
+        if not SENS_OVERLAP[0] or self.device.type != "cuda" or not hasattr(R, "sens_net") or not hasattr(self, "img_k_sampled"):
+            return
+        if self.__dict__.get("_aux_stream") is None:
+            self._aux_stream = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        ops.ensure_packs(self.device)                   # (on the main stream, before the fork point)
+        ev = _lib.light(torch.cuda.Event())
+        _lib.rec(ev.record, main)
+        self._sens_mark = ev
 
     def _sens_join(self) -> None:
         """The main stream waits for the sensitivity network's backward (its gradients are read by the exchange / the optimiser)."""
@@ -200,7 +214,7 @@ class CSModel(BaseModel):
     @_own_arena
     def forwardT(self):
         """model.py:142-155."""
-        self._sens_fork()
+        self._sens_mark_fork()
         aux_abs = ops.cabs(self.img_aux)
         self._aux_abs = aux_abs
         self.img_offset, self.img_grid = self.net_T(moving=aux_abs, fixed=ops.cabs(self.img_sampled))
@@ -209,6 +223,7 @@ class CSModel(BaseModel):
         self.loss_smooth = gradient_loss(self.img_offset)
         with _lib.untracked():                   # (host-visible scalar arithmetic: the direct backward does not read it)
             self.loss_all = self.loss_all + self.loss_smooth * self.cfg.weight_smooth
+        self._sens_fork()                        # (the sensitivity branch's launches: queued behind the alignment network's, see _sens_mark_fork)
 
     @_own_arena
     def forwardR(self):

@@ -1077,6 +1077,23 @@ def norm_finalize_pool(part: torch.Tensor, eps: float, x: Act, y: Act) -> None:
                _p(x.buf), x.ctot, x.coff, float(x.slope), _p(y.buf), y.ctot, y.coff, x.h, x.w, _stream())
 
 
+def replicate_channel(src: Act, dsts, ch: int) -> None:
+    """Channel ``ch`` of ``src`` -- raw plane and its (scale, shift) entries -- copied into every Act of ``dsts`` (same shapes), 16
+    per launch (san_replicate_channel): the cascades' shared, once-normalised reference channel."""
+    n, ctot, hw = src.n, src.ctot, src.h * src.w
+    for k0 in range(0, len(dsts), 16):
+        grp = dsts[k0:k0 + 16]
+        for d in grp:
+            assert tuple(d.buf.shape) == tuple(src.buf.shape) and d.scale is not None and tuple(d.scale.shape) == tuple(src.scale.shape)
+        arr = (ctypes.c_void_p * (3 * len(grp)))(*([d.buf.data_ptr() for d in grp] + [d.scale.data_ptr() for d in grp] +
+                                                  [d.shift.data_ptr() for d in grp]))
+        if _lib.KEEP is not None:
+            _lib.KEEP.append(arr)               # host memory the recorded call reads again at every replay
+        base, step = ctypes.addressof(arr), 8 * len(grp)
+        lib().call("san_replicate_channel", _p(src.buf), _p(src.scale), _p(src.shift), base, base + step, base + 2 * step, len(grp),
+                   n, ctot, int(ch), hw, _stream())
+
+
 def plane_stats(x: Act, arena: Arena = GLOBAL_ARENA, tag: str = "") -> torch.Tensor:
     tiles = lib().query("san_plane_stat_tiles", x.h * x.w)
     part = arena.get("pstat" + tag, (x.n, x.c, tiles, 3), x.buf.device)

@@ -732,12 +732,13 @@ class VarNet(nn.Module):
         # training: every cascade keeps its own activations, state and data-consistency residual
         x = ARENA.get("cas.x0", (n, c, h, w), dev, dtype=torch.complex64)
         ops.fft2c(masked_kspace, inverse=True, out=x)
-        xins = []
-        for j, cascade in enumerate(self.cascades):
-            xin = cascade.model.input_buffer(n, h, w, dev, f"cas{j}")
-            if self.use_ref:
-                cascade.model.set_ref(xin, ref1)
-            xins.append(xin)
+        xins = [cascade.model.input_buffer(n, h, w, dev, f"cas{j}") for j, cascade in enumerate(self.cascades)]
+        if self.use_ref and T:
+            # every cascade reads the SAME InstanceNorm-ed reference as channel 2 of its own input buffer (varnet.py:315-319):
+            # normalised once, then copied (plane + affine entries) into the other buffers by one launch
+            self.cascades[0].model.set_ref(xins[0], ref1)
+            if T > 1:
+                ops.replicate_channel(xins[0], xins[1:], 2)
         if join_sens is not None:
             join_sens()
         if T:
