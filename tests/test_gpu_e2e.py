@@ -455,8 +455,8 @@ def test_train_step_full_320_golden(S, tag, damp):
               f"probe-estimated relative L2 vs ref32 {pe32:.2e}, vs ref64 {pe64:.2e}; reference fp32-vs-fp64: exact "
               f"{floor:.2e}, probe-estimated {floor_probe:.2e}, worst per-tensor norm {floor_norm:.2e}")
         # no further from the fp64 truth than 3x the reference's own fp32 run, measured with the same estimators
-        assert pe64 < max(3.0 * max(floor, floor_probe), 2e-3), (nt, pe64, floor, floor_probe)
-        assert wn64 < max(3.0 * max(floor, floor_norm), 2e-3), (nt, wn64, name64, floor, floor_norm)
+        assert pe64 < max(3.0 * max(floor, floor_probe), 5e-4), (nt, pe64, floor, floor_probe)
+        assert wn64 < max(3.0 * max(floor, floor_norm), 5e-4), (nt, wn64, name64, floor, floor_norm)
     if tag == "raw":
         for k_ in gold.files:
             if k_.startswith("f32.bn_after.T."):
@@ -645,7 +645,7 @@ def test_mixed_backward_precision_full_320(S):
         wn64, name64, pe64 = _digest_errors_r2(S, named, gold, f"{tag}.f64.grad.{nt}.")
         print(f"mixed backward, net_{nt}: probe-estimated relative L2 vs ref64 {pe64:.2e}, worst per-tensor norm {wn64:.2e} "
               f"({name64}); reference fp32-vs-fp64 {floor:.2e}")
-        assert pe64 < max(3.0 * floor, 2e-3) and wn64 < max(3.0 * floor, 2e-3)
+        assert pe64 < max(3.0 * floor, 5e-4) and wn64 < max(3.0 * floor, 5e-4)
 
 
 def test_fp8_mode_e2e_psnr_and_train_step(S):
@@ -928,8 +928,8 @@ def test_train_step_bench_batch_n8_golden(S):
         print(f"[n8] net_{nt}: per-tensor norm error vs ref64 {wn64:.2e} ({name64}), vs ref32 {wn32:.2e}; probe-estimated relative "
               f"L2 vs ref64 {pe64:.2e}, vs ref32 {pe32:.2e}; reference fp32-vs-fp64: exact {floor:.2e}, probe-estimated "
               f"{floor_probe:.2e}, worst per-tensor norm {floor_norm:.2e}")
-        assert pe64 < max(3.0 * max(floor, floor_probe), 2e-3), (nt, pe64, floor, floor_probe)
-        assert wn64 < max(3.0 * max(floor, floor_norm), 2e-3), (nt, wn64, name64, floor, floor_norm)
+        assert pe64 < max(3.0 * max(floor, floor_probe), 5e-4), (nt, pe64, floor, floor_probe)
+        assert wn64 < max(3.0 * max(floor, floor_norm), 5e-4), (nt, wn64, name64, floor, floor_norm)
     for k_ in gold.files:
         if k_.startswith("f32.bn_after.T."):
             got = dict(net.net_T.named_buffers())[k_[len("f32.bn_after.T."):]]
