@@ -76,7 +76,7 @@ def _host_cores():
 # A replayed step keeps ~1.8 host cores busy per rank with HIP's direct dispatch: the launching thread spins inside the runtime
 # while the launch queue is full (the tape itself takes 3 ms per step) and a runtime thread handles completions.  With
 # AMD_DIRECT_DISPATCH=0 the runtime queues commands to its own thread instead: 0.17 cores per rank, the step 7 % slower
-# (measured, profiles/r04_host_env.txt).  On a node with fewer than three cores per rank the former leaves nothing for RCCL's own threads and starves the GPUs, so the
+# (measured, profiles/history/r04_host_env.txt).  On a node with fewer than three cores per rank the former leaves nothing for RCCL's own threads and starves the GPUs, so the
 # setting is chosen here, before the HIP runtime loads; an explicit AMD_DIRECT_DISPATCH in the environment wins.
 _LOCAL_WORLD = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
 if _LOCAL_WORLD > 1 and "AMD_DIRECT_DISPATCH" not in os.environ and _host_cores() // _LOCAL_WORLD < 3:
@@ -686,7 +686,7 @@ def main(argv=None):
             # HBM bytes per launch, algorithmic bytes and MFMA-busy fractions from the committed PMC passes of THIS workload
             # (separate rocprofv3 --pmc runs, corrected as the file states); bench.py itself cannot run the profiler
             pmc, pmc_file = {}, None
-            for cand in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc_traffic.json"):
+            for cand in ("r06_pmc.json", "r05_pmc.json", "history/r04_pmc.json", "history/r03_pmc.json"):
                 try:
                     pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))["kernels"]
                     pmc_file = cand

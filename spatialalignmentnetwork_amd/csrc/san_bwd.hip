@@ -734,10 +734,11 @@ __device__ __forceinline__ void dy_store(float* __restrict__ base, int i, bf4 o,
 template <int V, int T>
 __device__ __forceinline__ void act_bwd_load(const bf4* __restrict__ gp, const bf4* __restrict__ yp, const float* __restrict__ q2,
                                              const G2Src g2, int base, int n4, float s, float b, float slope, bf4 (&u)[V],
-                                             bf4 (&yh)[V], float& s1, float& s2) {
+                                             bf4 (&yh)[V], float& s1, float& s2, int tix = -1) {
+    const int tx = tix >= 0 ? tix : (int)threadIdx.x;   // index within the T threads that share the plane (chunk)
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-        const int i = min(base + (int)threadIdx.x + T * k, n4 - 1);
+        const int i = min(base + tx + T * k, n4 - 1);
         u[k] = gp[i];
         yh[k] = yp[i];
     }
@@ -746,7 +747,7 @@ __device__ __forceinline__ void act_bwd_load(const bf4* __restrict__ gp, const b
         bf2 v2[V];
 #pragma unroll
         for (int k = 0; k < V; ++k) {
-            const int i = min(base + (int)threadIdx.x + T * k, n4 - 1);
+            const int i = min(base + tx + T * k, n4 - 1);
             const int row = (int)(((float)i + 0.5f) * g2.inv_w4);           // exact for i < 2^22
             const int c4 = i - row * g2.w4;
             v2[k] = *reinterpret_cast<const bf2*>(q2 + (size_t)(row >> 1) * (2 * g2.w4) + 2 * c4);
@@ -761,7 +762,7 @@ __device__ __forceinline__ void act_bwd_load(const bf4* __restrict__ gp, const b
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-        const bool in = base + (int)threadIdx.x + T * k < n4;
+        const bool in = base + tx + T * k < n4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float t = in ? fmaf(yh[k][e], s, b) : 0.f;

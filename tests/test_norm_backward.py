@@ -185,3 +185,36 @@ def test_sync_records_carry_nothing_from_one_launch_to_the_next(S):
             if first[k] is None:
                 first[k] = [t.clone() for t in out]
             assert all(torch.equal(a, b) for a, b in zip(out, first[k]))
+
+
+@pytest.mark.parametrize("n,c,h,w,with_g2", [(8, 144, 40, 40, False), (8, 144, 40, 40, True), (8, 288, 20, 20, False), (2, 7, 20, 20, True),
+                                            (3, 5, 8, 16, False), (1, 3, 4, 4, False), (8, 72, 80, 80, True)])
+def test_small_planes_vs_autograd(S, n, c, h, w, with_g2):
+    """InstanceNorm + LeakyReLU backward of the small planes (80 x 80 down to 4 x 4: the one-workgroup plane kernel) against float64
+    autograd, plain, with the half-resolution second source, and with the pixel-unshuffled store (== act_bwd + unshuffle2 bit for
+    bit).  (Round 6 also tried one WAVE per plane for <= 40 x 40 -- no barrier, no LDS: correct, and no faster in the step,
+    41.18 / 41.07 vs 41.03 / 41.40 ms same box; not kept.)"""
+    ops = S.ops
+    gin = g(philox("sw.g", (n, c, h, w)) * 1e-3)
+    y = g(philox("sw.y", (n, c, h, w)) * 2 + 0.3)
+    g2 = g(philox("sw.g2", (n, c, h // 2, w // 2)) * 1e-3) if with_g2 else None
+    mean = y.double().mean((2, 3))
+    var = y.double().var((2, 3), unbiased=False)
+    sc = (1.0 / torch.sqrt(var + 1e-5)).float().contiguous()
+    sh = (-mean / torch.sqrt(var + 1e-5)).float().contiguous()
+    want = _in_autograd(gin, y, sc, sh, 0.2, g2)
+    ops.AMAX.reset(DEV)
+    dy = ops.Act(torch.full((n, c, h, w), float("nan"), device=DEV), 0, c)
+    ops.act_bwd(ops.full(gin), ops.Act(y, 0, c, sc, sh, 0.2), dy, instance_norm=True, g2=None if g2 is None else ops.full(g2))
+    torch.cuda.synchronize()
+    assert ((dy.buf.double() - want).abs().max() / want.abs().max()).item() < 5e-6
+    if dy.amax is not None:
+        assert abs(ops.amax_value(dy.amax) - dy.buf.abs().max().item()) <= 1e-12
+    if g2 is None and h % 2 == 0 and w % 4 == 0:
+        ops.AMAX.reset(DEV)
+        dyp = ops.Act(torch.zeros((n, 4 * c, h // 2, w // 2), device=DEV), 0, 4 * c)
+        ops.act_bwd_ex(ops.full(gin), ops.Act(y, 0, c, sc, sh, 0.2), dyp, instance_norm=True, unshuffle=True)
+        ref = ops.Act(torch.zeros((n, 4 * c, h // 2, w // 2), device=DEV), 0, 4 * c)
+        ops.unshuffle2(ops.Act(dy.buf, 0, c), ref)
+        torch.cuda.synchronize()
+        assert torch.equal(dyp.buf, ref.buf)
