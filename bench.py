@@ -294,8 +294,8 @@ def launch_test(args):
 ROCPROF_FAMILIES = {      # KernelTimer family -> kernel-name fragments of the rocprofv3 summary (all must match one of the alternatives)
     "conv3x3_bf16x3": (("conv_bf16x3_kernel<", ", 3, "), ("conv3x3_stream_kernel<",)),
     "wgrad3x3_bf16x3": (("wgrad_bf16x3_direct_kernel<",),),
-    "fft_dc": (("dc_rows320_kernel<0>",), ("dc_rows368_kernel<0>",)),
-    "fft_dc_bwd": (("dc_rows320_kernel<1>",), ("dc_rows368_kernel<1>",)),
+    "fft_dc": (("dc_rows320_kernel<0",), ("dc_rows368_kernel<0",)),
+    "fft_dc_bwd": (("dc_rows320_kernel<1",), ("dc_rows368_kernel<1",)),
     "act_bwd": (("act_bwd_kernel",), ("act_bwd_plane_kernel<",), ("bwd_stats_kernel",), ("act_bwd_coef_kernel",), ("act_bwd_cluster_kernel<",)),
     "conv3x3": (("conv_mfma_kernel<", ", 3, "), ("conv_direct_kernel<", ", 3, ")),
 }

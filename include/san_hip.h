@@ -565,6 +565,11 @@ int san_conv_bf16x3_debug_timeline(void* buf);   /* tuning: per-workgroup clock 
 int san_conv_bf16x3_set_tuning(int wd, int mb);   /* tests / tuning: weights-direct form (-1 auto, 0, 1), channel blocks per workgroup (-1 auto, 2..5) */
 size_t san_conv_bf16x3_packed_bytes(int cout, int cin);
 int san_conv_bf16x3_stat_tiles(int n, int h, int w);
+/* Statistics tiles of the 3x3 entry points below for THIS layer (round 6): the tile geometry of a 3x3 launch may depend on the batch and
+ * the channel counts (short full-width tiles where the default geometry leaves compute units idle), f16_format = 1 when the packed
+ * weights given to the launch hold two fp16 parts (mode + 16).  Same layout as san_conv_bf16x3_stat_tiles, which stays the count of the
+ * 1x1 / transposed forms.  (nn.Conv2d(3x3) + InstanceNorm2d statistics, varnet.py:139-146) */
+int san_conv3x3_bf16x3_stat_tiles(int n, int h, int w, int cin, int cout, int f16_format);
 int san_conv_bf16x3_pack(const float* w, void* packed, int cout, int cin, int mode, void* stream);
 int san_conv_bf16x3_pack_job(long long* job8, const float* w, void* packed, int cout, int cin, int mode);
 int san_conv_bf16x3_pack_batch(const long long* jobs_dev, int njobs, void* stream);

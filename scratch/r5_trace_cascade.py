@@ -1,5 +1,5 @@
 """One cascade of a traced training step, kernel by kernel: main-queue launches between two consecutive cascade-boundary launches
-(forward: dc_rows320_kernel<0>, backward: dc_rows320_kernel<1>) with start offset, duration and the gap in front of each."""
+(forward: dc_rows320_kernel<0, backward: dc_rows320_kernel<1) with start offset, duration and the gap in front of each."""
 import csv, glob, re, collections, sys
 fs = glob.glob("/tmp/ptrain/**/*kernel_trace.csv", recursive=True)
 rows = list(csv.DictReader(open(fs[0])))
@@ -18,7 +18,7 @@ def short(n):
     return m.group(1) if m else n[:40]
 ms = [r for r in seg if r[qkey] == main]
 t0 = int(ms[0]["Start_Timestamp"])
-for tag, which in (("forward", "dc_rows320_kernel<0>"), ("backward", "dc_rows320_kernel<1>")):
+for tag, which in (("forward", "dc_rows320_kernel<0"), ("backward", "dc_rows320_kernel<1")):
     pos = [i for i, r in enumerate(ms) if which in r["Kernel_Name"]]
     if len(pos) < 8:
         print(tag, "boundaries found:", len(pos)); continue
@@ -43,8 +43,8 @@ print("step span %.2f ms; main queue busy %.2f ms in %d launches; other queues b
     sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in ms) / 1e6, len(ms),
     sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg if r[qkey] != main) / 1e6, len(seg) - len(ms)))
 # the part of the step outside the cascades: before the first forward boundary and after the last backward boundary
-pf = [i for i, r in enumerate(ms) if "dc_rows320_kernel<0>" in r["Kernel_Name"]]
-pb = [i for i, r in enumerate(ms) if "dc_rows320_kernel<1>" in r["Kernel_Name"]]
+pf = [i for i, r in enumerate(ms) if "dc_rows320_kernel<0" in r["Kernel_Name"]]
+pb = [i for i, r in enumerate(ms) if "dc_rows320_kernel<1" in r["Kernel_Name"]]
 for tag, lo_, hi_ in (("head (set_input, packing, alignment + sensitivity forward)", 0, pf[0]), ("tail (sensitivity + alignment backward, optimiser)", pb[-1], len(ms))):
     seg_ = ms[lo_:hi_]
     print(f"==== {tag}: {len(seg_)} launches, {(int(seg_[-1]['End_Timestamp']) - int(seg_[0]['Start_Timestamp'])) / 1e3:.1f} us")

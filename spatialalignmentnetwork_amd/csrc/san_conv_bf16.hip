@@ -100,6 +100,7 @@ struct BArgs {
     int tiles_x, tiles_y, cgs, chunks, nblkp;   // nblkp: channel blocks in the packed image (>= cgs * MB)
     int S;                     // split-K: S workgroups share an output tile, each takes a contiguous range of the chunks
     float* ws;                 // [S][N][cout][H][W] partial outputs (S > 1); splitk_reduce_kernel adds them up
+    int nbw;                   // host only: 16-pixel blocks per wave of the launch (4, or 3 = the short-tile form, see tile_plan)
     int tw, th, hp, npx;       // tile width / height (tw * th <= 256 pixels, taken in flattened order), halo pitch tw + 2, halo pixels
     // Exact division by run-time constants without the ~25-instruction software divide (eight of them open every workgroup;
     // scratch/probe/wg_floor.hip: a dozen scalar divisions alone cost 1.7 us per 3,200-workgroup launch): q = umulhi(x, m)
@@ -208,8 +209,12 @@ __device__ __forceinline__ uint32_t cvt_f8x4(float f0, float f1, float f2, float
 // bytes per lane and the plane statistics are 16 in-lane values + two cross-row steps per channel.  Not for the pixel-shuffle
 // epilogue of the transposed form (there a lane must hold the four virtual channels of one real channel).
 // F8: the one-part fp8 e4m3 format (see kF8ActScale).
-template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16, bool F8>
+// NBW: 16-pixel blocks per wave (4: the 256-pixel tile; 3: full-width FLAT tiles of at most 192 pixels whose halo fits 256 staging
+// units -- round 6, for the 40^2 level: 40 x 4 tiles make 240 workgroups of three blocks per wave out of 168 of four, see tile_plan).
+template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16, bool F8, int NBW>
 __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3_kernel(const BArgs a) {
+    static_assert(NBW == 4 || (FLAT && KS == 3 && (NBW == 3 || NBW == 2)), "short tiles are a FLAT 3x3 form");
+    constexpr int kU = NBW == 4 ? kUnits : 3;          // staging units per thread (short tiles: halo <= 256 pixels, no fourth slot)
     static_assert(!F16 || NP == 2, "the fp16 format has two parts");
     static_assert(!F8 || (NP == 1 && !F16), "the fp8 format has one part");
     constexpr int kSteps = KS == 3 ? 7 : 1;            // (shadows the 3x3 constant)
@@ -256,10 +261,10 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
 
     // ---- staging units (pixel p, channel group chg): slots 0..2 = pixel tid of group s (the group, hence the
     // lazy-affine entries, is wave-uniform there), slot 3 = the remaining 84 pixels x 3 groups
-    int s_goff[kUnits], s_loff[kUnits], s_chg[kUnits];
-    bool s_in[kUnits], s_used[kUnits];
+    int s_goff[kU], s_loff[kU], s_chg[kU];
+    bool s_in[kU], s_used[kU];
 #pragma unroll
-    for (int s = 0; s < kUnits; ++s) {
+    for (int s = 0; s < kU; ++s) {
         int p, chg;
         bool used = true;
         if (s < 3) {
@@ -284,7 +289,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
     // The zero frame (halo pixels outside the image) is the same for every chunk: written ONCE here, and the staging
     // loop below stores in-image units only -- no per-element select (8 per unit per chunk before).
 #pragma unroll
-    for (int s = 0; s < kUnits; ++s)
+    for (int s = 0; s < kU; ++s)
         if (s_used[s] && !s_in[s]) {
             if constexpr (F8) {
                 *reinterpret_cast<uint2*>(smem + s_loff[s]) = make_uint2(0u, 0u);
@@ -294,7 +299,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             }
         }
 
-    float st[kUnits][8];
+    float st[kU][8];
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
     u32x4 wst[WSL];                                   // (a plain vector type: the struct uint4 copy kept this array in scratch)
     // The chunk's lazy affine (24 scales + 24 shifts of this sample) travels through a double-buffered LDS
@@ -340,12 +345,12 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
         xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x + (size_t)(n * a.x_ctot + a.x_coff) * HWp), 0,
                                                 (int)(ext > 0x7fffffffu ? 0x7fffffffu : ext), 0x00020000);
     }
-    unsigned s_boff[kUnits];
+    unsigned s_boff[kU];
 #pragma unroll
-    for (int s = 0; s < kUnits; ++s) s_boff[s] = (unsigned)s_goff[s] * 4u;
+    for (int s = 0; s < kU; ++s) s_boff[s] = (unsigned)s_goff[s] * 4u;
     auto prefetch = [&](int chunk) {
 #pragma unroll
-        for (int s = 0; s < kUnits; ++s) {
+        for (int s = 0; s < kU; ++s) {
             if (s < 3) {
                 const int c0 = chunk * kCKC + s * 8;
 #pragma unroll
@@ -374,11 +379,11 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
         }
     };
 
-    f4 acc[MB][4];
+    f4 acc[MB][NBW];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NBW; ++b) acc[m][b] = f4{0.f, 0.f, 0.f, 0.f};
 
     // ---- per-lane operand addressing.  B (activations): lane = (pixel nn = lane & 15, k-group kg = lane >> 4);
     // k-group g = 4 step + kg of the chunk is (tap = g / 3, channel group g % 3); group 27 is padding (zero weights).
@@ -397,11 +402,11 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
     }
     // block b of wave w = the 16 pixels 64 w + 16 b .. of the tile in flattened (row-major) order: any tile shape with
     // tw * th <= 256 works, a block may wrap from one tile row into the next (32 x 8: rows 2w, 2w+1 as before)
-    int boff[4], trow[4], tcol[4];
+    int boff[NBW], trow[NBW], tcol[NBW];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NBW; ++b) {
         if constexpr (FLAT) {
-            const int q = min(64 * wave + 16 * b + nn, tw * th - 1);
+            const int q = min(16 * NBW * wave + 16 * b + nn, tw * th - 1);
             trow[b] = fdiv(q, a.m_tw, tw);
             tcol[b] = q - trow[b] * tw;
         } else {
@@ -419,7 +424,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
 #if SAN_B16_HALFX
         Frag wa[2][MB][3], xa[2][2][3];              // activations: two half-sets (2 of a wave's 4 pixel blocks each)
 #else
-        Frag wa[2][MB][3], xa[2][4][3];
+        Frag wa[2][MB][3], xa[2][NBW][3];
 #endif
         const uint4* wsrc = a.wp + ((size_t)chunk * kSteps * a.nblkp + (size_t)cg * MB) * 192 + lane;      // (WD)
         auto load_w = [&](int s, Frag (&wq)[MB][3]) {
@@ -442,7 +447,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
         const float* afc = lds_aff + (chunk & 1) * 48;
         if (tid < 48) lds_aff[((chunk + 1) & 1) * 48 + tid] = my_aff;      // the NEXT chunk's table (prefetched below)
 #pragma unroll
-        for (int s = 0; s < kUnits; ++s) {
+        for (int s = 0; s < kU; ++s) {
             uint32_t q1[4], q2[4], q3[4];
             float vv[8];
             const f4 sc0 = *reinterpret_cast<const f4*>(afc + s_chg[s] * 8), sc1 = *reinterpret_cast<const f4*>(afc + s_chg[s] * 8 + 4);
@@ -500,10 +505,10 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                 }
         };
 #else
-        auto load_x = [&](int s, Frag (&xq)[4][3]) {
+        auto load_x = [&](int s, Frag (&xq)[NBW][3]) {
             const int to = tapoff[s];
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+            for (int b = 0; b < NBW; ++b)
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     if constexpr (F8) xq[b][p].l[0] = *reinterpret_cast<const long*>(lds_a + boff[b] + to);
@@ -563,7 +568,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) {
+                        for (int b = 0; b < NBW; ++b) {
                             if constexpr (F8) {
                                 if constexpr (SWAP)
                                     acc[m][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(xa[s & 1][b][px].l[0], wa[s & 1][m][pw].l[0], acc[m][b], 0, 0, 0);
@@ -605,17 +610,17 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
 #pragma unroll
         for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[m][b] = acc[m][b] * osc;
+            for (int b = 0; b < NBW; ++b) acc[m][b] = acc[m][b] * osc;
     }
     if constexpr (SWAP) {
         // acc[m][b][r] = output channel (cg MB + m) 16 + nn at the tile pixel r places after pixel 64 wave + 16 b + 4 kg
         const int cb0 = cg * MB * 16 + nn;
         const bool quad_ok = !FLAT || (tw & 3) == 0;    // FLAT tiles are full-width rows: a quad stays inside one row
-        int qy[4], qx[4];
-        bool vq[4], v1[4][4];
+        int qy[NBW], qx[NBW];
+        bool vq[NBW], v1[NBW][4];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int q = 64 * wave + 16 * b + 4 * kg;
+        for (int b = 0; b < NBW; ++b) {
+            const int q = 16 * NBW * wave + 16 * b + 4 * kg;
             int orow, ocol;
             bool oin = true;
             if constexpr (FLAT) {
@@ -648,13 +653,13 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     const int co = cb0 + 16 * m;
                     const float bv = co < a.cout ? a.bias[co] : 0.f;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[m][b] += f4{bv, bv, bv, bv};
+                    for (int b = 0; b < NBW; ++b) acc[m][b] += f4{bv, bv, bv, bv};
                 }
             }
             if (a.part) {
                 float cnt = 0.f;
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NBW; ++b)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) cnt += v1[b][r] ? 1.f : 0.f;
                 cnt += __shfl_xor(cnt, 16, 64);
@@ -666,7 +671,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                     const float pilot = __shfl(acc[m][0][0], nn, 64);      // the wave's first pixel of this channel
                     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
+                    for (int b = 0; b < NBW; ++b)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float e = v1[b][r] ? acc[m][b][r] - pilot : 0.f;
@@ -693,7 +698,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             if (co < a.cout) {
                 float* dst = ybase + (size_t)co * HWp;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < NBW; ++b) {
                     if (vq[b]) {
                         *reinterpret_cast<f4*>(dst + qy[b] * W + qx[b]) = acc[m][b];
                     } else if (quad_ok) {
@@ -704,7 +709,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (v1[b][r]) {
-                                const int q1 = 64 * wave + 16 * b + 4 * kg + r, rr = q1 / tw, cc = q1 - rr * tw;
+                                const int q1 = 16 * NBW * wave + 16 * b + 4 * kg + r, rr = q1 / tw, cc = q1 - rr * tw;
                                 dst[(y0 + rr) * W + x0 + cc] = acc[m][b][r];
                             }
                     }
@@ -716,13 +721,13 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
     }
     // acc[m][b][r] = output channel co = (cg MB + m) 16 + 4 (lane >> 4) + r at tile pixel (trow[b], tcol[b])
     const int cbase = cg * MB * 16 + 4 * kg;
-    int oy[4], ox[4];
-    bool valid[4];
+    int oy[NBW], ox[NBW];
+    bool valid[NBW];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < NBW; ++b) {
         oy[b] = y0 + trow[b];
         ox[b] = x0 + tcol[b];
-        valid[b] = (!FLAT || 64 * wave + 16 * b + nn < tw * th) && oy[b] < H && ox[b] < W;
+        valid[b] = (!FLAT || 16 * NBW * wave + 16 * b + nn < tw * th) && oy[b] < H && ox[b] < W;
     }
     if (a.S > 1) {
         // split-K: this workgroup covered only chunks [c0, c1): its partial sums go to slice sk of the scratch tensor;
@@ -735,7 +740,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                 if (co < a.cout) {
                     float* dst = a.ws + ((size_t)(sk * a.N + n) * a.cout + co) * HWp;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b)
+                    for (int b = 0; b < NBW; ++b)
                         if (valid[b]) dst[oy[b] * W + ox[b]] = acc[m][b][r];
                 }
             }
@@ -749,7 +754,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                 const int co = cbase + 16 * m + r;
                 const float bv = co < a.cout ? a.bias[co] : 0.f;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[m][b][r] += bv;
+                for (int b = 0; b < NBW; ++b) acc[m][b][r] += bv;
             }
     }
     if (a.part) {
@@ -757,7 +762,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
         // lanes of a DPP row hold the 16 pixels of a block, so four row-local DPP steps finish the sum
         float cnt = 0.f;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) cnt += valid[b] ? 1.f : 0.f;
+        for (int b = 0; b < NBW; ++b) cnt += valid[b] ? 1.f : 0.f;
         cnt += san_dpp_get<0xB1, 0xf>(cnt);
         cnt += san_dpp_get<0x4E, 0xf>(cnt);
         cnt += san_dpp_get<0x141, 0xf>(cnt);
@@ -772,7 +777,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
                 const float pilot = __shfl(acc[m][0][r], lane & 48, 64);
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) {
+                for (int b = 0; b < NBW; ++b) {
                     const float e = valid[b] ? acc[m][b][r] - pilot : 0.f;
                     s1 += e;
                     s2 = fmaf(e, e, s2);
@@ -806,7 +811,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             if (co < a.cout) {
                 float* dst = a.y + (size_t)(n * a.y_ctot + a.y_coff + (co >> 2)) * (4 * (size_t)HWp);
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NBW; ++b)
                     if (valid[b]) {
                         float* q = dst + (size_t)(2 * oy[b]) * (2 * W) + 2 * ox[b];
                         *reinterpret_cast<fl2v*>(q) = fl2v{acc[m][b][0], acc[m][b][1]};
@@ -824,7 +829,7 @@ __global__ void __launch_bounds__(kT, SAN_B16_MINWG(MB, WD, KS, NP)) conv_bf16x3
             if (co < a.cout) {
                 float* dst = a.y + (size_t)(n * a.y_ctot + a.y_coff + co) * HWp;
 #pragma unroll
-                for (int b = 0; b < 4; ++b)
+                for (int b = 0; b < NBW; ++b)
                     if (valid[b]) dst[oy[b] * W + ox[b]] = acc[m][b][r];
             }
         }
@@ -1041,6 +1046,8 @@ int g_b16_flat = 1;            // tuning hook (SAN_B16_FLAT=0): always 32 x 8 ti
 int g_b16_splitk = 4;          // tuning hook (SAN_B16_SPLITK=1 disables split-K, 2 / 4 = most parts per tile)
 int g_b16_splitcap = 1024;     // tuning hook (SAN_B16_SPLITCAP): most workgroups a split launch may have
 unsigned long long* g_b16_dbg = nullptr;
+int g_b16_wd_cold = 1;         // tuning hook (SAN_B16_WD_COLD=0): weights-direct also for launches of at most 256 workgroups (the round-5 choice)
+int g_b16_nbw = 0;             // tuning hook (SAN_B16_NBW): 0 automatic, 4 never the short-tile form, 3 wherever the geometry allows it
 int g_b16_swap = 1;            // tuning hook (SAN_B16_SWAP=0): the channel-per-register accumulator layout everywhere
 struct B16Env {
     B16Env() {
@@ -1050,6 +1057,8 @@ struct B16Env {
         if (const char* e = getenv("SAN_B16_SPLITK")) g_b16_splitk = atoi(e);
         if (const char* e = getenv("SAN_B16_SPLITCAP")) g_b16_splitcap = atoi(e);
         if (const char* e = getenv("SAN_B16_SWAP")) g_b16_swap = atoi(e);
+        if (const char* e = getenv("SAN_B16_NBW")) g_b16_nbw = atoi(e);
+        if (const char* e = getenv("SAN_B16_WD_COLD")) g_b16_wd_cold = atoi(e);
     }
 } g_b16_env;
 
@@ -1141,6 +1150,34 @@ int pick_mb_f16(int cin, int cout, int tiles) {
 }
 
 int g_conv_np = 3;             // operand parts of the bf16 convolutions / weight gradients (san_set_conv_precision)
+
+// Tile geometry of one 3x3 launch.  The default is tile_geom's (up to 256 pixels, four 16-pixel blocks per wave).  The SHORT form
+// (round 6, VERDICT r5 #1d: the 40^2 level leaves a third of the chip idle): full-width tiles of at most 192 pixels = three blocks per
+// wave, halo <= 256 staging units (three instead of four load slots per thread), chosen where the default launch does not fill the
+// 256 compute units and the short one has more workgroups that still run in one round -- 144 -> 144 @40^2, N = 8: 168 workgroups of
+// 40 x 6 -> 240 of 40 x 4, each with 3/4 of the matrix work and of the staging loads.  Two-fp16-part format only (the default mode).
+struct TilePlan {
+    TileGeom tg;
+    int nbw;
+};
+
+TilePlan tile_plan(int n, int h, int w, int cin, int cout, int ks, bool f16fmt, bool shuffle) {
+    TilePlan p{tile_geom(h, w), 4};
+    if (ks != 3 || !f16fmt || shuffle || g_conv_np != 3 || g_b16_nbw == 4) return p;
+    if (p.tg.tiles_x != 1 || p.tg.tw != w || (p.tg.tw == kTW && p.tg.th == kTH)) return p;      // only where the default is FLAT
+    int th = 192 / w;
+    if (th > h) th = h;
+    while (th > 1 && (w + 2) * (th + 2) > kT) --th;
+    if (th < 1 || w * th > 192 || (w + 2) * (th + 2) > kT) return p;
+    const int ty = san_cdiv(h, th), thb = san_cdiv(h, ty);
+    const int tiles4 = p.tg.tiles_x * p.tg.tiles_y;
+    if (ty <= tiles4) return p;
+    const int cgs = san_cdiv(san_cdiv(cout, 16), pick_mb_f16(cin, cout, tiles4 * n));
+    const long long wgs4 = (long long)tiles4 * n * cgs, wgs3 = (long long)ty * n * cgs;
+    if (g_b16_nbw == 3 || (wgs4 < 256 && wgs3 <= 256)) p = TilePlan{TileGeom{w, thb, 1, ty}, 3};
+    return p;
+}
+
 // Per-tensor power-of-two scale of the fp16-format weight images (round 6, san_conv_f16_wscale_enable / SAN_F16_WSCALE=1).  OFF by
 // default: it costs a max pass over every weight per optimiser step (+0.6 ms of a 41 ms step as measured) and buys 20 % of the
 // end-to-end error (12 cascades, 320^2: 7.8e-5 -> 6.1e-5 vs float64; per layer 3e-7 -> 1e-7) and weights of ANY magnitude.
@@ -1162,14 +1199,14 @@ int format_of(const void* packed) {
     return it == g_fmt.end() ? 0 : it->second;
 }
 
-template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16 = false, bool F8 = false>
+template <int MB, bool WD, int KS, bool FLAT, int NP, bool SWAP, bool F16 = false, bool F8 = false, int NBW = 4>
 int launch_bfns(const BArgs& a, hipStream_t s) {
     // (only the parts in use are allocated: 33 KB for the two-fp16-part form, 17 KB for one part -- LDS never limits residency)
     constexpr size_t lds = NP * (size_t)kPartB + (WD ? (size_t)0 : (size_t)kSteps * MB * 3 * 64 * 16) + 2 * 48 * sizeof(float);
     static SanPerDevice configured;
     const int dev__ = san_current_device();
     if (!configured.has(dev__)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8, NBW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
             san_set_error("cannot reserve %d bytes of LDS for the bf16x3 convolution", (int)lds);
             return SAN_E_UNSUPPORTED;
@@ -1177,7 +1214,7 @@ int launch_bfns(const BArgs& a, hipStream_t s) {
         configured.mark(dev__);
     }
     const int total = a.tiles_x * a.tiles_y * a.cgs * a.N * a.S;
-    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8>), dim3(total), dim3(kT), lds, s, a);
+    hipLaunchKernelGGL((conv_bf16x3_kernel<MB, WD, KS, FLAT, NP, SWAP, F16, F8, NBW>), dim3(total), dim3(kT), lds, s, a);
     return SAN_OK;
 }
 
@@ -1193,6 +1230,9 @@ int launch_bfn(const BArgs& a, hipStream_t s) {
 template <int MB, bool WD, int KS, bool FLAT>
 int launch_bf(const BArgs& a, hipStream_t s) {
     if (a.fmt == 1) {                               // two fp16 parts (forward operands, fp32-equivalent mode only)
+        if constexpr (FLAT && KS == 3) {
+            if (a.nbw == 3) return launch_bfns<MB, WD, KS, FLAT, 2, false, true, false, 3>(a, s);
+        }
         if (g_b16_swap && !a.shuffle && !FLAT) return launch_bfns<MB, WD, KS, FLAT, 2, true, true>(a, s);
         return launch_bfns<MB, WD, KS, FLAT, 2, false, true>(a, s);
     }
@@ -1279,6 +1319,11 @@ size_t san_conv_bf16x3_packed_bytes(int cout, int cin) { return san_conv_bf16x3_
 int san_conv_bf16x3_stat_tiles(int n, int h, int w) {
     (void)n;
     const TileGeom tg = tile_geom(h, w);
+    return tg.tiles_x * tg.tiles_y * 4;
+}
+
+int san_conv3x3_bf16x3_stat_tiles(int n, int h, int w, int cin, int cout, int f16_format) {
+    const TileGeom tg = tile_plan(n, h, w, cin, cout, 3, f16_format != 0, false).tg;
     return tg.tiles_x * tg.tiles_y * 4;
 }
 
@@ -1413,7 +1458,9 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     a.N = n;
     a.H = h;
     a.W = w;
-    const TileGeom tg = tile_geom(h, w);
+    const TilePlan tpl = tile_plan(n, h, w, cin, cout, ks, a.fmt == 1, shuffle != 0);
+    const TileGeom tg = tpl.tg;
+    a.nbw = tpl.nbw;
     a.tiles_x = tg.tiles_x;
     a.tiles_y = tg.tiles_y;
     a.tw = tg.tw;
@@ -1463,6 +1510,14 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     } else {
         int wd = (mb <= 4 && p.chunks <= 6 && h * w >= 1600) ? 1 : 0;        // see the WD note at the kernel
         if (a.fmt >= 1 && mb <= 4) wd = 1;      // fp16 parts: half the matrix work per chunk, residency wins at every depth
+        // ... except where the launch has at most one workgroup per compute unit anyway (the 40^2 level, the 36-channel data gradient
+        // at 80^2): nothing shares the unit, and the weights-direct K-steps run one step (0.4 us) ahead of operands that, INSIDE THE
+        // STEP, come from HBM (every layer's image was packed at the start of the step, ~100 MB of traffic ago) -- the LDS-staged form
+        // requests a chunk's weights a whole chunk ahead.  Round 6, rocprofv3 averages with a different weight image and input tensor per
+        // launch (scratch/r6_cold_probe.py; L2-hot figures in brackets): 144->144 @40^2 42.1 -> 32.3 us (28.8 -> 31.0), 72->144 @40^2
+        // 24.6 -> 20.3 (18.2 -> 19.6), 72->36 @80^2 26.4 -> 22.4; with more workgroups than units the direct form stays ahead
+        // (288->144 @40^2 split in two: 47.4 vs 58.9, 72->72 @80^2 31.6 vs 37.6).
+        if (a.fmt >= 1 && wd && g_b16_wd_cold && (long long)a.tiles_x * a.tiles_y * a.cgs * a.N * a.S <= 256) wd = 0;
         if (g_b16_wd >= 0) wd = g_b16_wd && mb <= 4;
         switch (mb * 2 + wd) {
             case 4: rc = launch_b<2, false>(a, s); break;
@@ -1477,7 +1532,7 @@ static int conv_bf16x3_run(const float* x, int x_ctot, int x_coff, int cin, cons
     if (rc != SAN_OK) return rc;
     SAN_LAUNCH_CHECK();
     if (a.S > 1) {
-        const TileGeom tgs = tile_geom(h, w);
+        const TileGeom tgs = tg;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(n * cout), dim3(256), 0, s, a.ws, a.S, bias, y, y_ctot, y_coff, part_stats,
                            tgs.tiles_x * tgs.tiles_y * 4, n, cout, h * w, fin_scale, fin_shift, fin_ctot, fin_coff, fin_eps);
         SAN_LAUNCH_CHECK();

@@ -847,15 +847,15 @@ __global__ void __launch_bounds__(64) fft320_cols_kernel(const FftArgs a) {
 // MODE 0 (forward): as above; optionally stores dk = M (fft_x(x) - k0x) for the dc_weight gradient.
 // MODE 1 (backward: the DC term is self-adjoint): g' = g - w ifft_x(M fft_x(g)), h = m_scale sum_c conj(S_c) g_c (the
 //        INPUT g: gradient wrt the regulariser output), and one partial of Re sum conj(fft_x(g)) dk per workgroup.
-template <int MODE>
+template <int MODE, int L>
 __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
-    __shared__ float2 lds[kDcL320 * kP320];
+    __shared__ float2 lds[L * kP320];
     __shared__ float2 tws[kN320];
     const int lane = threadIdx.x;
 #pragma unroll
     for (int r = 0; r < 5; ++r) tws[lane + 64 * r] = a.tw[lane + 64 * r];
     const int W = kN320, H = a.H;
-    constexpr int L = kDcL320, RA = Map320<0, L>::RA;
+    constexpr int RA = Map320<0, L>::RA;
     const int h0 = blockIdx.x * L;
     const int n = blockIdx.y;
     const float dcw = a.dcw[0];
@@ -1784,9 +1784,20 @@ int san_ifft2_rss_from_cols(const float* k_cols, float* out, int n, int c, int h
 }
 
 // rows per workgroup and grid of the image-domain cascade kernels (also sizes the dc_weight partials)
-static void dc_rows_geom(int h, int w, int* B, int* gx) {
+// Lines per wave of dc_rows320_kernel.  Two at the benchmark shape (N = 8 single-coil slices: 1,280 waves); ONE where two would leave
+// SIMDs without a wave (a 15-coil 320^2 slice: 160 -> 320 waves, 64.1 -> 52.8 us forward, 62.6 -> 49.4 backward).  Measured at N = 8,
+// C = 1 (round 6, profiles/r06_ab_dc_rows_lines_per_wave.txt): one line per wave = 2.5 waves per SIMD changes nothing forward
+// (10.9 vs 11.0 us) and costs the backward 1 us -- the launch is bound by each wave's load -> transform -> load -> transform -> store
+// chain, not by how many chains a SIMD interleaves.  SAN_DC_L320 = 1 / 2 forces a form (tuning hook).
+static int dc_l320(int n, int h) {
+    static const int forced = getenv("SAN_DC_L320") ? atoi(getenv("SAN_DC_L320")) : 0;
+    if (forced == 1 || forced == 2) return forced;
+    return (long long)n * san_cdiv(h, kDcL320) < 1024 ? 1 : kDcL320;
+}
+
+static void dc_rows_geom(int n, int h, int w, int* B, int* gx) {
     if (w == kN320) {
-        *B = kDcL320;
+        *B = dc_l320(n, h);
     } else if (w == kN368) {
         *B = kL368;
     } else {
@@ -1801,7 +1812,7 @@ static void dc_rows_geom(int h, int w, int* B, int* gx) {
 int san_dc_rows_partials(int n, int c, int h, int w) {
     if (n <= 0 || c <= 0 || h <= 0 || w <= 0) return 0;
     int B, gx;
-    dc_rows_geom(h, w, &B, &gx);
+    dc_rows_geom(n, h, w, &B, &gx);
     return gx * n * (w == kN320 ? 1 : c);      // the general-length kernel runs one coil per workgroup when c > 1
 }
 
@@ -1851,11 +1862,16 @@ int san_dc_rows(const float* x, const float* sens, const float* k0x, const float
     a.scale = (float)(1.0 / std::sqrt((double)w));
     hipStream_t s = (hipStream_t)stream;
     int B, gx;
-    dc_rows_geom(h, w, &B, &gx);
+    dc_rows_geom(n, h, w, &B, &gx);
     if (w == kN320) {
         const dim3 grid(gx, n);
-        if (backward) hipLaunchKernelGGL((dc_rows320_kernel<1>), grid, dim3(64), 0, s, a);
-        else hipLaunchKernelGGL((dc_rows320_kernel<0>), grid, dim3(64), 0, s, a);
+        if (B == 1) {
+            if (backward) hipLaunchKernelGGL((dc_rows320_kernel<1, 1>), grid, dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((dc_rows320_kernel<0, 1>), grid, dim3(64), 0, s, a);
+        } else {
+            if (backward) hipLaunchKernelGGL((dc_rows320_kernel<1, 2>), grid, dim3(64), 0, s, a);
+            else hipLaunchKernelGGL((dc_rows320_kernel<0, 2>), grid, dim3(64), 0, s, a);
+        }
         SAN_LAUNCH_CHECK();
         return SAN_OK;
     }

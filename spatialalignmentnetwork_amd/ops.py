@@ -1012,7 +1012,9 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
                    lambda: lib().call("san_conv_bf16x3_dgrad_amax", *gargs), _conv_abytes(n, h, w, cin, cout, ks), 3)
             return None
         if stats:
-            part = arena.get("part" + tag, (n, cout, lib().query("san_conv_bf16x3_stat_tiles", n, h, w), 3), x.buf.device)
+            tiles = (lib().query("san_conv3x3_bf16x3_stat_tiles", n, h, w, cin, cout, int(fmt == 16)) if ks == 3
+                     else lib().query("san_conv_bf16x3_stat_tiles", n, h, w))
+            part = arena.get("part" + tag, (n, cout, tiles, 3), x.buf.device)
         bargs = (_p(x.buf), x.ctot, x.coff, cin, _p(x.scale), _p(x.shift), float(x.slope), _p(wp), _p(bias), _p(y.buf),
                  y.ctot, y.coff, cout, _p(part), n, h, w, _stream())
         fin = (y.scale, y.shift, y.coff, instance_norm_eps) if (instance_norm_eps is not None and stats and y.scale is not None) else None
