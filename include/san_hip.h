@@ -563,6 +563,7 @@ int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot)
 int san_conv_stream_set_tuning(int on);
 int san_conv_bf16x3_debug_timeline(void* buf);   /* tuning: per-workgroup clock marks of the next launches (8 x u64 each; NULL = off), scratch/conv_timeline.py */
 int san_conv_bf16x3_set_tuning(int wd, int mb);   /* tests / tuning: weights-direct form (-1 auto, 0, 1), channel blocks per workgroup (-1 auto, 2..5) */
+int san_conv_bf16x3_tile_set_tuning(int nbw, int wd_cold);   /* tests / tuning (round 6): blocks per wave of the full-width tiles (0 auto, 3, 4); LDS-staged weights for launches of <= 256 workgroups (1 default, 0 off) */
 size_t san_conv_bf16x3_packed_bytes(int cout, int cin);
 int san_conv_bf16x3_stat_tiles(int n, int h, int w);
 /* Statistics tiles of the 3x3 entry points below for THIS layer (round 6): the tile geometry of a 3x3 launch may depend on the batch and

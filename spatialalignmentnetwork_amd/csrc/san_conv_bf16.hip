@@ -1285,6 +1285,14 @@ int san_conv_bf16x3_set_tuning(int wd, int mb) {
     return SAN_OK;
 }
 
+// tuning / test hook of the round-6 launch-plan choices: nbw = 0 automatic, 4 never the short-tile form, 3 wherever it fits;
+// wd_cold = 1 LDS-staged weights for launches of at most 256 workgroups (default), 0 the weights-direct form there too
+int san_conv_bf16x3_tile_set_tuning(int nbw, int wd_cold) {
+    g_b16_nbw = nbw;
+    g_b16_wd_cold = wd_cold;
+    return SAN_OK;
+}
+
 // 1 when san_conv2d_bf16x3_fwd takes this layer (3x3, channel counts that fill 16-wide tiles); the caller then
 // packs the weights with san_conv_bf16x3_pack and sizes statistics with san_conv_bf16x3_stat_tiles.
 // Tuning hook (builds with -DSAN_B16_TIMELINE only; -1 otherwise): buf = device array of 8 x u64 per workgroup of the NEXT

@@ -766,3 +766,55 @@ def test_f16x2_forward_operand_ranges(S, n, cin, cout, h, w, ks, xs, ws):
         finally:
             ops.F16_FWD[0] = True
         assert e3 < 3e-6, (xs, ws, e3)
+
+
+# ------------------------------------------------------------------ round 6: launch plans of the 40^2 level
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (8, 72, 144, 40, 40),       # 240 workgroups of 40 x 4 tiles (three blocks per wave), weights through LDS
+    (8, 144, 144, 40, 40),
+    (4, 144, 72, 40, 40),       # the decoder's data-gradient shape; split over K
+    (8, 72, 36, 80, 80),        # 32 x 8 tiles, 240 workgroups: weights through LDS
+    (3, 40, 24, 23, 44),        # ragged: 44-wide rows, 23 rows, partial channel blocks
+    (2, 144, 288, 20, 20),      # the 20^2 level keeps its 256-pixel tiles
+])
+def test_short_tiles_and_lds_staged_weights_match_the_round5_forms_bitwise(S, n, cin, cout, h, w):
+    """[round 6] The launch plan of a 3x3 convolution -- short full-width tiles (three 16-pixel blocks per wave) where the default
+    leaves compute units idle, weights staged through LDS where a launch has at most one workgroup per unit (san_conv_bf16.hip:
+    tile_plan, g_b16_wd_cold) -- changes WHICH workgroup computes a pixel, not the order of its sum: outputs are bit-identical to
+    the round-5 forms (256-pixel tiles, weights direct), forward and data gradient; both within 3e-6 of float64; the statistics
+    (other tiles, other merge order) finalise to the same InstanceNorm affine within 2e-6.  (nn.Conv2d + InstanceNorm2d,
+    varnet.py:139-146.)"""
+    ops = S.ops
+    x = g(philox("r6p.x", (n, cin, h, w)) * 2)
+    wt = g(philox("r6p.w", (cout, cin, 3, 3)) * 0.1)
+    sc = g(philox("r6p.sc", (n, cin)).abs() + 0.5)
+    sh = g(philox("r6p.sh", (n, cin)) * 0.3)
+    gout = g(philox("r6p.g", (n, cout, h, w)) * 1e-3)
+    xa = F.leaky_relu(x.double() * sc.double()[:, :, None, None] + sh.double()[:, :, None, None], 0.2)
+    y64 = F.conv2d(xa, wt.double(), padding=1)
+    dx64 = F.conv_transpose2d(gout.double(), wt.double(), padding=1)
+    res = []
+    try:
+        for nbw, wd_cold in ((0, 1), (4, 0)):
+            ops.lib().call("san_conv_bf16x3_tile_set_tuning", nbw, wd_cold)
+            y = ops.Act(torch.zeros((n, cout, h, w), device=DEV), 0, cout, torch.zeros((n, cout), device=DEV), torch.zeros((n, cout), device=DEV), 0.2)
+            part = ops.conv2d(ops.Act(x, 0, cin, sc, sh, 0.2), wt, None, y, stats=True, tag=f".r6p{nbw}", instance_norm_eps=1e-5)
+            if part is not None:
+                ops.norm_finalize(part, ops.NORM_INSTANCE, 1e-5, y.scale, y.shift, y.coff)
+            ops.AMAX.reset(DEV)
+            dy = ops.Act(torch.empty((n, cout, h, w), device=DEV), 0, cout)
+            ops.act_bwd(ops.full(gout), ops.full(torch.ones_like(gout)), dy, instance_norm=False)
+            dx = torch.empty((n, cin, h, w), device=DEV)
+            ops.conv2d_dgrad(dy, wt, ops.full(dx))
+            torch.cuda.synchronize()
+            res.append((y.buf.clone(), y.scale.clone(), y.shift.clone(), dx.clone()))
+    finally:
+        ops.lib().call("san_conv_bf16x3_tile_set_tuning", 0, 1)
+    (ya, sca, sha, dxa), (yb, scb, shb, dxb) = res
+    assert torch.equal(ya, yb) and torch.equal(dxa, dxb)
+    assert rel_err(ya.cpu().double(), y64.cpu()) < 3e-6 and rel_err(dxa.cpu().double(), dx64.cpu()) < 3e-6
+    var, mean = torch.var_mean(y64, dim=(2, 3), unbiased=False)
+    want_sc = torch.rsqrt(var + 1e-5)
+    for got_sc, got_sh in ((sca, sha), (scb, shb)):
+        assert ((got_sc.double() - want_sc).abs() / want_sc).max().item() < 2e-6
+        assert ((got_sh.double() + mean * want_sc).abs().max() / (mean * want_sc).abs().max()).item() < 1e-5
