@@ -23,6 +23,8 @@ import torch
 from . import ops
 from .ops import Act, GLOBAL_ARENA as ARENA
 
+# A residual add's gradient goes to both operands as ONE tensor (no copy per reader; round 6).  SAN_UNET_SHARE_GRADS=0: a copy per reader.
+SHARE_RES_GRADS = [__import__("os").environ.get("SAN_UNET_SHARE_GRADS", "1") != "0"]
 BN_EPS = 1e-5
 SLOPE = 0.01   # nn.LeakyReLU default, unet.py:126
 
@@ -222,8 +224,15 @@ class UNet(torch.nn.Module):
             counter[0] += 1
             return Act(ARENA.get(f"abwd.t{counter[0]}", (n, c, h, w), out.buf.device), 0, c)
 
-        def accum_input(x: Act, g: Act):
-            """g covers x's channels; split it over the activations that produced x's buffer."""
+        shared = set()          # gradient tensors two readers hold (a residual add hands ONE tensor to both operands)
+
+        def gkey(a: Act):
+            return (a.buf.data_ptr(), a.coff, a.c)
+
+        def accum_input(x: Act, g: Act, both: bool = False):
+            """g covers x's channels; split it over the activations that produced x's buffer.  ``both``: another reader holds
+            the same g (round 6: no private copy per reader -- a sum INTO a shared tensor goes to a fresh one instead, so the
+            step has one out-of-place add where it had a copy + an in-place add; same operands, same order, same bits)."""
             ranges = self._produced.get(x.buf.data_ptr())
             if not ranges:
                 return                                    # network input: no gradient needed
@@ -232,9 +241,17 @@ class UNet(torch.nn.Module):
                     key = (x.buf.data_ptr(), coff, c)
                     piece = g.view(coff - x.coff, c)
                     if key in grads:
-                        ops.add(grads[key], piece, grads[key])
+                        cur = grads[key]
+                        if gkey(cur) in shared:
+                            fresh = tmp(c, x.h, x.w, x.n)
+                            ops.add(cur, piece, fresh)
+                            grads[key] = fresh
+                        else:
+                            ops.add(cur, piece, cur)
                     else:
                         grads[key] = piece
+                        if both:
+                            shared.add(gkey(piece))
 
         def take(a: Act) -> Optional[Act]:
             return grads.get((a.buf.data_ptr(), a.coff, a.c))
@@ -277,10 +294,14 @@ class UNet(torch.nn.Module):
                 g = take(o)
                 if g is None:
                     continue
-                accum_input(a, g)
-                g2 = tmp(o.c, o.h, o.w, o.n)
-                ops.apply(g, g2)                                  # second reader gets its own copy
-                accum_input(b, g2)
+                if SHARE_RES_GRADS[0]:
+                    accum_input(a, g, both=True)
+                    accum_input(b, g, both=True)
+                else:                                                 # (SAN_UNET_SHARE_GRADS=0: the round-5 form, same bits)
+                    accum_input(a, g)
+                    g2 = tmp(o.c, o.h, o.w, o.n)
+                    ops.apply(g, g2)                                  # second reader gets its own copy
+                    accum_input(b, g2)
             elif kind == "pool":
                 _, x, o = op
                 g = take(o)
