@@ -473,6 +473,14 @@ int san_dc_rows_partials(int n, int c, int h, int w);
 int san_dc_rows(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
                 const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, const float* dk_in,
                 float* dcw_part, int backward, int n, int c, int h, int w, void* stream);
+/* Round 6: the forward form that also emits the statistics the NEXT cascade's NormUnet normalises its input with
+ * (NormUnet.norm, varnet.py:262-273: mean / std of the two planes of m_out): m_stats [n][2][san_dc_rows_stat_tiles(n, c, h, w)][3] =
+ * (count, mean, M2) per workgroup and plane, merged by san_norm_finalize like san_plane_stats' records.  A tile count of 0 means the
+ * shape's kernel does not emit them (only the 320-wide kernel does): run san_plane_stats on m_out instead. */
+int san_dc_rows_stat_tiles(int n, int c, int h, int w);
+int san_dc_rows_stats(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
+                      const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, float* m_stats, int n, int c,
+                      int h, int w, void* stream);
 
 /* -------------------------------------------------------- warp and losses */
 

@@ -63,6 +63,8 @@ struct FftArgs {
     const float2* dk_in;     // backward: that tensor of the forward pass
     float* dcw_part;         // backward: one partial of Re sum conj(fft_x(g)) dk_in per workgroup
     float m_scale;           // factor on the coil-combined planar output (-1 in the backward form)
+    float* m_stats;          // forward, 320-wide kernel: [n][2][workgroups per sample][3] = (count, mean, M2) of this workgroup's rows of the
+                             // two planes of the coil-combined output (the next cascade's NormUnet statistics, varnet.py:262-273), or null
 };
 
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
@@ -974,6 +976,39 @@ __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
             }
         }
     }
+    if (MODE == 0 && a.m_stats) {
+        // exact two-pass statistics of the rows this wave just produced (the values are still in registers): one record per
+        // workgroup and plane, merged by san_norm_finalize like san_plane_stats' chunk records -- that launch is not needed
+        int rows = 0;
+#pragma unroll
+        for (int t = 0; t < L; ++t) rows += h0 + t < H ? 1 : 0;
+        const float cnt = (float)(rows * W);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < L; ++t)
+#pragma unroll
+                for (int r = 0; r < 5; ++r) sum += h0 + t < H ? (p ? macc[t][r].y : macc[t][r].x) * a.m_scale : 0.f;
+            sum = san_wave_total(sum);
+            const float mean = cnt > 0.f ? sum / cnt : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < L; ++t)
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    const float d = h0 + t < H ? (p ? macc[t][r].y : macc[t][r].x) * a.m_scale - mean : 0.f;
+                    m2 = fmaf(d, d, m2);
+                }
+            m2 = san_wave_total(m2);
+            if (lane == 0) {
+                float* o = a.m_stats + ((size_t)(n * 2 + p) * gridDim.x + blockIdx.x) * 3;
+                o[0] = cnt;
+                o[1] = mean;
+                o[2] = m2;
+            }
+        }
+    }
     if (MODE == 1 && a.dcw_part) {
         wsum = san_wave_total(wsum);
         if (lane == 0) a.dcw_part[blockIdx.y * gridDim.x + blockIdx.x] = wsum;
@@ -1833,9 +1868,39 @@ int san_fft_cols(const float* in, float* out, int planes, int h, int w, int inve
     return launch_cols(c, planes, (hipStream_t)stream);
 }
 
+static int dc_rows_impl(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
+                        const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, const float* dk_in,
+                        float* dcw_part, int backward, int n, int c, int h, int w, float* m_stats, void* stream);
+
 int san_dc_rows(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
                 const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, const float* dk_in,
                 float* dcw_part, int backward, int n, int c, int h, int w, void* stream) {
+    return dc_rows_impl(x, sens, k0x, mask, dc_w, r_planar, x_out, m_out, m_ctot, dk_out, dk_in, dcw_part, backward, n, c, h, w, nullptr, stream);
+}
+
+// Statistics records per (sample, plane) that san_dc_rows_stats writes for this shape; 0: the shape's kernel does not emit them
+// (the caller runs san_plane_stats on m_out as before).
+int san_dc_rows_stat_tiles(int n, int c, int h, int w) {
+    if (n <= 0 || c <= 0 || h <= 0 || w != kN320) return 0;
+    int B, gx;
+    dc_rows_geom(n, h, w, &B, &gx);
+    return gx;
+}
+
+// The forward form of san_dc_rows that ALSO emits the (count, mean, M2) records of the two planes of m_out -- the statistics the next
+// cascade's NormUnet normalises its input with (varnet.py:262-273, 311-314): m_stats [n][2][san_dc_rows_stat_tiles(n, c, h, w)][3],
+// to be merged by san_norm_finalize exactly like san_plane_stats' records (round 6: one launch per cascade less).
+int san_dc_rows_stats(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
+                      const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, float* m_stats, int n, int c,
+                      int h, int w, void* stream) {
+    SAN_CHECK_ARG(m_stats && m_out, "m_stats and m_out are required");
+    SAN_CHECK_ARG(san_dc_rows_stat_tiles(n, c, h, w) > 0, "this shape's kernel does not emit statistics (san_dc_rows_stat_tiles == 0)");
+    return dc_rows_impl(x, sens, k0x, mask, dc_w, r_planar, x_out, m_out, m_ctot, dk_out, nullptr, nullptr, 0, n, c, h, w, m_stats, stream);
+}
+
+static int dc_rows_impl(const float* x, const float* sens, const float* k0x, const float* mask, const float* dc_w,
+                        const float* r_planar, float* x_out, float* m_out, int m_ctot, float* dk_out, const float* dk_in,
+                        float* dcw_part, int backward, int n, int c, int h, int w, float* m_stats, void* stream) {
     SAN_CHECK_ARG(x && sens && mask && dc_w, "null input");
     SAN_CHECK_ARG(n > 0 && c > 0 && h > 0 && w > 0, "bad dims");
     SAN_CHECK_ARG(!m_out || m_ctot >= 2, "m_ctot must be >= 2");
@@ -1858,6 +1923,7 @@ int san_dc_rows(const float* x, const float* sens, const float* k0x, const float
     a.dk_out = (float2*)dk_out;
     a.dk_in = (const float2*)dk_in;
     a.dcw_part = dcw_part;
+    a.m_stats = m_stats;
     a.m_scale = backward ? -1.f : 1.f;
     a.scale = (float)(1.0 / std::sqrt((double)w));
     hipStream_t s = (hipStream_t)stream;

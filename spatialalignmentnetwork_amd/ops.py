@@ -481,19 +481,30 @@ def fft_cols(x: torch.Tensor, inverse: bool, out: Optional[torch.Tensor] = None)
 
 def dc_rows(x: torch.Tensor, sens: torch.Tensor, k0x: Optional[torch.Tensor], mask: torch.Tensor, dc_w: torch.Tensor,
             r_planar: Optional[torch.Tensor], x_out: Optional[torch.Tensor], m_out: Optional[torch.Tensor],
-            dk_out: Optional[torch.Tensor] = None) -> None:
+            dk_out: Optional[torch.Tensor] = None, m_stats: Optional[torch.Tensor] = None) -> None:
     """One cascade boundary in the image domain (san_dc_rows): x_out = x - dc_w ifft_x(mask (fft_x(x) - k0x)) - r S and
-    m_out[:, 0:2] = sum_c conj(S_c) x_out_c (planar, into a [N, ctot, H, W] buffer)."""
+    m_out[:, 0:2] = sum_c conj(S_c) x_out_c (planar, into a [N, ctot, H, W] buffer).  ``m_stats`` (dc_rows_stat_part): the launch
+    also emits the (count, mean, M2) records of m_out's two planes -- the next NormUnet's statistics (san_dc_rows_stats, round 6)."""
     n, c, h, w = x.shape
-    args = (_p(_creal(x, "x")), _p(_creal(sens, "sens")), _p(None if k0x is None else _creal(k0x, "k0x")),
+    head = (_p(_creal(x, "x")), _p(_creal(sens, "sens")), _p(None if k0x is None else _creal(k0x, "k0x")),
             _p(_chk(mask, name="mask")), _p(_chk(dc_w, name="dc_w")), _p(None if r_planar is None else _chk(r_planar, name="r")),
             _p(None if x_out is None else _creal(x_out, "x_out")), _p(None if m_out is None else _chk(m_out, name="m_out")),
-            int(m_out.shape[1]) if m_out is not None else 2, _p(None if dk_out is None else _creal(dk_out, "dk_out")),
-            _p(None), _p(None), 0, n, c, h, w, _stream())
+            int(m_out.shape[1]) if m_out is not None else 2, _p(None if dk_out is None else _creal(dk_out, "dk_out")))
+    if m_stats is not None:
+        assert m_out is not None and tuple(m_stats.shape) == (n, 2, lib().query("san_dc_rows_stat_tiles", n, c, h, w), 3)
+        fn, args = "san_dc_rows_stats", head + (_p(_chk(m_stats, name="m_stats")), n, c, h, w, _stream())
+    else:
+        fn, args = "san_dc_rows", head + (_p(None), _p(None), 0, n, c, h, w, _stream())
     # SURVEY 8(d) bytes of one cascade's FFT + DC work: (6C + 2) planes of H*W*8 B per slice; this kernel itself moves
     # (4C + 2) (+ C for dk_out): the column passes of the two 2-D transforms are gone
-    _timed("fft_dc", float((6 * c + 2) * n * h * w * 8), "B", lambda: lib().call("san_dc_rows", *args),
+    _timed("fft_dc", float((6 * c + 2) * n * h * w * 8), "B", lambda: lib().call(fn, *args),
            float((4 * c + 2 + (c if dk_out is not None else 0)) * n * h * w * 8))
+
+
+def dc_rows_stat_part(n: int, c: int, h: int, w: int, device, arena: Arena = GLOBAL_ARENA, tag: str = "") -> Optional[torch.Tensor]:
+    """The records buffer for ``dc_rows(..., m_stats=)``, or None where the shape's kernel does not emit statistics."""
+    tiles = lib().query("san_dc_rows_stat_tiles", n, c, h, w)
+    return arena.get("dcstat" + tag, (n, 2, tiles, 3), device) if tiles else None
 
 
 def dc_rows_bwd(g: torch.Tensor, sens: torch.Tensor, mask: torch.Tensor, dc_w: torch.Tensor, g_out: torch.Tensor,

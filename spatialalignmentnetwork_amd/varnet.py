@@ -32,6 +32,8 @@ import os as _os
 FUSED_NU_BWD = [_os.environ.get("SAN_FUSED_NU_BWD", "1") != "0"]
 # InstanceNorm finalisation + average pooling of an encoder level in one launch (round 6; SAN_FUSED_FIN_POOL=0: two launches)
 FUSED_FIN_POOL = [_os.environ.get("SAN_FUSED_FIN_POOL", "1") != "0"]
+# The cascade-boundary launch emits the next NormUnet's input statistics (round 6; SAN_DC_STATS=0: a san_plane_stats launch per cascade)
+DC_STATS = [_os.environ.get("SAN_DC_STATS", "1") != "0"]
 
 
 class ConvBlock(nn.Module):
@@ -381,9 +383,10 @@ class NormUnet(nn.Module):
         hp, wp = ((h - 1) | 15) + 1, ((w - 1) | 15) + 1
         return (hp - h) // 2, (wp - w) // 2, hp, wp
 
-    def run(self, xin: Act, out_planar: torch.Tensor, key: str) -> torch.Tensor:
+    def run(self, xin: Act, out_planar: torch.Tensor, key: str, part: Optional[torch.Tensor] = None) -> torch.Tensor:
         """xin channels 0,1 hold the planar complex image (raw).  Writes the
-        un-normalised planar output [B,2,H,W]."""
+        un-normalised planar output [B,2,H,W].  ``part``: (count, mean, M2) records [B, 2, tiles, 3] of the two planes that the
+        producer of xin already emitted (ops.dc_rows(m_stats=)); None: one san_plane_stats launch here."""
         b, h, w = xin.n, xin.h, xin.w
         dev = xin.buf.device
         # [0] = std / mean of the planes (the un-normalisation affine), [1] = guarded 1 / std and -mean / std (the backward's
@@ -391,7 +394,8 @@ class NormUnet(nn.Module):
         std2 = ARENA.get(f"{key}.gn_std", (2, b, 2), dev)
         mean2 = ARENA.get(f"{key}.gn_mean", (2, b, 2), dev)
         std, mean = std2[0], mean2[0]
-        part = ops.plane_stats(xin.view(0, 2), tag="gn")
+        if part is None:
+            part = ops.plane_stats(xin.view(0, 2), tag="gn")
         ops.norm_finalize(part, ops.NORM_GROUP_BWD, 1e-6, xin.scale, xin.shift, 0, aux_a=std2, aux_b=mean2)
         top, left, hp, wp = self.pad_sizes(h, w)
         if (hp, wp) == (h, w):
@@ -626,14 +630,18 @@ class VarNetBlock(nn.Module):
 
     # -- image-domain form (what VarNet.forward runs) --------------------------------------------
     def run_img(self, x: torch.Tensor, k0x: torch.Tensor, mask_f: torch.Tensor, sens: torch.Tensor, xin: Act,
-                x_out: torch.Tensor, key: str, m_next: Optional[torch.Tensor], dk_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                x_out: torch.Tensor, key: str, m_next: Optional[torch.Tensor], dk_out: Optional[torch.Tensor] = None,
+                stats_in: Optional[torch.Tensor] = None, stats_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The same cascade on the state x = ifft2(k): the mask depends on kx only, so the soft data consistency is
         row-local there (ops.dc_rows).  xin channels 0, 1 already hold m = sum_c conj(S_c) x_c (written by the previous
-        cascade's launch); this one writes x_out = x - w D(x) - r S and the next cascade's m into ``m_next``."""
+        cascade's launch); this one writes x_out = x - w D(x) - r S and the next cascade's m into ``m_next``.
+        stats_in: the statistics records of xin's planes the previous cascade's launch emitted; stats_out: where this one's
+        launch puts those of ``m_next`` (ops.dc_rows_stat_part; the same buffer may serve both: it is read before it is written)."""
         n, c, h, w = x.shape
         r = ARENA.get(f"{key}.r", (n, 2, h, w), x.device)
-        self.model.run(xin, r, key)
-        ops.dc_rows(x, sens, k0x, mask_f, self.dc_weight, r, x_out, m_next, dk_out)
+        self.model.run(xin, r, key, part=stats_in)
+        ops.dc_rows(x, sens, k0x, mask_f, self.dc_weight, r, x_out, m_next, dk_out,
+                    m_stats=stats_out if m_next is not None else None)
         self._tape = (x, None, mask_f, sens, r, key)
         self._dk = dk_out
         return x_out
@@ -729,8 +737,10 @@ class VarNet(nn.Module):
                 if self.use_ref:
                     self.cascades[0].model.set_ref(xin, ref1)
                 ops.sens_reduce(masked_kspace, sens, xin.buf)
+            st = ops.dc_rows_stat_part(n, c, h, w, dev, ARENA) if (DC_STATS[0] and T > 1) else None
             for j, cascade in enumerate(self.cascades):
-                cascade.run_img(x, k0x, mask_f, sens, xin, x, "cas", xin.buf if j + 1 < T else None)
+                cascade.run_img(x, k0x, mask_f, sens, xin, x, "cas", xin.buf if j + 1 < T else None,
+                                stats_in=st if j > 0 else None, stats_out=st)
             return ops.rss(x)
         # training: every cascade keeps its own activations, state and data-consistency residual
         x = ARENA.get("cas.x0", (n, c, h, w), dev, dtype=torch.complex64)
@@ -746,11 +756,13 @@ class VarNet(nn.Module):
             join_sens()
         if T:
             ops.sens_reduce(masked_kspace, sens, xins[0].buf)
+        st = ops.dc_rows_stat_part(n, c, h, w, dev, ARENA) if (DC_STATS[0] and T > 1) else None
         for j, cascade in enumerate(self.cascades):
             key = f"cas{j}"
             x_out = ARENA.get(f"{key}.xout", (n, c, h, w), dev, dtype=torch.complex64)
             dk = ARENA.get(f"{key}.dk", (n, c, h, w), dev, dtype=torch.complex64)
-            x = cascade.run_img(x, k0x, mask_f, sens, xins[j], x_out, key, xins[j + 1].buf if j + 1 < T else None, dk)
+            x = cascade.run_img(x, k0x, mask_f, sens, xins[j], x_out, key, xins[j + 1].buf if j + 1 < T else None, dk,
+                                stats_in=st if j > 0 else None, stats_out=st)
         out = ops.rss(x)
         self._train_state = (x, out.detach(), ref, ref1)      # (a detached alias: the returned tensor will carry the grad_fn)
         return out

@@ -174,6 +174,43 @@ def test_dc_rows_vs_kspace_formula(S, n, c, h, w):
     assert rel_err(gS.cpu(), want_gs) < 3e-6
 
 
+@pytest.mark.parametrize("n,c,h,w", [(8, 1, 320, 320), (1, 15, 320, 320), (2, 3, 101, 320), (1, 1, 6, 320)])
+def test_cascade_boundary_emits_the_next_normunet_statistics(S, n, c, h, w):
+    """[round 6] san_dc_rows_stats == san_dc_rows bit for bit on x' and m', plus (count, mean, M2) records of m's two planes that
+    san_norm_finalize merges into the same statistics san_plane_stats' records give (the next cascade's NormUnet.norm,
+    varnet.py:262-273): mean / variance within 2e-6 of float64 on the stored planes; two lines per wave, one line per wave
+    (15 coils: under one wave per SIMD), an odd height; other row lengths report 0 tiles (the caller keeps san_plane_stats)."""
+    ops = S.ops
+    assert ops.lib().query("san_dc_rows_stat_tiles", 2, 1, 46, 368) == 0 and ops.lib().query("san_dc_rows_stat_tiles", 2, 3, 48, 80) == 0
+    x, sens, k0 = g(cplx("dcs.x", (n, c, h, w))), g(cplx("dcs.s", (n, c, h, w))), g(cplx("dcs.k0", (n, c, h, w)))
+    r = g(philox("dcs.r", (n, 2, h, w)))
+    mask = g((philox("dcs.m", (w,)) > 0.3).float())
+    dcw = g(torch.tensor([0.7]))
+    k0x = k0                                     # (any data term: the launch is row-local)
+    outs = []
+    for with_stats in (False, True):
+        x_out = torch.empty_like(x)
+        m_out = torch.zeros((n, 3, h, w), device=DEV)
+        st = ops.dc_rows_stat_part(n, c, h, w, DEV, tag=".t") if with_stats else None
+        if with_stats:
+            assert st is not None
+            st.fill_(float("nan"))
+        ops.dc_rows(x, sens, k0x, mask, dcw, r, x_out, m_out, None, m_stats=st)
+        torch.cuda.synchronize()
+        outs.append((x_out, m_out, st))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    m_out, st = outs[1][1], outs[1][2]
+    assert bool(torch.isfinite(st).all()) and float(st[..., 0].sum(dim=2).min()) == h * w == float(st[..., 0].sum(dim=2).max())
+    m64 = m_out[:, :2].double()
+    var, mean = torch.var_mean(m64, dim=(2, 3), unbiased=False)
+    for part in (st, ops.plane_stats(ops.Act(m_out, 0, 2), tag=".dcs")):
+        sc, sh = torch.zeros((n, 2), device=DEV), torch.zeros((n, 2), device=DEV)
+        ops.norm_finalize(part, ops.NORM_INSTANCE, 0.0, sc, sh, 0)
+        torch.cuda.synchronize()
+        assert ((sc.double() - torch.rsqrt(var)).abs() / torch.rsqrt(var)).max().item() < 2e-6
+        assert ((sh.double() + mean * torch.rsqrt(var)).abs().max() / (mean * torch.rsqrt(var)).abs().max().clamp_min(1e-3)).item() < 1e-5
+
+
 # ------------------------------------------------------------------ single layers
 def test_varnetblock_step_and_sens_expand_golden(S, ops_golden):
     """[round 2] One cascade with a real regulariser through VarNetBlock.forward, and the stand-alone sens_expand
