@@ -752,6 +752,11 @@ def main(argv=None):
                     ent["avg_launch_us"] = ent["rocprof"]["avg_launch_us"]
                     ent["timing"] = ("as shipped: rocprofv3 --kernel-trace --stats of this command (" + ent["rocprof"]["source"] +
                                      "); the in-step bracket of the launch run alone is `in_step_alone_net_of_event_pair`")
+            #  beside every HBM-bound fraction on the algorithmic byte count: the fraction on the bytes the kernel REALLY
+            # moves (PMC traffic per launch over the headline duration of the entry)
+            for field, ent in out.items():
+                if field.startswith("roofline") and isinstance(ent, dict) and ent.get("bound") == "hbm" and ent.get("traffic") and ent.get("avg_launch_us"):
+                    ent["traffic_frac"] = ent["traffic"] / (ent["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
             out["kernel_ms_per_step"] = {k: v["ms"] / args.steps for k, v in tot.items()}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cascades, h, w, args.mode, coils=c, sparsity=args.sparsity, batch=n)

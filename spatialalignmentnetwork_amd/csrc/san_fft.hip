@@ -977,35 +977,39 @@ __global__ void __launch_bounds__(64) dc_rows320_kernel(const FftArgs a) {
         }
     }
     if (MODE == 0 && a.m_stats) {
-        // exact two-pass statistics of the rows this wave just produced (the values are still in registers): one record per
-        // workgroup and plane, merged by san_norm_finalize like san_plane_stats' chunk records -- that launch is not needed
+        // statistics of the rows this wave just produced (the values are still in registers): one (count, mean, M2) record per
+        // workgroup and plane, merged by san_norm_finalize like san_plane_stats' chunk records -- that launch is not needed.
+        // Pilot-shifted single pass (the convolutions' scheme): the four wave sums are independent chains
         int rows = 0;
 #pragma unroll
         for (int t = 0; t < L; ++t) rows += h0 + t < H ? 1 : 0;
         const float cnt = (float)(rows * W);
+        const float p0 = __shfl(macc[0][0].x * a.m_scale, 0, 64), p1 = __shfl(macc[0][0].y * a.m_scale, 0, 64);     // row h0 always exists
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < L; ++t)
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const bool ok = h0 + t < H;
+                const float e0 = ok ? macc[t][r].x * a.m_scale - p0 : 0.f, e1 = ok ? macc[t][r].y * a.m_scale - p1 : 0.f;
+                s1[0] += e0;
+                s2[0] = fmaf(e0, e0, s2[0]);
+                s1[1] += e1;
+                s2[1] = fmaf(e1, e1, s2[1]);
+            }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            float sum = 0.f;
+            s1[p] = san_wave_total(s1[p]);
+            s2[p] = san_wave_total(s2[p]);
+        }
+        if (lane == 0) {
+            const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
 #pragma unroll
-            for (int t = 0; t < L; ++t)
-#pragma unroll
-                for (int r = 0; r < 5; ++r) sum += h0 + t < H ? (p ? macc[t][r].y : macc[t][r].x) * a.m_scale : 0.f;
-            sum = san_wave_total(sum);
-            const float mean = cnt > 0.f ? sum / cnt : 0.f;
-            float m2 = 0.f;
-#pragma unroll
-            for (int t = 0; t < L; ++t)
-#pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    const float d = h0 + t < H ? (p ? macc[t][r].y : macc[t][r].x) * a.m_scale - mean : 0.f;
-                    m2 = fmaf(d, d, m2);
-                }
-            m2 = san_wave_total(m2);
-            if (lane == 0) {
+            for (int p = 0; p < 2; ++p) {
                 float* o = a.m_stats + ((size_t)(n * 2 + p) * gridDim.x + blockIdx.x) * 3;
                 o[0] = cnt;
-                o[1] = mean;
-                o[2] = m2;
+                o[1] = (p ? p1 : p0) + s1[p] * inv;
+                o[2] = fmaxf(s2[p] - s1[p] * s1[p] * inv, 0.f);
             }
         }
     }
