@@ -565,7 +565,9 @@ int san_conv_bf16x3_eligible(int cin, int cout, int h, int w, int ks);
  * 32 x 8 tiles with the packed weights resident in LDS and the next tile's input requested a whole K-loop ahead.  Taken
  * automatically by san_conv2d_bf16x3_fwd / _fwd_ws / _fwd_ws_in / san_conv_bf16x3_dgrad_amax (same arguments, same statistics
  * records) where san_conv_stream_eligible() says 1: fp16-format weights, h % 8 == 0, w % 32 == 0, h * w >= 160^2, cin <= 96,
- * cout in {16, 18, 32, 36, 48}.  Replaces nn.Conv2d(3x3, padding 1) of varnet.py:139-146 and its autograd data gradient on the
+ * cout in {16, 18, 32, 36, 48} (round 6: also 2 / 3 -- the data gradient of a cascade's input convolution, varnet.py:139-146 with
+ * in_chans = 2 / 3 -- as a partial channel block alone; the caller asks san_conv_stream_eligible first: the one-tile kernel does not
+ * take such a layer).  Replaces nn.Conv2d(3x3, padding 1) of varnet.py:139-146 and its autograd data gradient on the
  * 320^2 / 160^2 levels.  san_conv_stream_set_tuning(0) sends every layer to the one-tile-per-workgroup kernel (tests). */
 int san_conv_stream_eligible(int n, int h, int w, int cin, int cout, int x_ctot);
 int san_conv_stream_set_tuning(int on);

@@ -958,6 +958,11 @@ class conv_precision:
 USE_BF16X3 = [os.environ.get("SAN_NO_BF16X3", "0") != "1"]
 
 
+# Data gradients to 2 / 3 channels (a cascade's input convolution) on the persistent matrix-core kernel instead of the direct fp32 one
+# (round 6, san_conv_stream_eligible; SAN_STREAM_SMALL_COUT=0: off -- read once, by the library too)
+STREAM_SMALL_COUT = [os.environ.get("SAN_STREAM_SMALL_COUT", "1") != "0"]
+
+
 def bf16x3_eligible(cin: int, cout: int, h: int, w: int, ks: int) -> bool:
     if not USE_BF16X3[0]:
         return False
@@ -1275,7 +1280,9 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
     """dx.buf[:, dx.coff:+cin] = dL/d(conv input) for dy = dL/d(conv output) (materialised)."""
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert dy.c == cout and dx.c == cin
-    if bf16x3_eligible(cout, cin, dy.h, dy.w, ks):       # the data-gradient conv maps cout -> cin channels
+    small = (STREAM_SMALL_COUT[0] and ks == 3 and cin in (2, 3) and cout >= 16 and USE_BF16X3[0] and dy.amax is not None and _CONV_NP[0] == 3
+             and dy.scale is None and lib().query("san_conv_stream_eligible", dy.n, dy.h, dy.w, cout, cin, dy.ctot))
+    if small or bf16x3_eligible(cout, cin, dy.h, dy.w, ks):       # the data-gradient conv maps cout -> cin channels
         if dy.amax is not None and _CONV_NP[0] == 3 and dy.scale is None:
             wp = PACKS16.get(weight, 2 + 16)             # two fp16 parts; dy scaled by the power of two its maximum asks for
             nbytes = lib().query("san_conv_bf16x3_ws_bytes", dy.n, dy.h, dy.w, cout, cin, 3) if ks == 3 else 0

@@ -818,3 +818,25 @@ def test_short_tiles_and_lds_staged_weights_match_the_round5_forms_bitwise(S, n,
     for got_sc, got_sh in ((sca, sha), (scb, shb)):
         assert ((got_sc.double() - want_sc).abs() / want_sc).max().item() < 2e-6
         assert ((got_sh.double() + mean * want_sc).abs().max() / (mean * want_sc).abs().max()).item() < 1e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,scale", [(8, 3, 18, 320, 320, 1e-3), (2, 2, 18, 160, 160, 3e-7), (1, 3, 36, 160, 192, 2e4), (2, 3, 18, 48, 64, 1.0)])
+def test_data_gradient_to_two_or_three_channels_on_the_persistent_kernel(S, n, cin, cout, h, w, scale):
+    """[round 6] dL/dx of Conv2d(cin = 2 / 3, cout, 3x3) -- a cascade's input convolution (varnet.py:139-146, in_chans 2 / 3) -- runs
+    on the persistent matrix-core kernel with the 2 / 3 output channels as a partial block alone (conv3x3_stream_kernel<0, REM>) where
+    san_conv_stream_eligible takes the shape, on the direct fp32 kernel elsewhere (the 48 x 64 case): <= 3e-6 of float64 either way,
+    gradients of magnitude 3e-7 .. 2e4 (scaled by their recorded maximum), every other channel of the destination untouched."""
+    ops = S.ops
+    wt = g(philox("sc.w", (cout, cin, 3, 3)) * 0.1)
+    gout = g(philox("sc.g", (n, cout, h, w)) * scale)
+    ops.AMAX.reset(DEV)
+    dy = ops.Act(torch.empty((n, cout, h, w), device=DEV), 0, cout)
+    ops.act_bwd(ops.full(gout), ops.full(torch.ones_like(gout)), dy, instance_norm=False)
+    taken = bool(ops.STREAM_SMALL_COUT[0] and ops.lib().query("san_conv_stream_eligible", n, h, w, cout, cin, cout))
+    assert taken == (h * w >= 160 * 160)
+    dst = torch.full((n, cin + 2, h, w), -3.0, device=DEV)
+    ops.conv2d_dgrad(dy, wt, ops.Act(dst, 1, cin))
+    torch.cuda.synchronize()
+    ref = F.conv_transpose2d(gout.double(), wt.double(), padding=1)
+    assert rel_err(dst[:, 1:1 + cin].cpu().double(), ref.cpu()) < 3e-6
+    assert float(dst[:, 0].min()) == -3.0 == float(dst[:, 0].max()) and float(dst[:, -1].min()) == -3.0 == float(dst[:, -1].max())
