@@ -1014,7 +1014,12 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
     assert x.buf.shape[2:] == y.buf.shape[2:]
     n, h, w = x.n, x.h, x.w
     part = None
-    if out_scale is None and bf16x3_eligible(cin, cout, h, w, ks):
+    # (round 6) a 3x3 convolution TO 2 / 3 channels (the alignment net's last layer, unet.py:108-111) on the persistent matrix-core
+    # kernel with those channels as a partial block alone, where its shape rules hold -- the one-tile kernel does not take such a layer
+    small = (STREAM_SMALL_COUT[0] and ks == 3 and cout in (2, 3) and cin >= 16 and out_scale is None and not stats and not grad_input
+             and USE_BF16X3[0] and _fwd_fmt() == 16 and y.buf.data_ptr() % 16 == 0
+             and lib().query("san_conv_stream_eligible", n, h, w, cin, cout, x.ctot))
+    if out_scale is None and (small or bf16x3_eligible(cin, cout, h, w, ks)):
         # bf16 matrix cores, operands split in three (fp32-level accuracy), csrc/san_conv_bf16.hip
         fmt = (16 if (x.amax is not None and _CONV_NP[0] == 3) else 0) if grad_input else _fwd_fmt()
         wp = PACKS16.get(weight, fmt)

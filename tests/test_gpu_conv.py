@@ -840,3 +840,22 @@ def test_data_gradient_to_two_or_three_channels_on_the_persistent_kernel(S, n, c
     ref = F.conv_transpose2d(gout.double(), wt.double(), padding=1)
     assert rel_err(dst[:, 1:1 + cin].cpu().double(), ref.cpu()) < 3e-6
     assert float(dst[:, 0].min()) == -3.0 == float(dst[:, 0].max()) and float(dst[:, -1].min()) == -3.0 == float(dst[:, -1].max())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(8, 32, 2, 320, 320), (2, 18, 3, 160, 160), (1, 32, 2, 48, 64)])
+def test_convolution_to_two_or_three_channels_on_the_persistent_kernel(S, n, cin, cout, h, w):
+    """[round 6] Conv2d(cin >= 16, 2 / 3, 3x3) + bias without statistics -- the alignment net's last layer (unet.py:108-111: 32 -> 2,
+    the displacement field) -- on the persistent matrix-core kernel (partial channel block alone; 69.9 -> 50.8 us at 32 -> 2 @320^2)
+    where san_conv_stream_eligible takes the shape, else on the direct fp32 kernel: <= 3e-6 of float64, lazily activated input,
+    a channel view as destination."""
+    ops = S.ops
+    x = g(philox("sf.x", (n, cin, h, w)) * 2)
+    wt, b = g(philox("sf.w", (cout, cin, 3, 3)) * 0.1), g(philox("sf.b", (cout,)))
+    sc, sh = g(philox("sf.sc", (n, cin)).abs() + 0.5), g(philox("sf.sh", (n, cin)) * 0.3)
+    dst = torch.full((n, cout + 2, h, w), 5.0, device=DEV)
+    ops.conv2d(ops.Act(x, 0, cin, sc, sh, 0.2), wt, b, ops.Act(dst, 0, cout))
+    torch.cuda.synchronize()
+    xa = F.leaky_relu(x.double() * sc.double()[:, :, None, None] + sh.double()[:, :, None, None], 0.2)
+    ref = F.conv2d(xa, wt.double(), b.double(), padding=1)
+    assert rel_err(dst[:, :cout].cpu().double(), ref.cpu()) < 3e-6
+    assert float(dst[:, cout:].min()) == 5.0 == float(dst[:, cout:].max())
