@@ -292,7 +292,8 @@ def launch_test(args):
 
 
 ROCPROF_FAMILIES = {      # KernelTimer family -> kernel-name fragments of the rocprofv3 summary (all must match one of the alternatives)
-    "conv3x3_bf16x3": (("conv_bf16x3_kernel<", ", 3, "), ("conv3x3_stream_kernel<",)),
+    # ("!fragment": must NOT occur -- the 2- / 3-channel layers of the persistent kernel, <0, REM>, are not part of the timed family)
+    "conv3x3_bf16x3": (("conv_bf16x3_kernel<", ", 3, "), ("conv3x3_stream_kernel<", "!conv3x3_stream_kernel<0,")),
     "wgrad3x3_bf16x3": (("wgrad_bf16x3_direct_kernel<",),),
     "fft_dc": (("dc_rows320_kernel<0",), ("dc_rows368_kernel<0",)),
     "fft_dc_bwd": (("dc_rows320_kernel<1",), ("dc_rows368_kernel<1",)),
@@ -316,7 +317,7 @@ def rocprof_family_us(profiles_dir):
         for r in csv.DictReader(open(path)):
             name = r["Name"]
             for key, alts in ROCPROF_FAMILIES.items():
-                if any(all(frag in name for frag in alt) for alt in alts):
+                if any(all((frag[1:] not in name) if frag.startswith("!") else (frag in name) for frag in alt) for alt in alts):
                     c, t = fam.get(key, (0, 0.0))
                     fam[key] = (c + int(r["Calls"]), t + float(r["TotalDurationNs"]))
     except (OSError, KeyError, ValueError):

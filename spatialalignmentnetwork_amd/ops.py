@@ -1044,8 +1044,9 @@ def conv2d(x: Act, weight: torch.Tensor, bias: Optional[torch.Tensor], y: Act, s
         def _go():
             done[0] = _bf16x3_launch(ks, bargs, n, h, w, cin, cout, x.buf.device, arena, fin)
 
-        _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * n * h * w * cout * cin * ks * ks, "FLOP",
-               _go, _conv_abytes(n, h, w, cin, cout, ks), _products(fmt != 0))
+        # (the 2- / 3-channel layers of the persistent kernel are their own family: a sixth of a channel block's work is algorithmic)
+        fam = "conv3x3_few_cout" if small else ("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3")
+        _timed(fam, 2.0 * n * h * w * cout * cin * ks * ks, "FLOP", _go, _conv_abytes(n, h, w, cin, cout, ks), _products(fmt != 0))
         return None if done[0] else part
     wp = packed_weight(weight)
     if stats:
@@ -1294,7 +1295,8 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
             ws = GLOBAL_ARENA.scratch("b16_splitk", nbytes, dy.buf.device) if nbytes else None
             gargs = (_p(dy.buf), dy.ctot, dy.coff, cout, _p(wp), _p(dx.buf), dx.ctot, dx.coff, cin, _p(dy.amax), dy.n, dy.h, dy.w,
                      ks, _p(ws), nbytes, _stream())
-            _timed("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3", 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
+            fam = "conv3x3_few_cout" if small else ("conv3x3_bf16x3" if ks == 3 else "conv1x1_bf16x3")
+            _timed(fam, 2.0 * dy.n * dy.h * dy.w * cout * cin * ks * ks, "FLOP",
                    lambda: lib().call("san_conv_bf16x3_dgrad_amax", *gargs), _conv_abytes(dy.n, dy.h, dy.w, cin, cout, ks), 3)
             return
         wp = PACKS16.get(weight, 2)
