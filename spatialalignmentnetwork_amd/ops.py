@@ -1287,7 +1287,8 @@ def conv2d_dgrad(dy: Act, weight: torch.Tensor, dx: Act) -> None:
     cout, cin, ks = weight.shape[0], weight.shape[1], weight.shape[2]
     assert dy.c == cout and dx.c == cin
     small = (STREAM_SMALL_COUT[0] and ks == 3 and cin in (2, 3) and cout >= 16 and USE_BF16X3[0] and dy.amax is not None and _CONV_NP[0] == 3
-             and dy.scale is None and lib().query("san_conv_stream_eligible", dy.n, dy.h, dy.w, cout, cin, dy.ctot))
+             and dy.scale is None and dx.buf.data_ptr() % 16 == 0
+             and lib().query("san_conv_stream_eligible", dy.n, dy.h, dy.w, cout, cin, dy.ctot))
     if small or bf16x3_eligible(cout, cin, dy.h, dy.w, ks):       # the data-gradient conv maps cout -> cin channels
         if dy.amax is not None and _CONV_NP[0] == 3 and dy.scale is None:
             wp = PACKS16.get(weight, 2 + 16)             # two fp16 parts; dy scaled by the power of two its maximum asks for
