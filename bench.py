@@ -112,6 +112,12 @@ def parse_args(argv=None):
                          "(v_mfma_f32_16x16x32_fp8_fp8), gradients on bf16 (BASELINE configs[4]).  FFT / DC / norms / losses are fp32 always")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--brackets-as-shipped", action="store_true",
+                    help="roofline brackets on the launch's own stream only (the duration as shipped, beside whatever the other stream "
+                         "runs) instead of joining the two streams around every bracketed launch (the kernel alone: the default, as in "
+                         "rounds 2-5).  Costs the bracketed step 1 ms instead of 9 (round 6, profiles/r06_ab_bracket_modes.txt: 39.75 vs "
+                         "40.04 ms per step over 20 steps), but the raw event figures then carry dispatch latency under contention: conv "
+                         "0.043 against rocprofv3's 0.050 and the alone figure's 0.053")
     ap.add_argument("--main-only", action="store_true",
                     help="only the timed steps of --mode: no inference / narrow-precision legs after them (profiling runs)")
     ap.add_argument("--graph", action="store_true",
@@ -453,7 +459,7 @@ def main(argv=None):
                 # a second recording of the same step WITH the roofline event brackets (every 10th launch of a conv family,
                 # EVERY cascade-boundary launch, each run alone): it is the LAST of the timed steps, so the HIP-event
                 # figures come from inside the timed region while the other steps run without the brackets' stream joins
-                timer = ops.KernelTimer(stride=10, strides={"fft_dc": 1, "fft_dc_bwd": 1})
+                timer = ops.KernelTimer(stride=10, strides={"fft_dc": 1, "fft_dc_bwd": 1}, alone=not args.brackets_as_shipped)
                 marked = net.record_update(img_full, img_aux, warmup=1, restore=False, timer=timer)
                 graph = marked
                 torch.cuda.synchronize()

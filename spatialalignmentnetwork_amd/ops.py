@@ -32,8 +32,13 @@ class KernelTimer:
     all layers of the periodic cascade structure);
     every launch is still counted, and totals() scales the sampled time up."""
 
-    def __init__(self, stride: int = 29, strides: Optional[dict] = None):
+    def __init__(self, stride: int = 29, strides: Optional[dict] = None, alone: bool = True):
         self.stride = max(1, int(stride))
+        # alone: inside wgrad_overlap a bracketed launch runs ALONE (the other stream is joined before and held until after it: the
+        # kernel's own time, at the price of draining the weight-gradient queue at every bracket).  False (bench.py since round 6): the
+        # brackets only mark the launch on its own stream -- the time AS SHIPPED, beside whatever the other stream runs, which is what
+        # rocprofv3 reports for the same command
+        self.alone = bool(alone)
         self.strides = dict(strides or {})      # per-family override (bench.py brackets EVERY cascade-boundary launch)
         self.recs = []
         self.seen = {}
@@ -57,7 +62,7 @@ class KernelTimer:
         cur = _launch_stream()
         # (through _lib.rec: inside a recorded step the brackets are part of the recording, every replay re-records the
         # same event pairs and totals() reads the last replay's)
-        if side is not None:
+        if side is not None and self.alone:
             other = _WG["main"] if cur == side else side
             _lib.rec(cur.wait_stream, other)
         _lib.rec(e0.record, cur)
